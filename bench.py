@@ -36,26 +36,61 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='mtl512',
+                    help='mtl512 = BASELINE configs[1] (the metric; default); det800 = configs[3] (DINO det step only, 800x800 '
+                         'bs=4); swinb1024 = configs[4] (Swin-B backbone, cls+det+seg round at 1024x1024 bs=1)')
+    ap.add_argument('--size', type=int, default=None, help='override the workload\'s image size')
+    ap.add_argument('--batch', type=int, default=None, help='override the workload\'s per-task batch size')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the eager profiled rounds after the timed region')
     ap.add_argument('--roofline-rounds', type=int, default=2)
     ap.add_argument('--roofline-hold-ms', type=float, default=60.0,
                     help='stream hold ahead of each eager roofline iteration so that its launches queue up')
-    ap.add_argument('--cpu-rounds', type=int, default=1)
+    ap.add_argument('--cpu-rounds', type=int, default=3, help='timed CPU-baseline rounds (after one untimed warm-up round)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--verbose', action='store_true', help='per-iteration wall times on stderr')
     ap.add_argument('--host-trace', action='store_true', help='per-iteration HOST times (no sync) on stderr')
     ap.add_argument('--watchdog', type=int, default=0,
                     help='dump all Python stacks and exit if the run takes longer than this many seconds')
-    return ap.parse_args()
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload]
+    a.size = a.size or w['size']
+    a.batch = a.batch or w['batch']
+    return a
+
+
+# BASELINE.json configs -> what one bench "step" runs.  tasks: the iterations of one step, in order; max_gt: ground truths
+# per image of the synthetic det batches (C2 U{1..20}, C4 U{1..50}); swin_b: configs[4]'s backbone.
+WORKLOADS = {
+    'mtl512': dict(size=512, batch=2, tasks=('cls', 'det', 'seg'), max_gt=20, swin_b=False,
+                   name='configs/multi MTL_slvlcls swin-t-p4-w7 RESISC45+DIOR+Potsdam',
+                   metric='images/sec MTL train step (Swin-T 512^2, bs=2/GPU)'),
+    'det800': dict(size=800, batch=4, tasks=('det',), max_gt=50, swin_b=False,
+                   name='configs/det DIOR Deformable-DETR (DINO) head only on the MTL trunk (Swin-T + ChannelMapper + shared '
+                        'encoder)',
+                   metric='images/sec det train step (Swin-T 800^2, bs=4/GPU)'),
+    'swinb1024': dict(size=1024, batch=1, tasks=('cls', 'det', 'seg'), max_gt=20, swin_b=True,
+                      name='Swin-B backbone MTL RESISC45+DIOR+Potsdam',
+                      metric='images/sec MTL train step (Swin-B 1024^2, bs=1/GPU)'),
+}
+
+
+def workload_model_cfg(cfg, workload):
+    """The model config of a workload: configs[4] swaps the backbone for Swin-B (embed 128, depths 2-2-18-2, heads
+    4-8-16-32; neck / cls head inputs follow) — SURVEY.md 8d C5."""
+    import copy
+    m = copy.deepcopy(cfg.model)
+    if WORKLOADS[workload]['swin_b']:
+        m['backbone'].update(embed_dims=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32))
+        m['neck']['in_channels'] = [256, 512, 1024]
+        m['cls_head']['in_channels'] = 1024
+    return m
 
 
 CPU_THREADS_CAP = 32  # host threads for the oracle (more only adds scheduling overhead on these op sizes)
 
 
-def cpu_baseline_worker(size, batch, rounds):
+def cpu_baseline_worker(size, batch, rounds, workload='mtl512'):
     """Oracle (plain PyTorch fp32 on the host cores) on the same workload: forward, loss, backward,
     clip, AdamW for `rounds` rounds of cls+det+seg.  Runs in its own process (see cpu_baseline)."""
     import copy
@@ -65,35 +100,41 @@ def cpu_baseline_worker(size, batch, rounds):
     threads = min(os.cpu_count() or 1, CPU_THREADS_CAP)
     torch.set_num_threads(threads)
     cfg = Config.fromfile(CFG)
+    wl = WORKLOADS[workload]
+    mcfg = workload_model_cfg(cfg, workload)
     torch.manual_seed(0)
-    model = MODELS.build(copy.deepcopy(cfg.model))
+    model = MODELS.build(copy.deepcopy(mcfg))
     model.init_weights()
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
     opt = OracleOptimizer({k: v for k, v in P.items() if v.requires_grad}, cfg.optimizer, max_norm=0.1)
-    t0 = time.time()
-    n_img = 0
-    for r in range(rounds):
-        for task in ('cls', 'det', 'seg'):
-            b = synth.make_batch(task, batch, size, seed=9000 + r)
+
+    def one_round(r):
+        for task in wl['tasks']:
+            b = synth.make_batch(task, batch, size, seed=9000 + r, max_gt=wl['max_gt'])
             rnd = synth.make_rnd(model, b, seed=r)
-            out = OM.train_step(P, cfg.model, b, rnd)
+            out = OM.train_step(P, mcfg, b, rnd)
             opt.zero_grad()
             out['loss'].backward()
             opt.step()
-            n_img += batch
+
+    one_round(-1)  # warm-up round (thread pools, allocator, oneDNN primitive caches): not timed
+    t0 = time.time()
+    for r in range(rounds):
+        one_round(r)
     dt = time.time() - t0
+    n_img = rounds * batch * len(wl['tasks'])
     print(json.dumps(dict(value=n_img / dt, unit='images/s', cores=threads, kind='port',
-                          sample=f'{rounds} round(s) of cls+det+seg at {size}x{size}, B={batch}/task '
-                                 f'({n_img} images), fwd+loss+bwd+clip+AdamW, oracle (plain PyTorch fp32) on '
-                                 f'{threads} host threads of {os.cpu_count()} logical CPUs, {dt:.1f}s')))
+                          sample=f'1 warm-up + {rounds} timed round(s) of {"+".join(wl["tasks"])} at {size}x{size}, '
+                                 f'B={batch}/task ({n_img} images timed), fwd+loss+bwd+clip+AdamW, oracle (plain PyTorch fp32) '
+                                 f'on {threads} host threads of {os.cpu_count()} logical CPUs, {dt:.1f}s')))
 
 
-def cpu_baseline(size, batch, rounds, limit_s=420):
+def cpu_baseline(size, batch, rounds, workload='mtl512', limit_s=420):
     """Bounded CPU baseline: the oracle timed in a child process with a hard time limit, so a slow
     host can never hang the benchmark.  kind = "port": the reference itself cannot be imported."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(size), '--batch', str(batch),
-           '--cpu-rounds', str(rounds)]
+           '--cpu-rounds', str(rounds), '--workload', workload]
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
@@ -109,7 +150,7 @@ def cpu_baseline(size, batch, rounds, limit_s=420):
 def main():
     a = parse()
     if a.cpu_baseline_worker:
-        return cpu_baseline_worker(a.size, a.batch, a.cpu_rounds)
+        return cpu_baseline_worker(a.size, a.batch, a.cpu_rounds, a.workload)
     if a.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(a.watchdog, exit=True)
@@ -133,12 +174,15 @@ def main():
     from rscotr_amd.runner import build_runner
 
     cfg = Config.fromfile(CFG)
+    wl = WORKLOADS[a.workload]
+    ntask = len(wl['tasks'])
     torch.manual_seed(0)  # identical init on all ranks
     np.random.seed(2022)  # identical task order / augment choice on all ranks (tools/train.py:211-215)
-    model = MODELS.build(copy.deepcopy(cfg.model))
+    model = MODELS.build(workload_model_cfg(cfg, a.workload))
     model.init_weights()
     model.to(dev).train()
-    loader = build_synthetic_multidataloader(cfg, dev, size=a.size, batch_size=a.batch, rank=rank)
+    loader = build_synthetic_multidataloader(cfg, dev, size=a.size, batch_size=a.batch, rank=rank, tasks=wl['tasks'],
+                                             max_gt=wl['max_gt'])
     runner = build_runner(model, cfg, loader)
 
     hold = dict(cycles=0)  # > 0: park the stream this many spin cycles before every iteration (roofline rounds)
@@ -146,7 +190,7 @@ def main():
     timing = dict(on=False)
 
     def one_round():
-        for _ in range(3):
+        for _ in range(ntask):
             if hold['cycles']:
                 # the eager host path issues ~3000 launches per iteration slower than the GPU drains them; parking
                 # the stream first lets the whole iteration queue up, so the kernels (and the events around them)
@@ -198,7 +242,7 @@ def main():
         per_task.setdefault(task, []).append(prev.elapsed_time(ev))
         prev = ev
     per_task = {t: round(sum(v) / len(v), 3) for t, v in per_task.items()}
-    if world == 1 and runner.graphed and not a.no_roofline:
+    if runner.graphed and not a.no_roofline:  # every rank runs these rounds (they hold collectives); rank 0 records
         # The timed region replays hipGraphs, which cannot carry per-kernel HIP events.  The rooflines are
         # therefore sampled on the same process, model and stream directly after it: the same iterations
         # launched eagerly (identical kernels, arguments and shapes) with the library recording a pair of
@@ -212,14 +256,15 @@ def main():
         runner.force_eager = True
         one_round()  # un-profiled: allocator / workspaces of the eager path
         torch.cuda.synchronize()
-        lib.call('rscotr_prof_enable', PROF_EVERY_GEMM, 1, 1, 8192)
+        if rank == 0:
+            lib.call('rscotr_prof_enable', PROF_EVERY_GEMM, 1, 1, 8192)
         for _ in range(a.roofline_rounds):
             one_round()
         torch.cuda.synchronize()
         runner.force_eager = False
         hold['cycles'] = 0
     prof = []
-    if rank == 0 and not a.no_roofline and (eager_timed or (world == 1 and runner.graphed)):
+    if rank == 0 and not a.no_roofline and (eager_timed or runner.graphed):
         import ctypes
         torch.cuda.synchronize()
         n = lib.rscotr_prof_pause()
@@ -236,7 +281,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        images = 3 * a.batch * world * a.steps
+        images = ntask * a.batch * world * a.steps
         # rooflines from HIP events recorded around the launches inside the timed region (on the launch
         # stream): algorithmic work of the sampled launches / their summed duration.
         def group(kind):
@@ -317,21 +362,21 @@ def main():
                 r_b['traffic'] = sum(tb(v) * v['dispatches'] for v in bw) / calls
         except (OSError, KeyError, ValueError):
             pass
-        out = dict(metric='images/sec MTL train step (Swin-T 512^2, bs=2/GPU)', value=images / dt, unit='images/s',
+        out = dict(metric=wl['metric'], value=images / dt, unit='images/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32' if lib.rscotr_gemm_get_precision() == 0 else 'f32 (large products: 3x bf16 MFMA on hi/lo splits, fp32 accumulate)',
                    data='synthetic',
-                   config=dict(workload='configs/multi MTL_slvlcls swin-t-p4-w7 RESISC45+DIOR+Potsdam, '
-                                        f'{a.size}x{a.size} bs={a.batch}/task/GPU',
-                               step='one round-robin round = cls+det+seg train iterations',
-                               images_per_step=3 * a.batch * world, parallelism=f'dp{world}',
+                   config=dict(workload=f'{a.workload}: {wl["name"]}, {a.size}x{a.size} bs={a.batch}/task/GPU',
+                               step=('one round-robin round = ' + '+'.join(wl['tasks']) + ' train iterations') if ntask > 1
+                               else f'one {wl["tasks"][0]} train iteration',
+                               images_per_step=ntask * a.batch * world, parallelism=f'dp{world}',
                                optimizer='AdamW+clip0.1 (fused HIP)', precision='fp32',
                                gemm_precision_mode={0: 'fp32', 1: 'bf16x3', 2: 'bf16x3-big'}[lib.rscotr_gemm_get_precision()],
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds)
+            out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

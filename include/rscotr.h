@@ -190,12 +190,15 @@ int rscotr_layernorm_flush(const int64_t* table, const int32_t* wgmap, int nwg, 
  *   qkv_bias (3C) or NULL: value of q/k/v on zero-padding tokens (the upstream Linear runs on them);
  *   bias_table (169, heads); out / dout (B, H*W, C), channel = head*32 + d.  ws must be 7, C = heads*32.
  * Backward recomputes the probabilities; dqkv (B, H*W, 3C) is fully overwritten; dqkv_bias (3C, pad-token
- * contributions only) and dbias_table (169, heads) are ACCUMULATED (caller zeroes); either may be NULL. */
+ * contributions only) and dbias_table (169, heads) are ACCUMULATED (caller zeroes); either may be NULL.  workspace:
+ * rscotr_swin_wattn_bwd_workspace() bytes of per-workgroup partial rows of those two gradients, folded in fixed order
+ * by a second launch (no global atomics: bit-reproducible). */
 int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
                           int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, int heads);
 int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* dout,
                           float* dqkv, float* dqkv_bias, float* dbias_table, int B, int H, int W, int C,
-                          int heads, int ws, int shift, void* stream);
+                          int heads, int ws, int shift, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- ChannelMapper neck in token layout -----------------------------------------------------------
  * mmdet ChannelMapper (configs/multi/MTL_slvlcls_...potsdam.py:26-33; models/multi/multitask_learner.py:84):
@@ -204,12 +207,16 @@ int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* 
  * position, column = c*9 + ky*3 + kx, the Conv2d weight's own (C, kH, kW) flattening), its input gradient
  * is rscotr_col2im3x3s2_tokens of the GEMM's dcol; GroupNorm(32, 256) runs on tokens.
  *   x, y, dy, dx (B, L, C) with C in {64, 128, 256}; mean_rstd (B, G, 2) written by forward; proj_ws (B, G, 2)
- *   scratch; dweight/dbias (C) ACCUMULATED (caller zeroes), may be NULL.  Ho = (H+1)/2, Wo = (W+1)/2. */
+ *   scratch; dweight/dbias (C) ACCUMULATED (caller zeroes), may be NULL.  Ho = (H+1)/2, Wo = (W+1)/2.
+ *   workspace: rscotr_groupnorm_tokens_workspace() bytes of per-workgroup partial sums, folded in fixed order (no
+ *   atomics: the statistics are bit-reproducible). */
+int64_t rscotr_groupnorm_tokens_workspace(int B, int L, int C, int G);
 int rscotr_groupnorm_tokens_fwd(const float* x, const float* weight, const float* bias, float* y,
-                                float* mean_rstd, int B, int L, int C, int G, float eps, void* stream);
+                                float* mean_rstd, int B, int L, int C, int G, float eps, float* workspace,
+                                int64_t workspace_bytes, void* stream);
 int rscotr_groupnorm_tokens_bwd(const float* dy, const float* x, const float* weight, const float* mean_rstd,
                                 float* dx, float* dweight, float* dbias, float* proj_ws, int B, int L, int C,
-                                int G, void* stream);
+                                int G, float* workspace, int64_t workspace_bytes, void* stream);
 int rscotr_im2col3x3s2_tokens(const float* x, float* col, int B, int H, int W, int C, void* stream);
 int rscotr_col2im3x3s2_tokens(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
 
@@ -218,10 +225,13 @@ int rscotr_col2im3x3s2_tokens(const float* dcol, float* dx, int B, int H, int W,
  * reduction='none') -> mean over ALL pixels; accuracy over the non-ignored ones) reached from
  * models/multi/seg_head/mask2former_head.py:204, without materialising the (B,C,H,W) upsampled logits.
  *   logit (B,C,h,w); label (B,H,W) int64; lse (B,H,W) per-pixel log-sum-exp saved for backward;
- *   sums[3] = {sum of CE over non-ignored pixels, #correct, #non-ignored} (zeroed inside);
+ *   sums[3] = {sum of CE over non-ignored pixels, #correct, #non-ignored} (written; per-workgroup partials in
+ *   `workspace` (rscotr_upsample_ce_workspace() bytes) folded in fixed order: bit-reproducible, no atomics);
  *   backward: dlogit (B,C,h,w) = grad_scale[0] * d(sums[0])/d(logit), grad_scale a DEVICE scalar. */
+int64_t rscotr_upsample_ce_workspace(void);
 int rscotr_upsample_ce_fwd(const float* logit, const int64_t* label, float* lse, float* sums, int B, int C,
-                           int h, int w, int H, int W, int ignore_index, void* stream);
+                           int h, int w, int H, int W, int ignore_index, float* workspace, int64_t workspace_bytes,
+                           void* stream);
 int rscotr_upsample_ce_bwd(const float* logit, const int64_t* label, const float* lse, const float* grad_scale,
                            float* dlogit, int B, int C, int h, int w, int H, int W, int ignore_index, void* stream);
 
@@ -283,8 +293,9 @@ int rscotr_lsap_batch_f32(const float* cost, const int64_t* offsets, const int* 
  * arenas with identical offsets; chunk k covers chunk_len[k] (multiple of 4) elements at
  * chunk_off[k] (multiple of 4) inside segment chunk_seg[k]; seg_dyn holds 8 floats per segment:
  * {lr, weight_decay, 1/bias_correction1, 1/sqrt(bias_correction2), live(0/1), 0, 0, 0}.
- * rscotr_grad_sumsq ADDS the squared L2 norm of the live segments' gradients into *sumsq (caller
- * zeroes it); rscotr_adamw_clip_step applies coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) (skipped
+ * rscotr_grad_sumsq WRITES the squared L2 norm of the live segments' gradients to sumsq[0]; sumsq is a
+ * buffer of 1 + 1024 floats (sumsq[1..] = per-workgroup partials, folded in fixed order: bit-reproducible,
+ * no atomics); rscotr_adamw_clip_step applies coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) (skipped
  * when max_norm <= 0) and the decoupled-weight-decay Adam update of torch 1.11 to live segments. */
 int rscotr_grad_sumsq(const float* grad, const int32_t* chunk_seg, const int64_t* chunk_off,
                       const int32_t* chunk_len, const float* seg_dyn, int nchunks, float* sumsq,

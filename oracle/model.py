@@ -268,10 +268,10 @@ def mlvl_memories(neck_feats, P, pre, T, enc_layers, nlev=4, strides=(4, 8, 16, 
         poss.append((lvl.view(1, -1, 1, 1) + pe).flatten(2).permute(2, 0, 1))
         inputs.append(f.flatten(2).permute(2, 0, 1))
         shapes.append((h, w))
-        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.get_default_dtype()), torch.arange(w, dtype=torch.get_default_dtype()), indexing='ij')
         stride = strides[len(neck_feats) - i - 1]
         pts = torch.stack([(xs.reshape(-1) + 0.5) * stride, (ys.reshape(-1) + 0.5) * stride], -1)
-        refs.append(pts / (torch.tensor([[w, h]], dtype=torch.float32) * stride))
+        refs.append(pts / (torch.tensor([[w, h]], dtype=torch.get_default_dtype()) * stride))
     x = torch.cat(inputs, 0)
     pos = torch.cat(poss, 0)
     ref = torch.cat(refs, 0)[None, :, None].repeat(B, 1, nlev, 1)
@@ -312,7 +312,7 @@ def cls_features(feats, neck, P, cfg, enc_layers):
 
 def apply_cls_augment(img, gt_label, num_classes, aug):
     """aug: dict(kind='identity'|'mixup'|'cutmix', lam, index (B,), bbox=(y1,y2,x1,x2))."""
-    onehot = F.one_hot(gt_label, num_classes).float()
+    onehot = F.one_hot(gt_label, num_classes).to(torch.get_default_dtype())
     if aug is None or aug['kind'] == 'identity':
         return img, onehot
     idx = aug['index']
@@ -400,7 +400,7 @@ def seg_losses(seg_logit, gt_semantic_seg, ignore_index=255):
     losses['loss_ce'] = ce.mean()
     pred = up.argmax(1)
     valid = lab != ignore_index
-    correct = ((pred == lab) & valid).float().sum()
+    correct = ((pred == lab) & valid).to(torch.get_default_dtype()).sum()
     losses['acc_seg'] = (correct * (100.0 / (valid.sum().item() + ops.FP32_EPS))).reshape(1)
     return losses
 
@@ -479,7 +479,7 @@ def cdn_queries(gt_bboxes, gt_labels, img_shapes, P, rnd, num_classes=20, num_qu
 def gen_sineembed(pos):
     """transformer.py:43-76 (4-d case)."""
     scale = 2 * math.pi
-    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = torch.arange(128, dtype=torch.get_default_dtype())
     dim_t = 10000 ** (2 * (dim_t // 2) / 128)
     outs = []
     for i in (1, 0, 2, 3):  # y, x, w, h
@@ -523,8 +523,8 @@ def det_forward(neck_feats, img_shapes, batch_shape, P, cfg, enc_layers, dn=None
     vr = []
     for m in masks:
         _, H, W = m.shape
-        vh = torch.sum(~m[:, :, 0], 1).float() / H
-        vw = torch.sum(~m[:, 0, :], 1).float() / W
+        vh = torch.sum(~m[:, :, 0], 1).to(torch.get_default_dtype()) / H
+        vw = torch.sum(~m[:, 0, :], 1).to(torch.get_default_dtype()) / W
         vr.append(torch.stack([vw, vh], -1))
     valid_ratios = torch.stack(vr, 1)  # (B,L,2)
     ref_list = []
@@ -635,8 +635,10 @@ def _loss_from_targets(cls_scores, bbox_preds, labels, bbox_targets, bbox_weight
     return loss_cls, loss_bbox, loss_iou
 
 
-def det_loss_single(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_shapes, num_classes=20, record=None):
-    """detr_head.py:333-416 incl. Hungarian target assignment (:475-543)."""
+def det_loss_single(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_shapes, num_classes=20, record=None, inject=None):
+    """detr_head.py:333-416 incl. Hungarian target assignment (:475-543).  `inject` (tests only): per image a dict with
+    the assignment (pos_inds, pos_assigned_gt_inds) to use instead of solving — the fp64 evaluation of a step takes the
+    fp32 evaluation's hard decisions so that the continuous part is compared under identical decisions."""
     B, Q = bbox_preds.shape[:2]
     labels_l, bt_l, bw_l = [], [], []
     npos = nneg = 0
@@ -649,6 +651,8 @@ def det_loss_single(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_shapes, nu
         if G > 0:
             cost = ops.match_cost(cls_scores[i].detach(), bbox_preds[i].detach(), gt_bboxes[i], gt_labels[i], iw, ih)
             pos, gti = ops.hungarian_assign(cost)
+            if inject is not None:
+                pos, gti = inject[i]['pos_inds'], inject[i]['pos_assigned_gt_inds']
         else:
             cost = torch.zeros(Q, 0)
             pos = gti = torch.zeros(0, dtype=torch.long)
@@ -700,19 +704,21 @@ def det_loss_dn_single(dn_cls, dn_box, gt_bboxes, gt_labels, img_shapes, dn_meta
 
 
 def det_losses(all_cls, all_box, topk_score, topk_anchor, gt_bboxes, gt_labels, img_shapes, dn_meta,
-               num_classes=20, record=None):
-    """dino_head.py:152-234."""
+               num_classes=20, record=None, inject_match=None):
+    """dino_head.py:152-234.  inject_match: {'interm' | 'dec{l}': [per-image assignment dicts]} (see det_loss_single)."""
+    inj = inject_match or {}
     pad = dn_meta['pad_size'] if dn_meta is not None else 0
     m_cls, m_box = all_cls[:, :, pad:], all_box[:, :, pad:]
     d = OrderedDict()
     rec = None if record is None else record.setdefault('interm', [])
     d['interm_loss_cls'], d['interm_loss_bbox'], d['interm_loss_iou'] = det_loss_single(
-        topk_score, topk_anchor, gt_bboxes, gt_labels, img_shapes, num_classes, rec)
+        topk_score, topk_anchor, gt_bboxes, gt_labels, img_shapes, num_classes, rec, inj.get('interm'))
     n = all_cls.shape[0]
     per = []
     for l in range(n):
         rec = None if record is None else record.setdefault(f'dec{l}', [])
-        per.append(det_loss_single(m_cls[l], m_box[l], gt_bboxes, gt_labels, img_shapes, num_classes, rec))
+        per.append(det_loss_single(m_cls[l], m_box[l], gt_bboxes, gt_labels, img_shapes, num_classes, rec,
+                                   inj.get(f'dec{l}')))
     d['loss_cls'], d['loss_bbox'], d['loss_iou'] = per[-1]
     for l in range(n - 1):
         d[f'd{l}.loss_cls'], d[f'd{l}.loss_bbox'], d[f'd{l}.loss_iou'] = per[l]
@@ -773,7 +779,7 @@ def forward_train(P, cfg, batch, rnd=None, record=None):
         record['det_outs'] = outs
         record['match'] = {}
     return det_losses(*outs, batch['gt_bboxes'], batch['gt_labels'], img_shapes, dn_meta, hcfg['num_classes'],
-                      None if record is None else record['match'])
+                      None if record is None else record['match'], inject_match=rnd.get('det_match'))
 
 
 def parse_losses(losses):

@@ -84,12 +84,12 @@ def sine_positional_encoding(mask, num_feats=128, temperature=10000, normalize=T
     """mmdet SinePositionalEncoding.forward; mask (B,H,W) bool (True = padded) -> (B,2*num_feats,H,W)."""
     mask = mask.to(torch.int)
     not_mask = 1 - mask
-    y_embed = not_mask.cumsum(1, dtype=torch.float32)
-    x_embed = not_mask.cumsum(2, dtype=torch.float32)
+    y_embed = not_mask.cumsum(1, dtype=torch.get_default_dtype())
+    x_embed = not_mask.cumsum(2, dtype=torch.get_default_dtype())
     if normalize:
         y_embed = (y_embed + offset) / (y_embed[:, -1:, :] + eps) * scale
         x_embed = (x_embed + offset) / (x_embed[:, :, -1:] + eps) * scale
-    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = torch.arange(num_feats, dtype=torch.get_default_dtype())
     dim_t = temperature ** (2 * (dim_t // 2) / num_feats)
     pos_x = x_embed[:, :, :, None] / dim_t
     pos_y = y_embed[:, :, :, None] / dim_t

@@ -13,8 +13,9 @@
 //
 // GroupNorm mapping: one wavefront per token row per step (C/4 lanes hold the row as float4, a
 // group of 8 channels = 2 adjacent lanes); per-(image, group) sums are lane-pair + LDS reductions
-// and a handful of atomics per workgroup into a (B, G, 2) table; a second pass applies the affine
-// transform.  All HBM-streaming: forward reads x twice and writes y once.
+// into one partial row per workgroup (caller workspace), folded in fixed order by the finalize
+// kernel — no atomics: the statistics, hence the whole forward pass, are bit-reproducible; a second
+// pass applies the affine transform.  All HBM-streaming: forward reads x twice and writes y once.
 #include "common.h"
 
 namespace rscotr {
@@ -25,9 +26,9 @@ namespace rscotr {
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ mean_rstd, float* __restrict__ sums,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int L,
-                                                       int C, int G, int tokens_per_block) {
+                                                       const float* __restrict__ mean_rstd, float* __restrict__ part,
+                                                       int L, int C, int G, int tokens_per_block) {
+  // part: [B][chunks][2 G + 2 C] = {sum f, sum f h} per group, then (MODE 1) dgamma | dbeta partials per channel
   const int LT = C >> 2;            // lanes per token row
   const int TPW = kWave / LT;       // token rows per wavefront step
   const int gs4 = (C / G) >> 2;     // lanes per group
@@ -87,27 +88,59 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     float v[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) v[k] = red[0][sub][k] + red[1][sub][k] + red[2][sub][k] + red[3][sub][k];
+    float* row = part + ((long)b * gridDim.x + blockIdx.x) * (2 * G + 2 * C);
     if (sub % gs4 == 0) {
-      unsafeAtomicAdd(sums + ((long)b * G + g) * 2, v[0]);
-      unsafeAtomicAdd(sums + ((long)b * G + g) * 2 + 1, v[1]);
+      row[2 * g] = v[0];
+      row[2 * g + 1] = v[1];
     }
     if (MODE == 1) {
-      if (dgamma)
-        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dgamma + sub * 4 + k, v[2 + k]);
-      if (dbeta)
-        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dbeta + sub * 4 + k, v[6 + k]);
+      for (int k = 0; k < 4; ++k) row[2 * G + sub * 4 + k] = v[2 + k];
+      for (int k = 0; k < 4; ++k) row[2 * G + C + sub * 4 + k] = v[6 + k];
     }
   }
 }
 
-// sums -> (mean, rstd) in place
-__global__ void gn_finalize_kernel(float* __restrict__ sums, int n_groups, float inv_count, float eps) {
+// partial rows -> (mean, rstd): fixed summation order over the chunks
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_rstd, int B, int G, int C,
+                                   int chunks, float inv_count, float eps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_groups) return;
-  const float mu = sums[2 * i] * inv_count;
-  const float var = fmaxf(sums[2 * i + 1] * inv_count - mu * mu, 0.f);
-  sums[2 * i] = mu;
-  sums[2 * i + 1] = rsqrtf(var + eps);
+  if (i >= B * G) return;
+  const int b = i / G, g = i - b * G;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* row = part + ((long)b * chunks + c) * (2 * G + 2 * C);
+    s1 += row[2 * g];
+    s2 += row[2 * g + 1];
+  }
+  const float mu = s1 * inv_count;
+  const float var = fmaxf(s2 * inv_count - mu * mu, 0.f);
+  mean_rstd[2 * i] = mu;
+  mean_rstd[2 * i + 1] = rsqrtf(var + eps);
+}
+
+// backward: proj[b][g] = the two projections; dgamma / dbeta (+)= their per-channel sums over images and chunks (fixed order)
+__global__ void gn_finalize_bwd_kernel(const float* __restrict__ part, float* __restrict__ proj, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int B, int G, int C, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * G) {
+    const int b = i / G, g = i - b * G;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+      const float* row = part + ((long)b * chunks + c) * (2 * G + 2 * C);
+      s1 += row[2 * g];
+      s2 += row[2 * g + 1];
+    }
+    proj[2 * i] = s1;
+    proj[2 * i + 1] = s2;
+  }
+  if (i < 2 * C) {  // i < C: dgamma[i], else dbeta[i - C]
+    float* dst = i < C ? dgamma : dbeta;
+    if (dst) {
+      float s = 0.f;
+      for (int r = 0; r < B * chunks; ++r) s += part[(long)r * (2 * G + 2 * C) + 2 * G + i];
+      dst[i < C ? i : i - C] += s;
+    }
+  }
 }
 
 // MODE 0: y = (x - mean) * rstd * gamma + beta
@@ -206,20 +239,29 @@ static dim3 gn_stats_grid(int B, int L, int* tpb) {
 
 using namespace rscotr;
 
+extern "C" int64_t rscotr_groupnorm_tokens_workspace(int B, int L, int C, int G) {
+  if (B <= 0 || L <= 0 || C <= 0 || G <= 0) return 0;
+  int tpb;
+  const dim3 grid = gn_stats_grid(B, L, &tpb);
+  return (int64_t)B * grid.x * (2 * G + 2 * C) * 4;
+}
+
 extern "C" int rscotr_groupnorm_tokens_fwd(const float* x, const float* weight, const float* bias, float* y,
-                                           float* mean_rstd, int B, int L, int C, int G, float eps, void* stream) {
+                                           float* mean_rstd, int B, int L, int C, int G, float eps, float* workspace,
+                                           int64_t workspace_bytes, void* stream) {
   if (int e = gn_check("rscotr_groupnorm_tokens_fwd", B, L, C, G)) return e;
   if (B == 0 || L == 0) return RSCOTR_OK;
   if (!x || !y || !mean_rstd) return fail(RSCOTR_E_ARG, "rscotr_groupnorm_tokens_fwd: null pointer");
   if (!aligned16(x) || !aligned16(y) || (weight && !aligned16(weight)) || (bias && !aligned16(bias)))
     return fail(RSCOTR_E_ALIGN, "rscotr_groupnorm_tokens_fwd: pointers must be 16-byte aligned");
+  if (!workspace || workspace_bytes < rscotr_groupnorm_tokens_workspace(B, L, C, G))
+    return fail(RSCOTR_E_ARG, "rscotr_groupnorm_tokens_fwd: workspace of rscotr_groupnorm_tokens_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(mean_rstd, 0, (size_t)B * G * 2 * sizeof(float), s);
   int tpb;
   const dim3 grid = gn_stats_grid(B, L, &tpb);
-  gn_stats_kernel<0><<<grid, 256, 0, s>>>(x, nullptr, nullptr, nullptr, mean_rstd, nullptr, nullptr, L, C, G, tpb);
+  gn_stats_kernel<0><<<grid, 256, 0, s>>>(x, nullptr, nullptr, nullptr, workspace, L, C, G, tpb);
   const float inv = 1.f / ((float)L * (float)(C / G));
-  gn_finalize_kernel<<<(B * G + 255) / 256, 256, 0, s>>>(mean_rstd, B * G, inv, eps);
+  gn_finalize_kernel<<<(B * G + 255) / 256, 256, 0, s>>>(workspace, mean_rstd, B, G, C, (int)grid.x, inv, eps);
   const int ax = (int)std::min<long>(((long)L * (C / 4) + 255) / 256, 1024);
   gn_apply_kernel<0><<<dim3(ax, B), 256, 0, s>>>(x, nullptr, weight, bias, mean_rstd, nullptr, y, L, C, G, inv);
   return check_launch("rscotr_groupnorm_tokens_fwd");
@@ -227,17 +269,21 @@ extern "C" int rscotr_groupnorm_tokens_fwd(const float* x, const float* weight, 
 
 extern "C" int rscotr_groupnorm_tokens_bwd(const float* dy, const float* x, const float* weight,
                                            const float* mean_rstd, float* dx, float* dweight, float* dbias,
-                                           float* proj_ws, int B, int L, int C, int G, void* stream) {
+                                           float* proj_ws, int B, int L, int C, int G, float* workspace,
+                                           int64_t workspace_bytes, void* stream) {
   if (int e = gn_check("rscotr_groupnorm_tokens_bwd", B, L, C, G)) return e;
   if (B == 0 || L == 0) return RSCOTR_OK;
   if (!dy || !x || !mean_rstd || !dx || !proj_ws) return fail(RSCOTR_E_ARG, "rscotr_groupnorm_tokens_bwd: null pointer");
   if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || (weight && !aligned16(weight)))
     return fail(RSCOTR_E_ALIGN, "rscotr_groupnorm_tokens_bwd: pointers must be 16-byte aligned");
+  if (!workspace || workspace_bytes < rscotr_groupnorm_tokens_workspace(B, L, C, G))
+    return fail(RSCOTR_E_ARG, "rscotr_groupnorm_tokens_bwd: workspace of rscotr_groupnorm_tokens_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(proj_ws, 0, (size_t)B * G * 2 * sizeof(float), s);
   int tpb;
   const dim3 grid = gn_stats_grid(B, L, &tpb);
-  gn_stats_kernel<1><<<grid, 256, 0, s>>>(x, dy, weight, mean_rstd, proj_ws, dweight, dbias, L, C, G, tpb);
+  gn_stats_kernel<1><<<grid, 256, 0, s>>>(x, dy, weight, mean_rstd, workspace, L, C, G, tpb);
+  gn_finalize_bwd_kernel<<<(std::max(B * G, 2 * C) + 255) / 256, 256, 0, s>>>(workspace, proj_ws, dweight, dbias, B, G, C,
+                                                                              (int)grid.x);
   const float inv = 1.f / ((float)L * (float)(C / G));
   const int ax = (int)std::min<long>(((long)L * (C / 4) + 255) / 256, 1024);
   gn_apply_kernel<1><<<dim3(ax, B), 256, 0, s>>>(x, dy, weight, nullptr, mean_rstd, proj_ws, dx, L, C, G, inv);

@@ -19,9 +19,11 @@ namespace rscotr {
 
 constexpr int SEG_STRIDE = 8;  // floats per segment row
 
-// Grid-stride over the chunk table: a workgroup folds all its chunks locally and issues ONE atomic.  (One atomic per
-// 4096-element chunk = 15 k same-address fp32 atomics per step, which execute one after the other at the memory side on
-// MI355X: 143 us for a 200 MB pass; 1024 workgroups: the pass is HBM-bound again.)
+// Grid-stride over the chunk table: a workgroup folds all its chunks locally and stores ONE partial; a one-workgroup
+// kernel folds the <= SUMSQ_PARTS partials in fixed order (no atomics: the clip coefficient, hence every updated weight,
+// is bit-reproducible).  (One atomic per 4096-element chunk = 15 k same-address fp32 atomics per step, which execute one
+// after the other at the memory side on MI355X: 143 us for a 200 MB pass.)
+constexpr int SUMSQ_PARTS = 1024;
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ chunk_seg,
     const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ chunk_len,
@@ -41,10 +43,17 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = part[0] + part[1] + part[2] + part[3];
-    if (t != 0.f) unsafeAtomicAdd(sumsq, t);
-  }
+  if (threadIdx.x == 0) sumsq[1 + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void grad_sumsq_final_kernel(float* __restrict__ sumsq, int nparts) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += sumsq[1 + i];
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sumsq[0] = part[0] + part[1] + part[2] + part[3];
 }
 
 __global__ __launch_bounds__(256) void adamw_clip_kernel(
@@ -102,8 +111,10 @@ extern "C" int rscotr_grad_sumsq(const float* grad, const int32_t* chunk_seg, co
   if (!grad || !chunk_seg || !chunk_off || !chunk_len || !seg_dyn || !sumsq)
     return fail(RSCOTR_E_ARG, "rscotr_grad_sumsq: null pointer");
   if (!aligned16(grad)) return fail(RSCOTR_E_ALIGN, "rscotr_grad_sumsq: grad must be 16-byte aligned");
-  grad_sumsq_kernel<<<dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream>>>(
+  const int nparts = nchunks < SUMSQ_PARTS ? nchunks : SUMSQ_PARTS;
+  grad_sumsq_kernel<<<dim3(nparts), dim3(256), 0, (hipStream_t)stream>>>(
       grad, chunk_seg, chunk_off, chunk_len, seg_dyn, sumsq, nchunks);
+  grad_sumsq_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(sumsq, nparts);
   return check_launch("rscotr_grad_sumsq");
 }
 

@@ -71,10 +71,24 @@ __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __res
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) { red[wv][0] = loss; red[wv][1] = correct; red[wv][2] = valid; }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    unsafeAtomicAdd(sums + threadIdx.x, t);
-  }
+  if (threadIdx.x < 3)  // one partial row per workgroup, folded in fixed order by upsample_ce_sums_kernel (no atomics)
+    sums[(long)blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void upsample_ce_sums_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                                               int nparts) {
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nparts; i += 256)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] += part[(long)i * 3 + k];
+  __shared__ float red[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) a[k] = wave_sum(a[k]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 3) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // grid = B*h*w low-resolution cells, 128 threads: lane = class; gathers
@@ -214,18 +228,27 @@ extern "C" int rscotr_seg_attn_mask(const float* mask_pred, unsigned char* out, 
 
 
 // sums[3] = {sum of per-pixel CE over non-ignored pixels, #correct, #non-ignored}; lse (B,H,W) saved.
+constexpr int UCE_MAX_WG = 4096;
+extern "C" int64_t rscotr_upsample_ce_workspace(void) { return (int64_t)UCE_MAX_WG * 3 * 4; }
+
 extern "C" int rscotr_upsample_ce_fwd(const float* logit, const int64_t* label, float* lse, float* sums, int B,
-                                      int C, int h, int w, int H, int W, int ignore_index, void* stream) {
+                                      int C, int h, int w, int H, int W, int ignore_index, float* workspace,
+                                      int64_t workspace_bytes, void* stream) {
   if (B < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
     return fail(RSCOTR_E_SHAPE, "rscotr_upsample_ce_fwd: bad shape");
   if (!sums) return fail(RSCOTR_E_ARG, "rscotr_upsample_ce_fwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(sums, 0, 3 * sizeof(float), s);
-  if (B == 0) return RSCOTR_OK;
+  if (B == 0) {
+    hipMemsetAsync(sums, 0, 3 * sizeof(float), s);
+    return RSCOTR_OK;
+  }
   if (!logit || !label || !lse) return fail(RSCOTR_E_ARG, "rscotr_upsample_ce_fwd: null pointer");
+  if (!workspace || workspace_bytes < rscotr_upsample_ce_workspace())
+    return fail(RSCOTR_E_ARG, "rscotr_upsample_ce_fwd: workspace of rscotr_upsample_ce_workspace() bytes required");
   const long npix = (long)B * H * W;
-  upsample_ce_fwd_kernel<<<(int)std::min<long>((npix + 255) / 256, 4096), 256, 0, s>>>(logit, label, lse, sums, B, C, h, w,
-                                                                                   H, W, ignore_index);
+  const int nwg = (int)std::min<long>((npix + 255) / 256, UCE_MAX_WG);
+  upsample_ce_fwd_kernel<<<nwg, 256, 0, s>>>(logit, label, lse, workspace, B, C, h, w, H, W, ignore_index);
+  upsample_ce_sums_kernel<<<1, 256, 0, s>>>(workspace, sums, nwg);
   return check_launch("rscotr_upsample_ce_fwd");
 }
 

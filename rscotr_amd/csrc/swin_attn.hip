@@ -30,6 +30,9 @@
 namespace rscotr {
 
 constexpr int WS = 7, WN = 49, HD = 32, TBL = 169;
+// per-workgroup partial row of the backward kernels: [0, TBL) bias-table gradient of the workgroup's head,
+// [WATTN_PBIAS, WATTN_PBIAS + 3 HD) pad-token gradient of the head's q | k | v bias slice
+constexpr int WATTN_PBIAS = 172, WATTN_PROW = WATTN_PBIAS + 3 * HD;
 
 struct WinGeom {
   int H, W, Hp, Wp, nWw, nW, C, heads, shift;
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(64) void swin_wattn_bwd_kernel(const float* __restr
                                                             const float* __restrict__ qkv_b,
                                                             const float* __restrict__ table,
                                                             const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, float* __restrict__ dqkv_b,
-                                                            float* __restrict__ dtable, WinGeom g, int B, int phases) {
+                                                            float* __restrict__ dqkv, float* __restrict__ part,
+                                                            WinGeom g, int B, int phases) {
   __shared__ float4 sQ[WN * HD / 4], sK[WN * HD / 4], sV[WN * HD / 4], sG[WN * HD / 4];
   __shared__ float sP[WN * WN];
   __shared__ float sT[TBL], sdT[TBL], sdB[3 * HD];
@@ -379,12 +382,11 @@ __global__ __launch_bounds__(64) void swin_wattn_bwd_kernel(const float* __restr
     pad_bias_grad(sdB + HD, acc, lane < WN && me.pad, scale, lane);
   }
   __syncthreads();
-  if (dtable)
-    for (int t = lane; t < TBL; t += 64)
-      if (sdT[t] != 0.f) unsafeAtomicAdd(dtable + t * g.heads + head, sdT[t]);
-  if (dqkv_b)
-    for (int t = lane; t < 3 * HD; t += 64)
-      if (sdB[t] != 0.f) unsafeAtomicAdd(dqkv_b + (t / HD) * g.C + head * HD + (t % HD), sdB[t]);
+  // this workgroup's share of the bias-table / pad-token (qkv-bias) gradients: one partial row, folded over the
+  // workgroups of the head in fixed order by wattn_param_fold_kernel (no global atomics: bit-reproducible)
+  float* prow = part + (long)blockIdx.x * WATTN_PROW;
+  for (int t = lane; t < TBL; t += 64) prow[t] = sdT[t];
+  for (int t = lane; t < 3 * HD; t += 64) prow[WATTN_PBIAS + t] = sdB[t];
 }
 
 
@@ -632,8 +634,8 @@ __global__ __launch_bounds__(64) void swin_wattn_bwd_mfma_kernel(const float* __
                                                                  const float* __restrict__ qkv_b,
                                                                  const float* __restrict__ table,
                                                                  const float* __restrict__ dout,
-                                                                 float* __restrict__ dqkv, float* __restrict__ dqkv_b,
-                                                                 float* __restrict__ dtable, WinGeom g, int B) {
+                                                                 float* __restrict__ dqkv, float* __restrict__ part,
+                                                                 WinGeom g, int B) {
   __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT], sG[WN * LDT];
   __shared__ float sP[NPD * LDP];
   __shared__ float sT[TBL], sdT[TBL], sdB[3 * HD];
@@ -765,12 +767,11 @@ __global__ __launch_bounds__(64) void swin_wattn_bwd_mfma_kernel(const float* __
     (void)any_pad;
   }
   __syncthreads();
-  if (dtable)
-    for (int t = lane; t < TBL; t += 64)
-      if (sdT[t] != 0.f) unsafeAtomicAdd(dtable + t * g.heads + head, sdT[t]);
-  if (dqkv_b)
-    for (int t = lane; t < 3 * HD; t += 64)
-      if (sdB[t] != 0.f) unsafeAtomicAdd(dqkv_b + (t / HD) * g.C + head * HD + (t % HD), sdB[t]);
+  // this workgroup's share of the bias-table / pad-token (qkv-bias) gradients: one partial row, folded over the
+  // workgroups of the head in fixed order by wattn_param_fold_kernel (no global atomics: bit-reproducible)
+  float* prow = part + (long)blockIdx.x * WATTN_PROW;
+  for (int t = lane; t < TBL; t += 64) prow[t] = sdT[t];
+  for (int t = lane; t < 3 * HD; t += 64) prow[WATTN_PBIAS + t] = sdB[t];
 }
 
 static int wattn_geom(const char* fn, WinGeom* g, int B, int H, int W, int C, int heads, int ws, int shift) {
@@ -818,22 +819,65 @@ extern "C" int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, co
   return check_launch("rscotr_swin_wattn_fwd");
 }
 
+// workgroups per head of the backward launch (the partial rows of a head are rows head, head + heads, ...)
+static int wattn_bwd_grid(const WinGeom& g, int B) { return wattn_grid(g, B, 4); }
+
+namespace rscotr {
+// grid (ceil(WATTN_PROW / 64), heads): column block x head; the 4 wavefronts take the head's partial rows round-robin,
+// fold through LDS in fixed order, and ADD into dtable[t][head] / dqkv_b[k * C + head * HD + c].
+__global__ __launch_bounds__(256) void wattn_param_fold_kernel(const float* __restrict__ part, float* __restrict__ dtable,
+                                                               float* __restrict__ dqkv_b, int heads, int C, int rows) {
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane, head = blockIdx.y;
+  float a = 0.f;
+  if (col < WATTN_PROW) {
+#pragma unroll 8
+    for (int r = w; r < rows; r += 4) a += part[((long)r * heads + head) * WATTN_PROW + col];
+  }
+  if (w > 0) red[w - 1][lane] = a;
+  __syncthreads();
+  if (w != 0 || col >= WATTN_PROW) return;
+  a += red[0][lane];
+  a += red[1][lane];
+  a += red[2][lane];
+  if (col < TBL) {
+    if (dtable) dtable[col * heads + head] += a;
+  } else if (col >= WATTN_PBIAS && dqkv_b) {
+    const int t = col - WATTN_PBIAS;
+    dqkv_b[(t / HD) * C + head * HD + (t % HD)] += a;
+  }
+}
+}  // namespace rscotr
+
+extern "C" int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, int heads) {
+  WinGeom g;
+  if (B <= 0 || wattn_geom("rscotr_swin_wattn_bwd_workspace", &g, B, H, W, C, heads, WS, 0)) return 0;
+  return (int64_t)wattn_bwd_grid(g, B) * WATTN_PROW * 4;
+}
+
 extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table,
                                      const float* dout, float* dqkv, float* dqkv_bias, float* dbias_table,
-                                     int B, int H, int W, int C, int heads, int ws, int shift, void* stream) {
+                                     int B, int H, int W, int C, int heads, int ws, int shift, float* workspace,
+                                     int64_t workspace_bytes, void* stream) {
   WinGeom g;
   if (int e = wattn_geom("rscotr_swin_wattn_bwd", &g, B, H, W, C, heads, ws, shift)) return e;
   if (B == 0) return RSCOTR_OK;
   if (!qkv || !bias_table || !dout || !dqkv) return fail(RSCOTR_E_ARG, "rscotr_swin_wattn_bwd: null pointer");
   if (!aligned16(qkv) || !aligned16(dout) || !aligned16(dqkv) || (qkv_bias && !aligned16(qkv_bias)))
     return fail(RSCOTR_E_ALIGN, "rscotr_swin_wattn_bwd: pointers must be 16-byte aligned");
+  const int nwg = wattn_bwd_grid(g, B);
+  if (!workspace || workspace_bytes < (int64_t)nwg * WATTN_PROW * 4)
+    return fail(RSCOTR_E_ARG, "rscotr_swin_wattn_bwd: workspace of rscotr_swin_wattn_bwd_workspace() bytes required");
   static const int phases = getenv("RSCOTR_WATTN_PHASES") ? atoi(getenv("RSCOTR_WATTN_PHASES")) : 4;
   static const int impl = getenv("RSCOTR_WATTN_BWD_IMPL") ? atoi(getenv("RSCOTR_WATTN_BWD_IMPL")) : 1;  // 0 VALU, 1 MFMA
+  hipStream_t s = (hipStream_t)stream;
   if (impl == 0)
-    swin_wattn_bwd_kernel<<<wattn_grid(g, B, 4), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, dout, dqkv,
-                                                                           dqkv_bias, dbias_table, g, B, phases);
+    swin_wattn_bwd_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B, phases);
   else
-    swin_wattn_bwd_mfma_kernel<<<wattn_grid(g, B, 4), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, dout,
-                                                                                dqkv, dqkv_bias, dbias_table, g, B);
+    swin_wattn_bwd_mfma_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B);
+  if (dbias_table || dqkv_bias)
+    wattn_param_fold_kernel<<<dim3((WATTN_PROW + 63) / 64, heads), 256, 0, s>>>(workspace, dbias_table, dqkv_bias, heads, C,
+                                                                              nwg / heads);
   return check_launch("rscotr_swin_wattn_bwd");
 }

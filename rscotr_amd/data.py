@@ -229,11 +229,11 @@ class SyntheticLoader:
     """Yields pre-generated device-resident batches (a small pool cycled over), so the timed
     region starts with its inputs already in HBM."""
 
-    def __init__(self, dataset, batch_size, device, pool=4, num_batches=None):
+    def __init__(self, dataset, batch_size, device, pool=4, num_batches=None, **batch_kw):
         self.dataset, self.batch_size, self.device = dataset, batch_size, device
         self.num_batches = num_batches or max(len(dataset) // batch_size, 1)
         self.pool = [synth.make_batch(dataset.task, batch_size, dataset.size, seed=dataset.seed + 17 * i,
-                                      device=device) for i in range(pool)]
+                                      device=device, **batch_kw) for i in range(pool)]
 
     def __len__(self):
         return self.num_batches
@@ -245,14 +245,17 @@ class SyntheticLoader:
 
 
 def build_synthetic_multidataloader(cfg, device, size=512, batch_size=2, rank=0, strategy_cfg=None,
-                                    lengths=None, pool=4):
+                                    lengths=None, pool=4, tasks=None, **batch_kw):
     """One synthetic loader per entry of cfg.data (task taken from the config), wrapped in a
-    MultiDataLoader with the configured strategy (default round_robin)."""
+    MultiDataLoader with the configured strategy (default round_robin).  `tasks`: keep only the datasets of these tasks
+    (BASELINE configs[3]: the det-only workload); batch_kw goes to synth.make_batch (e.g. max_gt)."""
     loaders = {}
     for i, (name, d) in enumerate(cfg['data'].items()):
+        if tasks is not None and d['task'] not in tasks:
+            continue
         n = (lengths or {}).get(name, 1 << 30)
         ds = SyntheticDataset(d['task'], n, size, seed=2022 + 1000 * rank + 100 * i)
         loaders[name] = SyntheticLoader(ds, batch_size, device, pool=pool,
-                                        num_batches=None if lengths else 1 << 30)
+                                        num_batches=None if lengths else 1 << 30, **batch_kw)
     scfg = dict(strategy=strategy_cfg) if strategy_cfg else ({'strategy': cfg['strategy']} if 'strategy' in cfg else {})
     return MultiDataLoader(loaders, build_iteration_strategy(scfg, loaders))

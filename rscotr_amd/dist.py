@@ -9,6 +9,10 @@ each task is static, so the plan is static too:
     ~bucket_mb, cut at tensor boundaries, ordered back-to-front like backward produces them);
   * a post-accumulate hook counts parameters down per bucket and launches `all_reduce(AVG)` for a
     bucket as soon as its last gradient is written, so the exchange overlaps the rest of backward;
+    buckets are always LAUNCHED in one fixed order (back to front of the arena, the order backward
+    completes them in): a bucket that becomes ready early waits for its predecessors, so a rank-local
+    difference in completion order can never pair mismatched collectives across ranks;
+  * the plans are compared across ranks once per task (hash all-reduced MIN / MAX);
   * all ranks must draw the same task each iteration (same strategy state / NumPy seed on every
     rank, as the reference requires — tools/train.py:211-215).
 """
@@ -37,6 +41,7 @@ class GradSync:
         self.param_index = {id(g['param']): i for i, g in enumerate(optimizer.groups)}
         self._bucket_of = None
         self.fires = {}       # task -> {param index: gradient-ready notifications per step}
+        self._order, self._next, self._warned = [], 0, False
         optimizer.ready_callbacks.append(self._on_ready)
 
     def _on_ready(self, i):
@@ -49,8 +54,27 @@ class GradSync:
             b = self._bucket_of.get(i)
             if b is not None:
                 b['pending'] -= 1
-                if b['pending'] == 0:
-                    self._launch(b)
+                if b['pending'] <= 0:
+                    self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch, in the fixed order, every bucket up to the first one that is not complete yet."""
+        while self._next < len(self._order) and self._order[self._next]['pending'] <= 0:
+            self._launch(self._order[self._next])
+            self._next += 1
+
+    def _check_plan(self, task):
+        """All ranks must have cut the same buckets (same parameters fired): one tiny all-reduce per task."""
+        if not is_dist():
+            return
+        import zlib
+        h = zlib.crc32(repr([(b['lo'], b['hi']) for b in self.plans[task]]).encode()) & 0x7FFFFFFF
+        t = torch.tensor([h, -h], dtype=torch.int64, device=self.opt.flat_g.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lo, hi = -int(t[1]), int(t[0])
+        if lo != hi:
+            raise RuntimeError(f'gradient bucket plans of task {task!r} differ across ranks: the ranks did not run the '
+                               'same task / parameter subset this iteration')
 
     def reduce_task(self, task):
         """Exchange the task's gradient buckets now (no overlap with backward) and make the current stream
@@ -103,6 +127,7 @@ class GradSync:
                 b['pending'] = sum(fires[i] for i in b['params'])
                 for i in b['params']:
                     self._bucket_of[i] = b
+            self._order, self._next = list(reversed(plan)), 0
 
     def finish_step(self, task):
         """Call after backward, before the optimizer step: waits for the exchange."""
@@ -110,8 +135,22 @@ class GradSync:
             self.plans[task] = self._build_plan(self.fired)
             self.fires[task] = dict(self.fired)
             self.fired = None
+            self._check_plan(task)
             for b in self.plans[task]:
                 self._launch(b)
+        elif self._bucket_of is not None:
+            # backward is over: whatever has not been launched (a parameter fired fewer times than in the discovery
+            # step, so its bucket never counted down to zero) goes out now, in the same fixed order on every rank —
+            # never skipped: a skipped bucket would leave that gradient un-averaged and the ranks would diverge
+            late = [b for b in self._order[self._next:] if b['pending'] != 0]
+            if late and not self._warned:
+                self._warned = True
+                import warnings
+                warnings.warn(f'GradSync: {len(late)} bucket(s) of task {task!r} did not count down to zero during '
+                              'backward (fire counts differ from the discovery step); exchanged after backward')
+            while self._next < len(self._order):
+                self._launch(self._order[self._next])
+                self._next += 1
         for h in self.handles:
             h.wait()
         self.handles = []

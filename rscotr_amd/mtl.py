@@ -56,6 +56,13 @@ class LazyLogVars(Mapping):
         assert self._vals is None
         return LazyLogVars([f'{prefix}.{n}' for n in self._all], self._packed)
 
+    def all_reduced(self):
+        """Rank-averaged values (multitask_learner.py:299-304): ONE all-reduce of the packed vector, still no host sync."""
+        assert self._vals is None
+        packed = self._packed / dist.get_world_size()
+        dist.all_reduce(packed)
+        return LazyLogVars(self._all, packed)
+
     def scaled(self, weight):
         assert self._vals is None
         return LazyLogVars(self._all, self._packed * weight)
@@ -320,7 +327,7 @@ class MTL(nn.Module):
 
     def _parse_losses(self, losses):
         loss, names, packed = MTL.pack_losses(losses)
-        if dist.is_available() and dist.is_initialized():
+        if dist.is_available() and dist.is_initialized() and not getattr(self, 'defer_log_allreduce', False):
             world = dist.get_world_size()
             # rank-consistency guard of the reference (multitask_learner.py:289-296) rides along
             packed = torch.cat([packed / world, packed.new_tensor([float(len(names))])])

@@ -297,6 +297,25 @@ class _DeferredCombine:
         self.blocks, self.cur, self.off = [], 0, 0
         self.entries, self.notify, self.cache = [], [], {}
         self.ln_entries, self.ln_cache = [], {}
+        # flush tables are addressed by raw pointer from captured hipGraphs: a table that was looked up while a graph
+        # was being warmed up / captured (`pin = True`, set by runner.GraphedTask) is never evicted; the others are
+        # dropped oldest-first once more than MAX_TABLES signatures have been seen
+        self.pin = False
+        self.pinned = set()
+
+    MAX_TABLES = 64
+
+    def _remember(self, cache, sig, hit):
+        if self.pin:
+            self.pinned.add(sig)
+        if sig not in cache:
+            cache[sig] = hit
+            if len(cache) > self.MAX_TABLES:
+                for k in list(cache):
+                    if len(cache) <= self.MAX_TABLES:
+                        break
+                    if k not in self.pinned and k != sig:
+                        del cache[k]
 
     def reserve(self, nbytes, device):
         nbytes = (nbytes + 255) // 256 * 256
@@ -342,9 +361,7 @@ class _DeferredCombine:
                 wg = [(r, c) for r, e in enumerate(ents) for c in range((2 * e[4] + 63) // 64)]
                 hit.append((torch.from_numpy(np.asarray(ents, dtype=np.int64)).to(dev),
                             torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg)))
-            if len(self.ln_cache) > 16:
-                self.ln_cache.clear()
-            self.ln_cache[sig] = hit
+        self._remember(self.ln_cache, sig, hit)
         for tab, wg, nwg in hit:
             lib.call('rscotr_layernorm_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
         self.ln_entries = []
@@ -378,9 +395,7 @@ class _DeferredCombine:
                         M, N = e[4], e[5]
                         wg.extend((r, c) for c in range((max(M * N // 4, M) + 255) // 256))
                     hit.append((torch.from_numpy(tab).to(dev), torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg)))
-                if len(self.cache) > 16:
-                    self.cache.clear()
-                self.cache[sig] = hit
+            self._remember(self.cache, sig, hit)
             for tab, wg, nwg in hit:
                 lib.call('rscotr_splitk_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
         notify, self.notify = self.notify, []
@@ -688,8 +703,9 @@ class _GroupNormTokens(Function):
         B, L, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        nws = lib.rscotr_groupnorm_tokens_workspace(B, L, C, groups)
         lib.call('rscotr_groupnorm_tokens_fwd', x.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats.data_ptr(),
-                 B, L, C, groups, float(eps), _stream())
+                 B, L, C, groups, float(eps), _WS.get(nws, x.device).data_ptr(), nws, _stream())
         ctx.save_for_backward(x, w, stats)
         ctx.groups, ctx.has_b = groups, b is not None
         return y
@@ -702,8 +718,10 @@ class _GroupNormTokens(Function):
         dx = torch.empty_like(x)
         dwb = torch.zeros((2, C), dtype=torch.float32, device=x.device)
         proj = torch.empty((B, ctx.groups, 2), dtype=torch.float32, device=x.device)
+        nws = lib.rscotr_groupnorm_tokens_workspace(B, L, C, ctx.groups)
         lib.call('rscotr_groupnorm_tokens_bwd', dy.data_ptr(), x.data_ptr(), _ptr(w), stats.data_ptr(), dx.data_ptr(),
-                 dwb[0].data_ptr(), dwb[1].data_ptr(), proj.data_ptr(), B, L, C, ctx.groups, _stream())
+                 dwb[0].data_ptr(), dwb[1].data_ptr(), proj.data_ptr(), B, L, C, ctx.groups,
+                 _WS.get(nws, x.device).data_ptr(), nws, _stream())
         return dx, dwb[0] if w is not None else None, dwb[1] if ctx.has_b else None, None, None
 
 
@@ -823,8 +841,10 @@ class _SwinWindowAttn(Function):
         dt_ptr = skt[1].data_ptr() if skt is not None else dtable.data_ptr()
         db_ptr = skb[1].data_ptr() if skb is not None else _ptr(dqkv_b)
         with _Prof('swin_wattn_bwd', 4 * B * H * W * 8 * C):
+            nws = lib.rscotr_swin_wattn_bwd_workspace(B, H, W, C, heads)
             lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), dout.data_ptr(),
-                     dqkv.data_ptr(), db_ptr, dt_ptr, B, H, W, C, heads, ws, shift, _stream())
+                     dqkv.data_ptr(), db_ptr, dt_ptr, B, H, W, C, heads, ws, shift,
+                     _WS.get(nws, qkv.device).data_ptr(), nws, _stream())
         for sk in (skt, skb):
             if sk is not None:
                 GRAD_SINK.grad_written(sk[0])
@@ -1269,8 +1289,9 @@ class _UpsampleCE(Function):
         lse = torch.empty((B, H, W), dtype=torch.float32, device=logit.device)
         sums = torch.empty(3, dtype=torch.float32, device=logit.device)
         with _Prof('upsample_ce_fwd', 4 * B * C * h * w + 12 * B * H * W):
+            nws = lib.rscotr_upsample_ce_workspace()
             lib.call('rscotr_upsample_ce_fwd', logit.data_ptr(), label.data_ptr(), lse.data_ptr(), sums.data_ptr(),
-                     B, C, h, w, H, W, int(ignore_index), _stream())
+                     B, C, h, w, H, W, int(ignore_index), _WS.get(nws, logit.device).data_ptr(), nws, _stream())
         ctx.save_for_backward(logit, label, lse)
         ctx.ignore = int(ignore_index)
         ctx.mark_non_differentiable(sums)

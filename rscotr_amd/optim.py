@@ -136,7 +136,8 @@ class FlatAdamW:
         self.lr_factor = 1.0
         self._dyn_host = torch.zeros((n, 8), dtype=torch.float32, pin_memory=device.type == 'cuda')
         self.seg_dyn = torch.zeros((n, 8), dtype=torch.float32, device=device)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self._dyn_event = None
+        self.sumsq = torch.zeros(1 + 1024, dtype=torch.float32, device=device)  # [0] = total, [1:] = partials
         # gradient-ready notifications: autograd's AccumulateGrad (post hook) or the direct-write path
         # of rscotr_amd.ops (GRAD_SINK) both end in _on_ready(i)
         self.ready_callbacks = []
@@ -212,6 +213,10 @@ class FlatAdamW:
         self.steps[live] += 1
         b1, b2 = self.betas
         t = np.maximum(self.steps, 1).astype(np.float64)
+        if table is None and self._dyn_event is not None:
+            # the shared pinned table is read by the previous step's asynchronous upload: do not refill it under that copy
+            # (captured iterations own a table each and guard it with their `done` event)
+            self._dyn_event.synchronize()
         dyn = (self._dyn_host if table is None else table).numpy()
         dyn[:, 0] = self.base_lr * self.lr_factor
         dyn[:, 1] = self.wd
@@ -224,9 +229,11 @@ class FlatAdamW:
         ops.flush_deferred()  # (no-op unless a caller skipped the flush after backward)
         b1, b2 = self.betas
         self.seg_dyn.copy_(self._dyn_host if table is None else table, non_blocking=True)
+        if table is None and self.device.type == 'cuda':
+            self._dyn_event = torch.cuda.Event()
+            self._dyn_event.record()
         s = ops._stream()
         if self.max_norm > 0:
-            self.sumsq.zero_()
             lib.call('rscotr_grad_sumsq', self.flat_g.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
                      self.chunk_len.data_ptr(), self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), s)
         lib.call('rscotr_adamw_clip_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
@@ -246,9 +253,26 @@ class FlatAdamW:
             if self.live[i]:
                 state[i] = dict(step=int(self.steps[i]), exp_avg=self.flat_m[o:o + n].view(g['param'].shape).clone(),
                                 exp_avg_sq=self.flat_v[o:o + n].view(g['param'].shape).clone())
-        return dict(state=state, param_groups=[dict(lr=g['lr'] * self.lr_factor, weight_decay=g['weight_decay'],
-                                                     betas=self.betas, eps=self.eps, params=[i])
+        # the param_groups of torch.optim.AdamW (torch 1.11) as mmcv leaves them: `initial_lr` is what mmcv's LrUpdaterHook
+        # setdefault()s on resume — without it a reference resume past a decay step would take the decayed `lr` as the
+        # base and decay it a second time
+        return dict(state=state, param_groups=[dict(lr=g['lr'] * self.lr_factor, initial_lr=g['lr'],
+                                                     weight_decay=g['weight_decay'], betas=self.betas, eps=self.eps,
+                                                     amsgrad=False, maximize=False, params=[i])
                                                 for i, g in enumerate(self.groups)])
+
+    def snapshot(self):
+        """Weights, moments and step counts (GraphedTask restores them after its warm-up iterations)."""
+        return dict(p=self.flat_p.clone(), m=self.flat_m.clone(), v=self.flat_v.clone(), steps=self.steps.copy(),
+                    live=self.live.copy())
+
+    def restore(self, snap):
+        self.flat_p.copy_(snap['p'])
+        self.flat_m.copy_(snap['m'])
+        self.flat_v.copy_(snap['v'])
+        self.steps[:] = snap['steps']
+        self.live[:] = snap['live']
+
 
 
     def load_state_dict(self, sd):

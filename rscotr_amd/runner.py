@@ -38,9 +38,18 @@ class GraphedTask:
         self.aug = None
         self.det_static = None
         if task == 'det':
-            from .det_head import DetStatic
+            from .det_head import DetStatic, _round_up
+            gcap = None
+            if runner.sync is not None:
+                # one capacity for all ranks (MAX of what each rank's capture batch needs, with headroom): the ranks then
+                # take the same graph-or-eager decision for most batches; when they do not, both paths issue the same
+                # collective sequence (see IterBasedRunner._train_iter)
+                import torch.distributed as dist
+                need = torch.tensor([max([int(l.shape[0]) for l in batch['gt_labels']] + [1])], device=batch['img'].device)
+                dist.all_reduce(need, op=dist.ReduceOp.MAX)
+                gcap = _round_up(max(int(need.item()), 32), 32)
             self.det_static = DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
-                                        batch['img'].device)
+                                        batch['img'].device, gcap=gcap)
         if task == 'cls':
             sp = self.model.cls_augments.static_params(self._draw(), batch['img'].shape[0])
             self.aug = {k: v.to(batch['img'].device) for k, v in sp.items()}
@@ -56,21 +65,30 @@ class GraphedTask:
         # warm-up (allocator, workspaces, lazy inits), then capture — both on the runner's stream, which is
         # the current stream here
         side = torch.cuda.current_stream()
-        for _ in range(2):
+        # the two warm-up iterations must not move the training trajectory (the reference applies ONE update per batch):
+        # weights, moments and step counts are put back afterwards; only the first replay below counts
+        snap = self.opt.snapshot()
+        ops.DEFER.pin = True  # the flush tables looked up from here on are baked into the graph by address
+        try:
+            for _ in range(2):
+                self.opt.prepare_step(self.table)
+                self._body()
+                self._finish()
+                side.synchronize()  # the pinned optimizer table is refilled by the next prepare_step()
+            torch.cuda.synchronize()
+            self.opt.restore(snap)
+            del snap
+            self.graph = torch.cuda.CUDAGraph()
             self.opt.prepare_step(self.table)
-            self._body()
-            self._finish()
-            side.synchronize()  # the pinned optimizer table is refilled by the next prepare_step()
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        self.opt.prepare_step(self.table)
-        # thread_local: the RCCL watchdog thread polls its events while this thread captures; under the default
-        # global mode that poll is "not permitted when stream is capturing" and kills the process group
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
-            self._body()
+            # thread_local: the RCCL watchdog thread polls its events while this thread captures; under the default
+            # global mode that poll is "not permitted when stream is capturing" and kills the process group
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
+                self._body()
+        finally:
+            ops.DEFER.pin = False
         self.graph.replay()  # capture only records: this replay is the iteration prepare_step() announced
         self._finish()
-        self.warm_iters = 3  # iterations applied to the weights on this batch (2 warm-up + 1 replay)
+        self.warm_iters = 1  # iterations applied to the weights on this batch (the warm-ups were rolled back)
 
     def _draw(self):
         return self.model.cls_augments.draw(self.static['img'].shape[0], self.static['img'].shape[-2:])
@@ -86,7 +104,6 @@ class GraphedTask:
         loss, self.names, packed = self.model.pack_losses(losses)
         self.packed = packed * self.weight
         self.opt.zero_grad()
-        from . import ops
         # weight-gradient contractions on a second stream, joined before anything reads the arena.  Off by
         # default: inside a hipGraph the forked branch brought nothing on ROCm 7.2 (71.9 ms/round without,
         # 72-73 with; profiles/README.md) — the replay does not overlap the two branches.
@@ -141,12 +158,10 @@ class GraphedTask:
         # the packed loss vector is cloned (the static one is overwritten by the next replay) and read
         # lazily: the host does not wait for the graph, it goes on to queue the next iteration
         prefix = f"{self.task}.{batch.get('dataset_name')}"
-        packed = self.packed.clone()
+        lv = LazyLogVars(self.names, self.packed.clone())
         if self.split:  # rank-averaged log variables (multitask_learner.py:299-304), one packed all-reduce
-            import torch.distributed as dist
-            packed.div_(dist.get_world_size())
-            dist.all_reduce(packed)
-        return dict(loss=None, log_vars=LazyLogVars(self.names, packed).prefixed(prefix),
+            lv = lv.all_reduced()
+        return dict(loss=None, log_vars=lv.prefixed(prefix),
                     num_samples=len(batch['img_metas']))
 
 
@@ -217,16 +232,29 @@ class IterBasedRunner:
                 keep = self.model._drop_keep(batch['img'].shape[0], batch['img'].device, None)
                 if keep is not None:
                     self.model.enable_graphed_trunk(batch['img'], keep)
+        # Distributed: every path of a task must issue the SAME collective sequence on every rank, whichever path each rank
+        # takes for this batch (a rank whose det batch exceeds the captured capacities runs eagerly while the others replay
+        # their graph): [det: normalisers, in forward] -> gradient buckets in arena order after backward -> packed log
+        # vector (n floats).  Tasks that are never graphed keep the overlapped exchange (buckets launched from backward
+        # hooks, back to front) — there all ranks run eagerly, always.
+        graphed_task = self.sync is not None and task in self.graph_tasks and not self.force_eager
+        if self.sync is not None:
+            self.model.defer_log_allreduce = True  # the packed log vector is exchanged here, after the buckets
         out = self.model.train_step(batch, self.optimizer)
         # OptimizerHook.after_train_iter
         self.optimizer.zero_grad()
-        if self.sync is not None:
-            self.sync.begin_step(batch['task'])
+        if self.sync is not None and not (graphed_task and task in self.sync.plans):
+            self.sync.begin_step(task)
         out['loss'].backward()
         ops.flush_deferred()
         if self.sync is not None:
-            self.sync.finish_step(batch['task'])
+            if graphed_task and task in self.sync.plans:
+                self.sync.reduce_task(task)
+            else:
+                self.sync.finish_step(task)
         self.optimizer.step()
+        if self.sync is not None and isinstance(out['log_vars'], LazyLogVars):
+            out['log_vars'] = out['log_vars'].all_reduced()
         out['loss'] = out['loss'].detach()  # drop the autograd graph (and its AccumulateGrad nodes) now
         self.iter += 1
         self.log_buffer = out['log_vars']

@@ -10,9 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'timeout: per-test limit (pytest-timeout)')
     import torch
-    # the oracle's CPU ops: a bounded thread pool (the container has 8 cores; the gloo test spawns 2 more processes)
-    torch.set_num_threads(min(4, os.cpu_count() or 1))
+    # the oracle's CPU ops: a bounded thread pool (the build container has 8 cores and the gloo test spawns 2 more
+    # processes; the GPU box has hundreds of logical CPUs and the oracle is what the `-m gpu` suite waits for)
+    torch.set_num_threads(min(32 if torch.cuda.is_available() else 4, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope='session')

@@ -1,6 +1,8 @@
 """Product-vs-oracle comparison of one MTL.train_step (forward losses, log keys, gradients,
 Hungarian indices).  Used on CPU (HIP ops patched with the oracle: host-logic test) and on the
 GPU (real HIP path: parity test)."""
+import contextlib
+
 import torch
 
 from oracle import model as OM
@@ -11,10 +13,48 @@ from util import rel_err, state_to_oracle
 RTOL = 1e-3
 
 
-def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2, P=None, inject_decisions=True):
-    batch_cpu = synth.make_batch(task, batch_size, size, seed=seed)
+@contextlib.contextmanager
+def default_dtype(dt):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dt)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(old)
+
+
+def cast_tree(obj, dt):
+    """Floating tensors of a nested batch / rnd structure to dtype dt (everything else untouched)."""
+    if torch.is_tensor(obj):
+        return obj.to(dt) if obj.dtype.is_floating_point else obj
+    if isinstance(obj, dict):
+        return {k: cast_tree(v, dt) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(cast_tree(v, dt) for v in obj)
+    return obj
+
+
+def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None):
+    """The oracle's train step evaluated in fp64 on the same weights, batch and draws, under the SAME hard decisions the
+    fp32 evaluation took where they are injectable (seg attention masks and det top-k ride in rnd_cpu already; the 7*B
+    assignments come from the fp32 record): the reference point that tells rounding error from wrong arithmetic.
+    Returns (P64 with .grad, out)."""
+    P64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v.detach().clone())
+           for k, v in P.items()}
+    rnd64 = cast_tree(dict(rnd_cpu or {}), torch.float64)
+    if orec32 is not None and orec32.get('match'):
+        rnd64['det_match'] = orec32['match']
+    with default_dtype(torch.float64):
+        out = OM.train_step(P64, model_cfg, cast_tree(batch_cpu, torch.float64), rnd64, {})
+        out['loss'].backward()
+    return P64, out
+
+
+def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2, P=None, inject_decisions=True,
+                  fp64=False, **batch_kw):
+    batch_cpu = synth.make_batch(task, batch_size, size, seed=seed, **batch_kw)
     rnd_cpu = synth.make_rnd(model, batch_cpu, seed=seed)
-    batch_dev = synth.make_batch(task, batch_size, size, seed=seed, device=device)
+    batch_dev = synth.make_batch(task, batch_size, size, seed=seed, device=device, **batch_kw)
     rnd_dev = synth.make_rnd(model, batch_cpu, seed=seed, device=device)
     if P is None:
         P = state_to_oracle(model)
@@ -34,6 +74,8 @@ def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2
         rnd_cpu = dict(rnd_cpu or {}, det_topk_idx=rec['topk_idx'].cpu())
     oout = OM.train_step(P, model_cfg, batch_cpu, rnd_cpu, orec)
     oout['loss'].backward()
+    if fp64:
+        orec['P64'], orec['out64'] = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec)
     return out, oout, rec, orec, P
 
 
@@ -53,6 +95,22 @@ def grad_report(model, P):
         tol = RTOL * float(go.abs().max()) + 1e-5 * gmax
         rows.append((n, float(e.max()) / tol, float((e > tol).double().mean()),
                      float(e.norm() / (go.double().norm() + 1e-30))))
+    return rows
+
+
+def anchor_report(model, P, P64):
+    """Per parameter tensor: ep / eo = relative L2 distance of the product's / the fp32 oracle's gradient from the fp64
+    evaluation of the same step (same decisions).  The denominator carries a floor (1e-5 of the largest gradient
+    maximum, spread over the tensor) so that tensors whose exact gradient is zero or negligible compare as zero."""
+    gmax = max(float(p.grad.abs().max()) for p in P64.values() if p.grad is not None)
+    rows = []
+    for n, p in model.named_parameters():
+        g64 = P64[n].grad
+        if g64 is None or p.grad is None or P[n].grad is None:
+            continue
+        den = float(g64.norm()) + 1e-5 * gmax * (g64.numel() ** 0.5)
+        rows.append(dict(name=n, ep=float((p.grad.detach().cpu().double() - g64).norm()) / den,
+                         eo=float((P[n].grad.double() - g64).norm()) / den))
     return rows
 
 

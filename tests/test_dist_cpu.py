@@ -63,6 +63,41 @@ def _worker(rank, world, port, q):
             for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
                 want = torch.zeros_like(p) if pr.grad is None else pr.grad
                 assert torch.allclose(p.grad, want, atol=1e-6), ('reduce_task', task, n)
+        # Robustness of the overlapped exchange: (1) a bucket that completes EARLY must not be launched before
+        # its predecessors in the fixed back-to-front order — rank 0 sees the completions in reversed order here and the
+        # collectives still pair up; (2) a bucket whose count never reaches zero (a parameter fired fewer times than in
+        # the discovery step) is exchanged by finish_step instead of being skipped silently.
+        import warnings
+        order = []
+        real_launch = sync._launch
+        sync._launch = lambda b: (order.append(b['lo']), real_launch(b))[1]
+        xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(4000 + r)) for r in range(world)]
+        opt.zero_grad()
+        g_local = torch.autograd.grad(model(xs[rank], 'a'), [p for n, p in model.named_parameters() if not n.startswith(('never', 'head_b'))])
+        sync.begin_step('a')
+        plan = sync.plans['a']
+        assert len(plan) >= 2
+        with torch.no_grad():  # write the local gradients into the arena, then notify in a rank-dependent order
+            for p, g in zip([p for n, p in model.named_parameters() if not n.startswith(('never', 'head_b'))], g_local):
+                p.grad.copy_(g)
+        fire = [i for b in (plan if rank == 0 else list(reversed(plan))) for i in b['params']]
+        skipped = plan[0]['params'][0] if rank == 1 else None  # rank 1 "forgets" one notification
+        for i in fire:
+            if i != skipped:
+                for _ in range(sync.fires['a'][i]):
+                    sync._on_ready(i)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            sync.finish_step('a')
+        assert order == [b['lo'] for b in reversed(plan)], (rank, order)
+        assert (rank == 1) == any('did not count down' in str(x.message) for x in w), (rank, [str(x.message) for x in w])
+        sync._launch = real_launch
+        ref.zero_grad()
+        for r in range(world):
+            (ref(xs[r], 'a') / world).backward()
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            want = torch.zeros_like(p) if pr.grad is None else pr.grad
+            assert torch.allclose(p.grad, want, atol=1e-6), ('fixed order', n)
         # reduce_mean of a small device vector (det loss normalisers)
         from rscotr_amd import ops
         assert torch.allclose(ops.dist_mean_tensor(torch.tensor([2.0 * rank, 4.0])), torch.tensor([1.0, 4.0]))
