@@ -28,6 +28,8 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (= fp32 vector)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA peak, dense (no sparsity)
 # gemm_bf16x3_big_kernel issues three bf16 MFMAs per fp32-equivalent product ("count 3x MFMA issue")
 BF16X3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
+# gemm_bf16x6_kernel (precision mode 3, fp32-accurate): six bf16 MFMAs per fp32-equivalent product
+BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 PROF_EVERY_GEMM = 4  # one GEMM launch in n carries a pair of HIP events during the roofline rounds
 
 
@@ -310,13 +312,16 @@ def main():
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12
-            split = 'bf16x3' in name
-            peak = BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF
+            split = 'bf16x3' in name or 'bf16x6' in name
+            peak = BF16X6_PEAK_TF if 'bf16x6' in name else (BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF)
             r_gemm = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
                           traffic=None, kernel=name, launches_sampled=d[2], avg_us=d[1] / d[2] * 1e6,
                           flops_per_launch=d[0] / d[2],
-                          note=('fp32 operands split into hi + lo bf16 halves in the kernel, three v_mfma_f32_32x32x16_bf16 per '
-                                'k-step, fp32 accumulate: achieved = fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 3; '
+                          note=(('fp32 operands split into three bf16 planes in the kernel (all 24 significand bits), six '
+                                 'v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate — fp32-FMA-class error: achieved = '
+                                 'fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 6; ' if 'bf16x6' in name else
+                                 'fp32 operands split into hi + lo bf16 halves in the kernel, three v_mfma_f32_32x32x16_bf16 per '
+                                 'k-step, fp32 accumulate: achieved = fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 3; ')
                                 if split else 'fp32 in / fp32 accumulate MFMA (v_mfma_f32_32x32x2_f32); ') + '1 launch in '
                                f'{PROF_EVERY_GEMM} sampled (events recorded inside the C entry, on the launch stream); ' + (
                                    f'sampled in {a.roofline_rounds} eager round(s) run right after the timed region '
@@ -336,17 +341,20 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
             tf, tt = sum(v[0] for v in gg.values()), sum(v[1] for v in gg.values())
-            sf = sum(v[0] for k, v in gg.items() if 'bf16x3' in k)
-            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k)
-            # the family mixes two matrix pipes: its peak is the time the same flops would take at each kernel's own peak
-            fam_peak = tf / (sf / BF16X3_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
+            sf3 = sum(v[0] for k, v in gg.items() if 'bf16x3' in k)
+            sf6 = sum(v[0] for k, v in gg.items() if 'bf16x6' in k)
+            sf = sf3 + sf6
+            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or 'bf16x6' in k)
+            # the family mixes the matrix pipes: its peak is the time the same flops would take at each kernel's own peak
+            fam_peak = tf / (sf3 / BF16X3_PEAK_TF + sf6 / BF16X6_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
-                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x3_big_kernel<*>, gemm_small_kernel<*>, '
-                              'gemm_dw_direct_kernel<*>',
-                       launches_sampled=sum(v[2] for v in gg.values()), bf16x3_flop_share=sf / tf if tf else 0.0,
-                       bf16x3_time_share=st / tt if tt else 0.0,
-                       note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe) and 2500/3 (bf16x3)')
+                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_bf16x3_big_kernel<*>, '
+                              'gemm_small_kernel<*>, gemm_dw_direct_kernel<*>',
+                       launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
+                       split_product_time_share=st / tt if tt else 0.0,
+                       note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
+                            '2500/3 (bf16x3)')
         r_f = hbm('msda_fwd', 'rscotr::msda_fwd_kernel<32, 4>')
         r_b = hbm('msda_bwd', 'rscotr_msda_bwd (hist + sample + plan + fill + pull kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
@@ -364,14 +372,17 @@ def main():
             pass
         out = dict(metric=wl['metric'], value=images / dt, unit='images/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32' if lib.rscotr_gemm_get_precision() == 0 else 'f32 (large products: 3x bf16 MFMA on hi/lo splits, fp32 accumulate)',
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype={0: 'f32', 3: 'f32 (large products as six bf16 MFMAs on three-plane splits of the fp32 operands, fp32 accumulate: '
+                                     'fp32-FMA-class error)'}.get(lib.rscotr_gemm_get_precision(),
+                                                                  'f32 (large products: 3x bf16 MFMA on hi/lo splits, fp32 accumulate)'),
                    data='synthetic',
                    config=dict(workload=f'{a.workload}: {wl["name"]}, {a.size}x{a.size} bs={a.batch}/task/GPU',
                                step=('one round-robin round = ' + '+'.join(wl['tasks']) + ' train iterations') if ntask > 1
                                else f'one {wl["tasks"][0]} train iteration',
                                images_per_step=ntask * a.batch * world, parallelism=f'dp{world}',
                                optimizer='AdamW+clip0.1 (fused HIP)', precision='fp32',
-                               gemm_precision_mode={0: 'fp32', 1: 'bf16x3', 2: 'bf16x3-big'}[lib.rscotr_gemm_get_precision()],
+                               gemm_precision_mode={0: 'fp32', 1: 'bf16x3', 2: 'bf16x3-big', 3: 'bf16x6'}[lib.rscotr_gemm_get_precision()],
+                               rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0,
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region

@@ -48,20 +48,23 @@ int rscotr_prof_disable(void);
  *   value (B,Nk,H,D) | spatial_shapes (L,2) int64 rows (H_l,W_l), DEVICE memory |
  *   level_start_index (L) int64, DEVICE memory | loc (B,Nq,H,L,P,2) as (x,y) in [0,1] |
  *   attn (B,Nq,H,L,P) | out (B,Nq,H*D).  D in {16,32,64}, P in {1,2,4,8}.
- * Backward: grad_loc / grad_attn are fully overwritten.  With a `workspace` of at least
- * rscotr_msda_bwd_workspace() bytes (16-byte aligned, caller-allocated, contents irrelevant) the
- * samples are counting-sorted by destination token and grad_value (B,Nk,H,D) is fully overwritten
- * without fp32 atomics in the common case; with workspace NULL (or too small, or L > 16) the
- * scatter strategy is used and grad_value must be ZEROED by the caller (atomic accumulation). */
+ * Backward: grad_loc / grad_attn are fully overwritten.  grad_value (B,Nk,H,D), by what the caller provides:
+ *   shapes_host (HOST copy of spatial_shapes, L <= 8) + a `workspace` of rscotr_msda_bwd_tiled_workspace() bytes
+ *     (16-byte aligned, contents irrelevant): tile accumulation — samples partitioned by destination tile in
+ *     sample order, per-tile LDS accumulators, fixed-order combine: fully overwritten, BIT-REPRODUCIBLE (default);
+ *   shapes_host NULL (or RSCOTR_MSDA_BWD=sorted) + rscotr_msda_bwd_workspace() bytes: the round-1 counting sort by
+ *     destination token (order inside a bin follows LDS-atomic ranks: reproducible only to rounding);
+ *   workspace NULL / too small: scatter with fp32 atomics into a grad_value the caller has ZEROED. */
 int rscotr_msda_fwd(const float* value, const int64_t* spatial_shapes,
                     const int64_t* level_start_index, const float* loc, const float* attn,
                     float* out, int B, int Nk, int Nq, int H, int D, int L, int P, void* stream);
 int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes,
                     const int64_t* level_start_index, const float* loc, const float* attn,
                     const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
-                    int B, int Nk, int Nq, int H, int D, int L, int P, void* workspace,
-                    int64_t workspace_bytes, void* stream);
+                    int B, int Nk, int Nq, int H, int D, int L, int P, const int64_t* shapes_host,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L, int P);
+int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L, int P);
 /* The element-wise prologue of mmcv MultiScaleDeformableAttention.forward in one launch per direction:
  *   attn (B,Nq,H,L,P) = softmax over L*P of logit (B,Nq,H,L*P);
  *   loc (B,Nq,H,L,P,2) = ref_xy + off / norm[l]            for ref (B,Nq,L,2), norm (L,2) = (W_l, H_l), or

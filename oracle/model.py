@@ -206,7 +206,7 @@ def msda_module(query, value, identity, query_pos, key_padding_mask, reference_p
 
 
 def ffn_module(x, P, pre):
-    return x + _lin(F.relu(_lin(x, P, pre + '.layers.0.0')), P, pre + '.layers.1')
+    return x + _lin(ops.relu(_lin(x, P, pre + '.layers.0.0')), P, pre + '.layers.1')
 
 
 def mha_module(query, key, value, identity, query_pos, key_pos, attn_mask, P, pre, heads=8):
@@ -364,7 +364,7 @@ def seg_forward(neck_feats, P, cfg, enc_layers, inject_masks=None):
 
     def forward_head(dec_out, target_size):
         d = _ln(dec_out, P, 'seg_head.transformer_decoder.post_norm').transpose(0, 1)
-        me = _lin(F.relu(_lin(F.relu(_lin(d, P, 'seg_head.mask_embed.0')), P, 'seg_head.mask_embed.2')), P, 'seg_head.mask_embed.4')
+        me = _lin(ops.relu(_lin(ops.relu(_lin(d, P, 'seg_head.mask_embed.0')), P, 'seg_head.mask_embed.2')), P, 'seg_head.mask_embed.4')
         mp = torch.einsum('bqd,bdhw->bqhw', me, mask_feature)
         am = F.interpolate(mp, target_size, mode='bilinear', align_corners=False)
         am = am.flatten(2).unsqueeze(1).repeat(1, heads, 1, 1).flatten(0, 1)
@@ -491,7 +491,7 @@ def gen_sineembed(pos):
 
 def _reg_branch(x, P, i):
     pre = f'bbox_head.reg_branches.{i}'
-    return _lin(F.relu(_lin(F.relu(_lin(x, P, pre + '.0')), P, pre + '.2')), P, pre + '.4')
+    return _lin(ops.relu(_lin(ops.relu(_lin(x, P, pre + '.0')), P, pre + '.2')), P, pre + '.4')
 
 
 def det_forward(neck_feats, img_shapes, batch_shape, P, cfg, enc_layers, dn=None, inject_topk=None, record=None):
@@ -589,7 +589,7 @@ def det_forward(neck_feats, img_shapes, batch_shape, P, cfg, enc_layers, dn=None
     for lid in range(ndec):
         rp_in = refp[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         qse = gen_sineembed(rp_in[:, :, 0, :])
-        qpos = _lin(F.relu(_lin(qse, P, 'bbox_head.transformer.decoder.ref_point_head.0')), P,
+        qpos = _lin(ops.relu(_lin(qse, P, 'bbox_head.transformer.decoder.ref_point_head.0')), P,
                     'bbox_head.transformer.decoder.ref_point_head.2').permute(1, 0, 2)
         lp = f'bbox_head.transformer.decoder.layers.{lid}'
         out = mha_module(out, out, out, None, qpos, qpos, attn_mask, P, lp + '.attentions.0')

@@ -72,6 +72,22 @@ def msda_sample_grid_sample(value, spatial_shapes, loc, attn):
 # helpers restated from mmdet 2.25.1 (mmdet/models/utils/transformer.py, positional_encoding.py,
 # core/bbox/transforms.py) — reached from models/multi/bbox_head/transformer.py and dino_head.py
 # ----------------------------------------------------------------------------------------------
+# Tests only (tests/parity.py): with RELU_BAND = d the gates whose pre-activation lies within d * mean|x| of zero are
+# FLIPPED.  A ReLU gate that close to zero is a coin toss between any two correct fp32 implementations; evaluating the
+# step once more with all of them flipped measures how far such flips can move each gradient tensor.
+RELU_BAND = None
+
+
+def relu(x):
+    """F.relu (mmcv FFN / the branch MLPs: nn.ReLU)."""
+    import torch.nn.functional as F
+    if RELU_BAND is None:
+        return F.relu(x)
+    xd = x.detach()
+    near = xd.abs() < RELU_BAND * xd.abs().mean()
+    return x * ((xd > 0) ^ near).to(x.dtype)
+
+
 def inverse_sigmoid(x, eps=1e-5):
     x = x.clamp(min=0, max=1)
     x1 = x.clamp(min=eps)

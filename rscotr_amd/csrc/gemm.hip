@@ -889,6 +889,323 @@ static void launch_bf16x3_big(const GemmParams& p, unsigned nwg, hipStream_t s) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf16x6: the fp32-ACCURATE split product (precision mode 3; scripts/lab/bf16x6_lab.hip is the stand-alone version).
+// x = h + m + l with h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m) — both subtractions exact in fp32, so the
+// three bf16 planes carry all 24 significand bits and bf16 keeps the fp32 exponent (no range problem).  Per k-step of 16
+// the product keeps the six plane pairs of order <= 2^-16 — l*h + h*l + m*m + m*h + h*m + h*h, small terms first, fp32
+// accumulate (v_mfma_f32_32x32x16_bf16); what is dropped (m*l + l*m + l*l) is <= 2^-23 |a||b| per product, the rounding
+// class of an fp32 FMA.  Measured against fp64 (lab, MI355X): 3.0e-7 of max|C| on M = 10880, N = 2048, K = 256 where the
+// fp32 FMA chain has 4.4e-7 and the two-plane bf16x3 product 4.4e-6.  Six MFMAs of 32 cycles per 32x32x16 block against
+// eight of 64 on the fp32 pipe: 2500 / 6 = 417 TFLOP/s-equivalent peak against 157.3.
+// Structure: BK = 16 per stage; operands staged global -> VGPR -> (split, pack) -> LDS with the three planes of a row
+// side by side (row-major source: 112-byte rows, one conflict-free 16-byte read per fragment and plane) or as k-pair
+// dwords (k-major source: written as 16-byte rows, four dword reads per fragment); 128 x 128 tiles on one LDS stage with
+// two barriers per k-tile (1-3 resident workgroups cover each other), 64 x 64 tiles double-buffered with one barrier.
+// Interior shapes only (host-checked); split-K slabs, deferred combine, bias-gradient row sums, per-sample k scaling and
+// the staged epilogue are shared with the kernels above.
+template <int NPL>
+__device__ __forceinline__ void split_planes(float x, __bf16 (&p)[3]) {
+  p[0] = (__bf16)x;
+  const float r1 = x - (float)p[0];
+  p[1] = (__bf16)r1;
+  if (NPL == 3) p[2] = (__bf16)(r1 - (float)p[1]);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(__bf16 a, __bf16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <int R, bool KM, int NPL>
+struct SplitOperand {
+  static constexpr int LDR = 16 * NPL + 8;                          // bf16 per LDS row (row-major source)
+  static constexpr int WORDS = KM ? NPL * 8 * R : R * LDR / 2;      // dwords per stage
+  static constexpr int ITEMS = KM ? 8 * R / 4 : R * 4;              // float4 (pairs) per tile
+  static constexpr int NV = (ITEMS + 255) / 256;
+  float4 v[NV], w[NV];  // row-major: v; k-major: v = even k row, w = odd k row of a pair
+
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      if (ITEMS % 256 == 0 || idx < ITEMS) {
+        if (!KM) {
+          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + (idx >> 2)) * ld + k0 + (idx & 3) * 4);
+        } else {
+          const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
+          const float* src = P + (long)(k0 + 2 * kp) * ld + row0 + r4;
+          v[i] = *reinterpret_cast<const float4*>(src);
+          w[i] = *reinterpret_cast<const float4*>(src + ld);
+        }
+      }
+    }
+  }
+  // k-major only: row k of the staged tile times ks[k / per]
+  __device__ __forceinline__ void scale_k(const float* __restrict__ ks, int per, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      if (ITEMS % 256 == 0 || idx < ITEMS) {
+        const int k = k0 + 2 * (idx / (R / 4));
+        const float f0 = ks[k / per], f1 = ks[(k + 1) / per];
+        v[i].x *= f0; v[i].y *= f0; v[i].z *= f0; v[i].w *= f0;
+        w[i].x *= f1; w[i].y *= f1; w[i].z *= f1; w[i].w *= f1;
+      }
+    }
+  }
+  // k-major only: running sums over k of the four rows this thread stages (r4 is the same for all its items when NV == 1)
+  __device__ __forceinline__ void accum(float4& a, int tid) const {
+    static_assert(!KM || NV == 1, "row sums assume one item per thread");
+    if (ITEMS % 256 == 0 || tid < ITEMS) {
+      a.x += v[0].x + w[0].x; a.y += v[0].y + w[0].y; a.z += v[0].z + w[0].z; a.w += v[0].w + w[0].w;
+    }
+  }
+  __device__ __forceinline__ void store(unsigned* S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      if (ITEMS % 256 == 0 || idx < ITEMS) {
+        if (!KM) {
+          const int row = idx >> 2, kq = (idx & 3) * 4;
+          __bf16 a[3], b[3], c[3], d[3];
+          split_planes<NPL>(v[i].x, a); split_planes<NPL>(v[i].y, b); split_planes<NPL>(v[i].z, c); split_planes<NPL>(v[i].w, d);
+          unsigned* dst = S + (row * LDR + kq) / 2;
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            uint2 q;
+            q.x = pack_bf16(a[pl], b[pl]);
+            q.y = pack_bf16(c[pl], d[pl]);
+            *reinterpret_cast<uint2*>(dst + pl * 8) = q;
+          }
+        } else {
+          const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
+          __bf16 e0[3], o0[3], e1[3], o1[3], e2[3], o2[3], e3[3], o3[3];
+          split_planes<NPL>(v[i].x, e0); split_planes<NPL>(w[i].x, o0);
+          split_planes<NPL>(v[i].y, e1); split_planes<NPL>(w[i].y, o1);
+          split_planes<NPL>(v[i].z, e2); split_planes<NPL>(w[i].z, o2);
+          split_planes<NPL>(v[i].w, e3); split_planes<NPL>(w[i].w, o3);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            uint4 q;
+            q.x = pack_bf16(e0[pl], o0[pl]); q.y = pack_bf16(e1[pl], o1[pl]);
+            q.z = pack_bf16(e2[pl], o2[pl]); q.w = pack_bf16(e3[pl], o3[pl]);
+            *reinterpret_cast<uint4*>(S + (pl * 8 + kp) * R + r4) = q;
+          }
+        }
+      }
+    }
+  }
+  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, bf16x8 (&f)[3]) {
+    if (!KM) {
+      const unsigned* q = S + (row * LDR + 8 * g) / 2;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const unsigned* q = S + (pl * 8 + 4 * g) * R + row;
+        uint4 t;
+        t.x = q[0]; t.y = q[R]; t.z = q[2 * R]; t.w = q[3 * R];
+        f[pl] = __builtin_bit_cast(bf16x8, t);
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool AKM, bool BKM, int PIPE>
+__global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
+  constexpr int NPL = 3, SBK = 16;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  using OA = SplitOperand<BM, AKM, NPL>;
+  using OB = SplitOperand<BN, BKM, NPL>;
+  constexpr int NBUF = PIPE ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned sA[NBUF][OA::WORDS], sB[NBUF][OB::WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = p.N / BN;
+  int tile, split = 0;
+  if (p.splits == 1) {
+    tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  } else {  // an XCD owns a run of tiles with all their splits (as gemm_f32_kernel)
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int q = p.tiles >> 3, r = p.tiles & 7, run = q + (r ? 1 : 0);
+    const int nt = q + (x < r ? 1 : 0);
+    split = j / run;
+    const int tl = j - split * run;
+    if (tl >= nt) return;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + tl;
+  }
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kbeg = split * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg) / SBK;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  OA la;
+  OB lb;
+  const bool do_rs = AKM && p.rowsum && n0 == 0;  // bias gradient riding the dW contraction (tile column 0)
+  float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int fr = lane & 31, g = lane >> 5;
+  auto fetch = [&](int t) {
+    la.load(p.A, p.lda, m0, kbeg + t * SBK, tid);
+    lb.load(p.B, p.ldb, n0, kbeg + t * SBK, tid);
+    if (AKM && p.kscale) la.scale_k(p.kscale, p.krows_per, kbeg + t * SBK, tid);
+  };
+  auto stage = [&](unsigned* a_s, unsigned* b_s) {
+    if (AKM && do_rs) la.accum(rs, tid);
+    la.store(a_s, tid);
+    lb.store(b_s, tid);
+  };
+  auto mma = [&](const unsigned* a_s, const unsigned* b_s) {
+    bf16x8 af[MT][3], bf[NT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, af[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, bf[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {  // small terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+  if (PIPE) {
+    fetch(0);
+    stage(sA[0], sB[0]);
+    if (nk > 1) fetch(1);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      const int cur = t & 1;
+      mma(sA[cur], sB[cur]);
+      if (t + 1 < nk) {  // registers hold tile t+1: split / pack / write to the other stage, then fetch tile t+2
+        stage(sA[cur ^ 1], sB[cur ^ 1]);
+        if (t + 2 < nk) fetch(t + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    fetch(0);
+    for (int t = 0; t < nk; ++t) {
+      __syncthreads();  // the previous tile has been consumed
+      stage(sA[0], sB[0]);
+      __syncthreads();
+      if (t + 1 < nk) fetch(t + 1);  // next tile's global loads fly under the MFMAs
+      mma(sA[0], sB[0]);
+    }
+  }
+
+  if (AKM && do_rs) {  // thread t summed rows (t % (BM/4)) * 4 .. + 3 over the k-pairs it staged: fold the 8 k-lanes
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(sA[0]);
+    if (tid < 8 * BM / 4) red[tid] = rs;  // [k-lane][BM / 4]
+    __syncthreads();
+    if (tid < BM) {
+      const float* rf = reinterpret_cast<const float*>(sA[0]);
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += rf[k * BM + tid];
+      const int m = m0 + tid;
+      if (p.splits > 1) p.rs_slabs[(long)split * p.M + m] = v;
+      else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
+    }
+  }
+
+  if (p.splits > 1) {
+    float* slab = p.slabs + (long)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          slab[(long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * g;
+      float* crow = p.C + (long)mb * p.ldc + n;
+      if (plain) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
+          epilogue_rows4<false>(p, v, mb + 8 * g4, n);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+}
+
+// Tile / slice choice of the bf16x6 kernel for one problem; bm == 0: not its domain (the fp32 pipe takes it).
+struct Split6Cfg {
+  int bm, splits, klen;
+};
+
+static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, int64_t ws_bytes) {
+  Split6Cfg c{0, 1, p.K};
+  static const int on = getenv("RSCOTR_BF16X6") ? atoi(getenv("RSCOTR_BF16X6")) : 1;
+  static const long t128_min = getenv("RSCOTR_BF16X6_T128") ? atol(getenv("RSCOTR_BF16X6_T128")) : 512;
+  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 340;
+  static const int gelu_ok = getenv("RSCOTR_BF16X6_GELU") ? atoi(getenv("RSCOTR_BF16X6_GELU")) : 1;
+  static const int dw_ok = getenv("RSCOTR_BF16X6_DW") ? atoi(getenv("RSCOTR_BF16X6_DW")) : 1;
+  if (!on || !p.vecA || !p.vecB || p.K % 16 || p.K < 64 || p.M % 64 || p.N % 64) return c;
+  if (!gelu_ok && (p.act == ACT_GELU || p.act == ACT_GELU_GRAD || p.pre)) return c;
+  const long t64 = (long)(p.M / 64) * (p.N / 64);
+  const long t128 = (p.M % 128 == 0 && p.N % 128 == 0) ? (long)(p.M / 128) * (p.N / 128) : 0;
+  if (a_kmajor && b_kmajor) {  // weight gradients: small outputs, long reductions -> k-slices through slabs
+    if (!dw_ok || p.rowscale || p.K < 1024) return c;
+    const int bm = t128 >= 16 ? 128 : 64;
+    const long tiles = bm == 128 ? t128 : t64;
+    if (tiles > 2048) return c;
+    long sp = std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, p.K / 256));
+    const int64_t per = ((int64_t)p.M * p.N + p.M) * 4;
+    if (sp > 1) sp = std::min<long>(sp, ws_bytes / per);
+    if (sp < 1) sp = 1;
+    int klen = (int)((p.K + sp - 1) / sp);
+    klen = (klen + 15) / 16 * 16;
+    c.bm = bm; c.klen = klen; c.splits = (p.K + klen - 1) / klen;
+    if (c.splits == 1) c.klen = p.K;
+    return c;
+  }
+  if (p.kscale) return c;
+  if (t128 >= t128_min) c.bm = 128;
+  else if (t64 >= t64_min && p.K <= 4096) c.bm = 64;
+  return c;
+}
+
+template <int BM, int PIPE>
+static void launch_split6(const GemmParams& p, int a_kmajor, int b_kmajor, unsigned nwg, hipStream_t s) {
+  if (!a_kmajor && !b_kmajor) gemm_bf16x6_kernel<BM, BM, false, false, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!a_kmajor) gemm_bf16x6_kernel<BM, BM, false, true, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!b_kmajor) gemm_bf16x6_kernel<BM, BM, true, false, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
+  else gemm_bf16x6_kernel<BM, BM, true, true, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Low-latency kernel for the decoders' small products (M x N <= ~1M outputs, K <= 512: the per-layer Linears and
 // weight gradients of the DINO / Mask2Former decoders, a few hundred launches per round).  On such shapes the tiled
 // kernel above is a chain of dependent memory round trips (k-tile -> LDS -> barrier, 4-16 times) on a fraction of the
@@ -1289,11 +1606,13 @@ constexpr size_t gemm_lds_bytes() {
 // 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32), 1: bf16x3 (three bf16 MFMAs on hi / lo splits, fp32 accumulate).
 // RSCOTR_GEMM_PREC=fp32|bf16x3 sets the start value, rscotr_gemm_set_precision() changes it (tests, A/B runs).
 // 2: bf16x3 only where it pays — gemm_bf16x3_big_kernel on the large row-major products, fp32 pipe elsewhere.
+// 3: bf16x6 (three planes, six MFMAs: fp32-accurate) where it pays — gemm_bf16x6_kernel, fp32 pipe elsewhere.
 static std::atomic<int> g_gemm_prec{[] {
   const char* e = getenv("RSCOTR_GEMM_PREC");
   if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) return 0;
   if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) return 1;
   if (e && (!strcmp(e, "bf16x3-big") || !strcmp(e, "2"))) return 2;
+  if (e && (!strcmp(e, "bf16x6") || !strcmp(e, "3"))) return 3;
   return RSCOTR_GEMM_PREC_DEFAULT;
 }()};
 
@@ -1506,7 +1825,7 @@ static thread_local int tl_last_splits = 1;
 
 // Workspace the split-K path wants for this problem (bytes; 0 = never splits): slabs + row-sum partials.
 extern "C" int rscotr_gemm_set_precision(int prec) {
-  if (prec < 0 || prec > 2) return fail(RSCOTR_E_ARG, "rscotr_gemm_set_precision: 0 (fp32 MFMA), 1 (bf16x3) or 2 (bf16x3 on the large row-major products)");
+  if (prec < 0 || prec > 3) return fail(RSCOTR_E_ARG, "rscotr_gemm_set_precision: 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x3 on the large row-major products) or 3 (bf16x6: fp32-accurate split product)");
   g_gemm_prec.store(prec);
   return RSCOTR_OK;
 }
@@ -1518,7 +1837,13 @@ extern "C" int64_t rscotr_gemm_f32_workspace(int M, int N, int K) {
   const GemmCfg c = choose_cfg(M, N, K);
   const DwCfg d = choose_dw_direct(M, N, K);
   int64_t sp = std::max<int64_t>(c.splits > 1 ? c.splits : 0, d.splits);
-  if (g_gemm_prec.load(std::memory_order_relaxed) && M % 128 == 0 && N % 128 == 0 && K % 32 == 0) {
+  if (g_gemm_prec.load(std::memory_order_relaxed) == 3 && M % 64 == 0 && N % 64 == 0 && K % 16 == 0 && K >= 1024) {
+    const long t128 = (M % 128 == 0 && N % 128 == 0) ? (long)(M / 128) * (N / 128) : 0;
+    const long tiles = t128 >= 16 ? t128 : (long)(M / 64) * (N / 64);
+    sp = std::max<int64_t>(sp, std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, K / 256)));  // as a weight gradient
+  }
+  const int pm = g_gemm_prec.load(std::memory_order_relaxed);
+  if ((pm == 1 || pm == 2) && M % 128 == 0 && N % 128 == 0 && K % 32 == 0) {
     if (bf16x3_big_dims(M, N, K)) sp = std::max<int64_t>(sp, bf16x3_big_splits(M, N, K));
     if (K >= 2048 && (long)(M / 128) * (N / 128) >= 16) sp = std::max<int64_t>(sp, bf16x3_big_splits(M, N, K, true));  // as a weight gradient
   }
@@ -1586,7 +1911,32 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
     }
   }
 
-  if (g_gemm_prec.load(std::memory_order_relaxed) && bf16x3_big_ok(p, a_kmajor, b_kmajor)) {
+  const int prec_mode = g_gemm_prec.load(std::memory_order_relaxed);
+  if (prec_mode == 3) {
+    const Split6Cfg sc = choose_split6(p, a_kmajor, b_kmajor, workspace ? workspace_bytes : 0);
+    if (sc.bm) {
+      p.tiles = (M / sc.bm) * (N / sc.bm);
+      p.splits = sc.splits; p.ksplit_len = sc.klen;
+      p.slabs = sc.splits > 1 ? workspace : nullptr;
+      p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
+      static const bool prof_shapes_6 = getenv("RSCOTR_PROF_SHAPES") != nullptr;
+      char xname[112];
+      if (prof_shapes_6) snprintf(xname, sizeof(xname), "M=%d N=%d K=%d %d%d bf16x6-%d splits=%d", M, N, K, a_kmajor, b_kmajor, sc.bm, sc.splits);
+      else snprintf(xname, sizeof(xname), "rscotr::gemm_bf16x6_kernel<%d, %d, %s, %s, *>", sc.bm, sc.bm, a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
+      ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", xname);
+      const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
+      if (sc.bm == 128) launch_split6<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
+      else launch_split6<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+      if (int e = check_launch("rscotr_gemm_f32 (bf16x6)")) return e;
+      if (sc.splits > 1) {
+        if (tl_defer) { tl_last_splits = sc.splits; return RSCOTR_OK; }
+        launch_splitk_reduce(p, workspace, s);
+        return check_launch("rscotr_gemm_f32 (bf16x6, split-K reduce)");
+      }
+      return RSCOTR_OK;
+    }
+  }
+  if ((prec_mode == 1 || prec_mode == 2) && bf16x3_big_ok(p, a_kmajor, b_kmajor)) {
     const bool dw = a_kmajor && b_kmajor;
     int sp = bf16x3_big_splits(M, N, K, dw);
     if (sp > 1 && (!workspace || workspace_bytes < sp * ((int64_t)M * N + M) * 4))

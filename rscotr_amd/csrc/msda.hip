@@ -25,6 +25,7 @@
 //     DPP via __shfl_xor) over the G lanes, results gathered in LDS and written back
 //     coalesced; grad_value scatter uses the hardware fp32 atomic (global_atomic_add_f32).
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -673,6 +674,372 @@ __global__ __launch_bounds__(256) void msda_pull_kernel(const int64_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, grad_value by TILE ACCUMULATION — deterministic (round 2; replaces the sort pipeline above as the default)
+// ---------------------------------------------------------------------------------------------
+// Every level's value map is cut into square tiles of ts x ts tokens (ts = 16 on the largest level, halved per octave so
+// that every level has about the same number of tiles: the levels receive the same number of samples).  A sample belongs
+// to the tile of its TOP-LEFT tap; its four taps then lie inside the tile's (ts+1) x (ts+1) block (one-token halo to the
+// right / bottom).
+//   1. msda_tile_part_kernel: one WAVEFRONT per chunk of 1024 consecutive samples of one (b, h): tile id per sample, STABLE
+//      rank inside (chunk, tile) — lanes of equal tile found with ballots, running per-tile counters in LDS updated by one
+//      wavefront in program order — then the chunk's samples are written, partitioned by tile, as 16-byte records
+//      {query | local top-left cell, attention weight, lw, lh} plus a (chunk, tile) -> (offset, count) table.  No atomics
+//      whose order matters: the record order inside a tile is the sample order, always.
+//   2. msda_tile_acc_kernel: one workgroup per (b, h, tile) with the block's accumulators in LDS.  Its four wavefronts own
+//      the four tap parities (x & 1, y & 1) — the 2x2 footprint of a sample has exactly one tap of each parity — so no two
+//      wavefronts ever touch the same accumulator; inside a wavefront the records are processed in list order, 64 / (D/4)
+//      samples per step, D/4 lanes x float4 per sample: grad_out row gather (L2-resident: one head per XCD) and four LDS
+//      atomic adds (ds_add_f32; same-address lanes of one instruction are serialised by the LDS in lane order).  The block
+//      is then written to a partial buffer.
+//   3. msda_tile_combine_kernel: grad_value[token] = its own tile's cell + the halo cells of the left / upper / upper-left
+//      neighbour tiles, fixed order.
+// The result is bit-reproducible; traffic: 16-byte records written + read once, partial blocks ~1.2x grad_value.
+constexpr int MSDA_T_MAXL = 8;      // levels the tile path handles
+constexpr int MSDA_T_CH = 1024;     // samples per partition chunk = 16 rounds of one wavefront
+constexpr int MSDA_T_MAXNT = 1024;  // tiles per (b, h)
+constexpr int MSDA_T_MAXCH = 2048;  // chunks per (b, h)
+
+struct MsdaTiles {
+  int L, NT, prows;  // levels, tiles per (b, h), partial rows (tokens incl. halos) per (b, h)
+  int Hl[MSDA_T_MAXL], Wl[MSDA_T_MAXL], lsi[MSDA_T_MAXL];
+  int tsh[MSDA_T_MAXL], ntx[MSDA_T_MAXL];      // log2 of the tile edge, tiles per row
+  int tbase[MSDA_T_MAXL], pbase[MSDA_T_MAXL];  // first tile / first partial row of the level
+};
+
+static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, int Nk) {
+  if (!shapes_host || L < 1 || L > MSDA_T_MAXL) return false;
+  static const int ts0 = [] { const char* e = getenv("RSCOTR_MSDA_TS"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 16) ? v : 16; }();
+  int maxdim0 = 1;
+  for (int l = 0; l < L; ++l) maxdim0 = std::max<int>(maxdim0, (int)std::max(shapes_host[2 * l], shapes_host[2 * l + 1]));
+  T->L = L;
+  int tiles = 0, prows = 0, tok = 0;
+  for (int l = 0; l < L; ++l) {
+    const int Hh = (int)shapes_host[2 * l], Ww = (int)shapes_host[2 * l + 1];
+    if (Hh < 1 || Ww < 1) return false;
+    int ts = ts0;
+    for (int d = std::max(Hh, Ww); 2 * d <= maxdim0 + d / 2 && ts > 2; d *= 2) ts >>= 1;  // one halving per octave below the largest level
+    int tsh = 0;
+    while ((1 << tsh) < ts) ++tsh;
+    T->Hl[l] = Hh; T->Wl[l] = Ww; T->lsi[l] = tok; T->tsh[l] = tsh;
+    T->ntx[l] = (Ww + ts - 1) >> tsh;
+    const int nty = (Hh + ts - 1) >> tsh;
+    T->tbase[l] = tiles; T->pbase[l] = prows;
+    tiles += T->ntx[l] * nty;
+    prows += T->ntx[l] * nty * (ts + 1) * (ts + 1);
+    tok += Hh * Ww;
+  }
+  for (int l = L; l < MSDA_T_MAXL; ++l) {
+    T->Hl[l] = T->Wl[l] = 1; T->lsi[l] = tok; T->tsh[l] = 1; T->ntx[l] = 1; T->tbase[l] = tiles; T->pbase[l] = prows;
+  }
+  T->NT = tiles; T->prows = prows;
+  return tok == Nk && tiles <= MSDA_T_MAXNT;
+}
+
+struct MsdaTileWs {
+  long tbl, rec, part, total;  // byte offsets
+  int NCH;
+};
+
+static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, long S, int D) {
+  MsdaTileWs w;
+  w.NCH = (int)((S + MSDA_T_CH - 1) / MSDA_T_CH);
+  long o = 0;
+  w.tbl = o; o += (long)BH * w.NCH * T.NT * 8;
+  o = (o + 15) & ~15L;
+  w.rec = o; o += (long)BH * S * 16;
+  w.part = o; o += (long)BH * T.prows * D * 4;
+  w.total = o;
+  return w;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void msda_tile_part_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                            int2* __restrict__ tbl, int4* __restrict__ rec, MsdaTiles T,
+                                                            int Nq, int H, int S, int NCH) {
+  __shared__ int run[MSDA_T_MAXNT], off[MSDA_T_MAXNT];
+  __shared__ int gH[MSDA_T_MAXL], gW[MSDA_T_MAXL], gS[MSDA_T_MAXL], gN[MSDA_T_MAXL], gB[MSDA_T_MAXL];
+  constexpr int R = MSDA_T_CH / 64;
+  const int lane = threadIdx.x, chunk = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int LP = T.L * P;
+  if (lane < MSDA_T_MAXL) {
+    gH[lane] = T.Hl[lane]; gW[lane] = T.Wl[lane]; gS[lane] = T.tsh[lane]; gN[lane] = T.ntx[lane]; gB[lane] = T.tbase[lane];
+  }
+  for (int i = lane; i < T.NT; i += 64) run[i] = 0;
+  __syncthreads();
+  float2 xy[R];
+  int key[R], rank[R];
+  const long rowbase = ((long)b * Nq * H + h) * LP;  // + q * H * LP + lp
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
+    xy[j] = make_float2(-9.f, -9.f);  // "outside": no bin
+    if (sid < S) {
+      const int q = sid / LP, lp = sid - q * LP;
+      xy[j] = *reinterpret_cast<const float2*>(loc + (rowbase + (long)q * H * LP + lp) * 2);
+    }
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
+    const int lp = sid % LP, l = lp / P;
+    const int Hl = gH[l], Wl = gW[l];
+    const float h_im = xy[j].y * (float)Hl - 0.5f, w_im = xy[j].x * (float)Wl - 0.5f;
+    const bool in = sid < S && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
+    int k = -1;
+    if (in) {
+      const int x0 = (int)floorf(w_im), y0 = (int)floorf(h_im);
+      const int tsh = gS[l];
+      k = gB[l] + (max(y0, 0) >> tsh) * gN[l] + (max(x0, 0) >> tsh);
+    }
+    // stable rank among the lanes of equal tile (wave-uniform loop over the distinct tiles of this round)
+    int rk = 0, cnt = 0;
+    bool leader = false;
+    unsigned long long rem = __ballot(k >= 0);
+    while (rem) {
+      const int src = __ffsll((long long)rem) - 1;
+      const int kk = __shfl(k, src, 64);
+      const unsigned long long m = __ballot(k == kk);
+      if (k == kk) {
+        rk = __popcll(m & below);
+        cnt = __popcll(m);
+        leader = lane == src;
+      }
+      rem &= ~m;
+    }
+    const int old = k >= 0 ? run[k] : 0;  // every lane reads before the leaders write (one wavefront, program order)
+    if (leader) run[k] = old + cnt;
+    key[j] = k;
+    rank[j] = old + rk;
+  }
+  __syncthreads();
+  {  // exclusive scan of the chunk's per-tile totals -> off[]; table row of the chunk
+    const int per = (T.NT + 63) / 64;
+    const int i0 = min(T.NT, lane * per), i1 = min(T.NT, i0 + per);
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += run[i];
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    int r = inc - sum;
+    int2* row = tbl + ((long)bh * NCH + chunk) * T.NT;
+    for (int i = i0; i < i1; ++i) {
+      const int c = run[i];
+      off[i] = r;
+      row[i] = make_int2(r, c);
+      r += c;
+    }
+  }
+  __syncthreads();
+  int4* out = rec + (long)bh * S + (long)chunk * MSDA_T_CH;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (key[j] < 0) continue;
+    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
+    const int q = sid / LP, lp = sid - q * LP, l = lp / P;
+    const int Hl = gH[l], Wl = gW[l], tsh = gS[l];
+    const float h_im = xy[j].y * (float)Hl - 0.5f, w_im = xy[j].x * (float)Wl - 0.5f;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int x0 = (int)wf, y0 = (int)hf;
+    // local top-left cell (+1: -1 .. ts-1 -> 0 .. ts) inside the tile's block
+    const int lx = x0 - ((max(x0, 0) >> tsh) << tsh) + 1, ly = y0 - ((max(y0, 0) >> tsh) << tsh) + 1;
+    const float a = attn[rowbase + (long)q * H * LP + lp];
+    out[off[key[j]] + rank[j]] = make_int4(q | (lx << 20) | (ly << 25), __float_as_int(a), __float_as_int(w_im - wf),
+                                           __float_as_int(h_im - hf));
+  }
+}
+
+struct TileRec {
+  int4 r;
+  bool ok;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void msda_tile_acc_kernel(const float* __restrict__ grad_out, const int2* __restrict__ tbl,
+                                                            const int4* __restrict__ rec, float* __restrict__ part, MsdaTiles T,
+                                                            int Nq, int H, int S, int NCH, int BH) {
+  constexpr int G = D / 4, SPW = kWave / G, U = 2;  // lanes per sample, samples per wavefront step, steps per iteration
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_scan[2][4];
+  const int bh = blockIdx.x % BH, tile = blockIdx.x / BH;  // blockIdx % 8 == head (H = 8): one head's grad_out rows per XCD's L2
+  const int b = bh / H, h = bh - b * H;
+  int l = 0;
+  while (l + 1 < T.L && tile >= T.tbase[l + 1]) ++l;
+  const int tsh = T.tsh[l], ts = 1 << tsh, ntx = T.ntx[l];
+  const int tl = tile - T.tbase[l], ty = tl / ntx, tx = tl - ty * ntx;
+  const int Wl = T.Wl[l], Hl = T.Hl[l];
+  const int bw = ts + 1, ncell = bw * bw;
+  float* acc = smem;                                          // [ncell][D], channel positions skewed per cell (banks)
+  int* s_pre = reinterpret_cast<int*>(smem + 17 * 17 * D);    // [K + 1] exclusive prefix of the segment lengths
+  int* s_adr = s_pre + NCH + 1;                               // [K] first record of the segment
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < ncell * D; i += 256) acc[i] = 0.f;
+  // non-empty (chunk, tile) segments in chunk order: thread t takes a contiguous run of chunks
+  int K, n;
+  {
+    constexpr int PER = MSDA_T_MAXCH / 256;
+    const int per = (NCH + 255) / 256;
+    int2 e[PER];
+    int mine = 0, msum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid * per + i;
+      e[i] = make_int2(0, 0);
+      if (i < per && c < NCH) e[i] = tbl[((long)bh * NCH + c) * T.NT + tile];
+      if (e[i].y > 0) { ++mine; msum += e[i].y; }
+    }
+    int ia = mine, ib = msum;  // inclusive scans over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+      if (lane >= o) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { s_scan[0][wave] = ia; s_scan[1][wave] = ib; }
+    __syncthreads();
+    int oa = 0, ob = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) { oa += s_scan[0][w]; ob += s_scan[1][w]; }
+      ta += s_scan[0][w]; tb += s_scan[1][w];
+    }
+    K = ta; n = tb;
+    int k = oa + ia - mine, p = ob + ib - msum;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (e[i].y > 0) {
+        s_pre[k] = p;
+        s_adr[k] = (tid * per + i) * MSDA_T_CH + e[i].x;
+        ++k;
+        p += e[i].y;
+      }
+    }
+    if (tid == 0) s_pre[K] = n;
+  }
+  __syncthreads();
+
+  const int grp = lane / G, sub = lane - grp * G;
+  const int px = wave & 1, py = wave >> 1;  // tap parity this wavefront owns
+  const int4* rb = rec + (long)bh * S;
+  const float* gb = grad_out + ((long)b * Nq * H + h) * D + sub * 4;
+  const int niter = (n + SPW * U - 1) / (SPW * U);
+  int cur = 0;  // segment cursor of this lane group (its sample index only grows)
+  auto load_rec = [&](int it, TileRec (&r)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (it * U + u) * SPW + grp;
+      r[u].ok = j < n;
+      r[u].r = make_int4(0, 0, 0, 0);
+      if (r[u].ok) {
+        while (j >= s_pre[cur + 1]) ++cur;
+        r[u].r = rb[s_adr[cur] + (j - s_pre[cur])];
+      }
+    }
+  };
+  auto load_go = [&](const TileRec (&r)[U], float4 (&g)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      g[u] = r[u].ok ? *reinterpret_cast<const float4*>(gb + (long)(r[u].r.x & 0xFFFFF) * H * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto accumulate = [&](const TileRec (&r)[U], const float4 (&g)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!r[u].ok) continue;
+      const int lx = (r[u].r.x >> 20) & 31, ly = (r[u].r.x >> 25) & 31;  // local top-left cell + 1
+      const int dx = px ^ ((lx + 1) & 1), dy = py ^ ((ly + 1) & 1);      // the tap of this wavefront's parity (ts is even)
+      const int cx = lx - 1 + dx, cy = ly - 1 + dy;
+      const int x = (tx << tsh) + cx, y = (ty << tsh) + cy;
+      if (x < 0 || y < 0 || x >= Wl || y >= Hl) continue;
+      const float a = __int_as_float(r[u].r.y), lw = __int_as_float(r[u].r.z), lh = __int_as_float(r[u].r.w);
+      const float w = a * (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+      const int cell = cy * bw + cx;
+      float* dst = acc + cell * D;
+      const int sk = sub + G * (cell & 3);
+      atomicAdd(dst + ((sk + 0 * G) & (D - 1)), w * g[u].x);
+      atomicAdd(dst + ((sk + 1 * G) & (D - 1)), w * g[u].y);
+      atomicAdd(dst + ((sk + 2 * G) & (D - 1)), w * g[u].z);
+      atomicAdd(dst + ((sk + 3 * G) & (D - 1)), w * g[u].w);
+    }
+  };
+  if (niter > 0) {  // three-stage software pipeline: records two iterations ahead, grad_out rows one iteration ahead
+    TileRec r0[U], r1[U], r2[U];
+    float4 g0[U], g1[U];
+    load_rec(0, r0);
+    load_rec(1, r1);
+    load_go(r0, g0);
+    for (int it = 0; it < niter; ++it) {
+      load_rec(it + 2, r2);
+      load_go(r1, g1);
+      accumulate(r0, g0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; g0[u] = g1[u]; }
+    }
+  }
+  __syncthreads();
+  float* prow = part + ((long)bh * T.prows + T.pbase[l] + (long)tl * ncell) * D;
+  for (int i = tid; i < ncell * D; i += 256) {
+    const int cell = i / D, c = i - cell * D;
+    prow[i] = acc[cell * D + (((c >> 2) + (c & 3) * G + G * (cell & 3)) & (D - 1))];
+  }
+}
+
+// grad_value row of every token = own tile's cell + the neighbours' halo cells that alias it, fixed order
+template <int D>
+__global__ __launch_bounds__(256) void msda_tile_combine_kernel(const float* __restrict__ part, float* __restrict__ grad_value,
+                                                                MsdaTiles T, int Nk, int H, int BH) {
+  constexpr int G = D / 4;
+  const long total = (long)BH * Nk * G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % G);
+    const long r = i / G;
+    const int tok = (int)(r % Nk), bh = (int)(r / Nk);
+    const int b = bh / H, h = bh - b * H;
+    int l = 0;
+    while (l + 1 < T.L && tok >= T.lsi[l + 1]) ++l;
+    const int Wl = T.Wl[l], tsh = T.tsh[l], ts = 1 << tsh, bw = ts + 1, ntx = T.ntx[l];
+    const int rr = tok - T.lsi[l], y = rr / Wl, x = rr - y * Wl;
+    const int tx = x >> tsh, ty = y >> tsh, lx = x & (ts - 1), ly = y & (ts - 1);
+    const float* base = part + ((long)bh * T.prows + T.pbase[l]) * D + c4 * 4;
+    auto cellp = [&](int ttx, int tty, int cy, int cx) {
+      return *reinterpret_cast<const float4*>(base + ((long)(tty * ntx + ttx) * bw * bw + cy * bw + cx) * D);
+    };
+    float4 v = cellp(tx, ty, ly, lx);
+    if (lx == 0 && tx > 0) { const float4 u = cellp(tx - 1, ty, ly, ts); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (ly == 0 && ty > 0) { const float4 u = cellp(tx, ty - 1, ts, lx); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (lx == 0 && tx > 0 && ly == 0 && ty > 0) { const float4 u = cellp(tx - 1, ty - 1, ts, ts); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + tok) * H + h) * D + c4 * 4) = v;
+  }
+}
+
+template <int D, int P>
+static void launch_bwd_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                             const float* go, float* gv, float* gl, float* ga, int B, int Nk, int Nq, int H, int L,
+                             const MsdaTiles& T, char* ws, hipStream_t s) {
+  constexpr int QB = 4 * (kWave / (D / 4));
+  const int ntiles = (Nq + QB - 1) / QB;
+  const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
+  const int BH = B * H;
+  const long S = (long)Nq * L * P;
+  const MsdaTileWs W = msda_tile_ws(T, BH, S, D);
+  int2* tbl = reinterpret_cast<int2*>(ws + W.tbl);
+  int4* rec = reinterpret_cast<int4*>(ws + W.rec);
+  float* part = reinterpret_cast<float*>(ws + W.part);
+  msda_tile_part_kernel<P><<<dim3(W.NCH, BH), 64, 0, s>>>(loc, attn, tbl, rec, T, Nq, H, (int)S, W.NCH);
+  // grad_loc / grad_attn by sample (independent of the partition: the two kernels overlap at the launch boundary)
+  msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, Nk, Nq, H, L, ntiles, 0);
+  const size_t acc_lds = ((size_t)17 * 17 * D + 2 * (W.NCH + 1)) * sizeof(float);
+  if (acc_lds > 48 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_acc_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)acc_lds);
+  msda_tile_acc_kernel<D><<<dim3((unsigned)((long)BH * T.NT)), 256, acc_lds, s>>>(go, tbl, rec, part, T, Nq, H, (int)S, W.NCH, BH);
+  const long items = (long)BH * Nk * (D / 4);
+  msda_tile_combine_kernel<D><<<(unsigned)std::min<long>((items + 255) / 256, 4096), 256, 0, s>>>(part, gv, T, Nk, H, BH);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------------------------
 static int check_shape(const char* fn, int B, int Nk, int Nq, int H, int D, int L, int P) {
@@ -800,12 +1167,27 @@ extern "C" int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L
   return (int64_t)(W.body + (long)B * H * W.per_bh) * 4;
 }
 
+// 0 = sorted (round 1), 1 = tiled (deterministic; needs the host copy of the level shapes)
+static int msda_bwd_mode() {
+  static const int v = [] { const char* e = getenv("RSCOTR_MSDA_BWD"); return (e && !strcmp(e, "sorted")) ? 0 : 1; }();
+  return v;
+}
+
+extern "C" int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L,
+                                                   int P) {
+  MsdaTiles T;
+  if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || !msda_tiles_build(&T, shapes_host, L, Nk)) return 0;
+  const long S = (long)Nq * L * P;
+  if ((S + MSDA_T_CH - 1) / MSDA_T_CH > MSDA_T_MAXCH || Nq >= (1 << 20)) return 0;
+  return msda_tile_ws(T, B * H, S, D).total;
+}
+
 extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes,
                                const int64_t* level_start_index, const float* loc,
                                const float* attn, const float* grad_out, float* grad_value,
                                float* grad_loc, float* grad_attn, int B, int Nk, int Nq, int H,
-                               int D, int L, int P, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
+                               int D, int L, int P, const int64_t* shapes_host, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
   if (int e = check_shape("rscotr_msda_bwd", B, Nk, Nq, H, D, L, P)) return e;
   if (B == 0 || Nq == 0) return RSCOTR_OK;  // grad_value stays as zeroed by the caller
   if (!value || !spatial_shapes || !level_start_index || !loc || !attn || !grad_out ||
@@ -817,6 +1199,19 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
   // algorithmic bytes: read value, read-modify-write grad_value, read loc/attn/grad_out, write grad_loc/grad_attn
   ProfScope prof(PROF_MSDA_BWD, 4.0 * B * (3.0 * Nk * H * D + (double)Nq * H * L * P * 6 + (double)Nq * H * D), s,
                  "rscotr_msda_bwd<%d, %d> (hist + sample + plan + fill + pull kernels)", D, P);
+  if (workspace && shapes_host && msda_bwd_mode() == 1 && Nk > 0) {
+    MsdaTiles T;
+    const int64_t need_t = rscotr_msda_bwd_tiled_workspace(shapes_host, B, Nk, Nq, H, D, L, P);
+    if (need_t > 0 && workspace_bytes >= need_t && msda_tiles_build(&T, shapes_host, L, Nk)) {
+      if (!aligned16(workspace)) return fail(RSCOTR_E_ALIGN, "rscotr_msda_bwd: workspace must be 16-byte aligned");
+#define CALL(DD, PP)                                                                                    \
+  launch_bwd_tiled<DD, PP>(value, spatial_shapes, level_start_index, loc, attn, grad_out, grad_value, \
+                           grad_loc, grad_attn, B, Nk, Nq, H, L, T, (char*)workspace, s)
+      RSCOTR_DISPATCH_DP(D, P, CALL)
+#undef CALL
+      return check_launch("rscotr_msda_bwd (tiled)");
+    }
+  }
   const int64_t need = rscotr_msda_bwd_workspace(B, Nk, Nq, H, L, P);
   if (workspace && need > 0 && workspace_bytes >= need && Nk > 0) {
     if (!aligned16(workspace)) return fail(RSCOTR_E_ALIGN, "rscotr_msda_bwd: workspace must be 16-byte aligned");

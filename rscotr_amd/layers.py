@@ -315,6 +315,7 @@ class LevelGeometry:
     def __init__(self, shapes, device):
         self.shapes = [tuple(int(v) for v in s) for s in shapes]
         self.spatial_shapes = torch.tensor(self.shapes, dtype=torch.long, device=device)
+        ops.msda_register_shapes(self.spatial_shapes, self.shapes)
         starts, s = [], 0
         for h, w in self.shapes:
             starts.append(s)

@@ -156,9 +156,27 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 # multi-scale deformable attention sampling (mmcv MultiScaleDeformableAttnFunction contract)
 # ------------------------------------------------------------------------------------------
-# 'sorted' (default): grad_value pulled per destination token (no fp32 atomics in the common case);
-# 'scatter': atomic accumulation.  Tests run both.
-MSDA_BWD_STRATEGY = 'sorted'
+# 'tiled' (default): grad_value by per-tile LDS accumulation in sample order, bit-reproducible; 'sorted': round 1's
+# counting sort by destination token (reproducible to rounding only); 'scatter': atomic accumulation.  Tests run all three.
+MSDA_BWD_STRATEGY = 'tiled'
+
+# host copies of the level-shape tensors (the mmcv contract keeps spatial_shapes on the device; the tile-accumulation
+# backward sizes its launches from the shapes): data_ptr -> int64 numpy array, registered by whoever builds the device
+# tensor (layers.LevelGeometry); an unregistered tensor is read back once (a device sync, eager callers only)
+_MSDA_HOST_SHAPES = {}
+
+
+def msda_register_shapes(spatial_shapes, shapes):
+    import numpy as np
+    _MSDA_HOST_SHAPES[spatial_shapes.data_ptr()] = np.ascontiguousarray(np.asarray(shapes, dtype=np.int64).reshape(-1, 2))
+
+
+def _msda_host_shapes(spatial_shapes):
+    a = _MSDA_HOST_SHAPES.get(spatial_shapes.data_ptr())
+    if a is None:
+        msda_register_shapes(spatial_shapes, spatial_shapes.detach().cpu().numpy())
+        a = _MSDA_HOST_SHAPES[spatial_shapes.data_ptr()]
+    return a
 
 
 class _MSDA(Function):
@@ -187,7 +205,13 @@ class _MSDA(Function):
         grad_out = _f32c(grad_out)
         B, Nk, H, D = value.shape
         _, Nq, _, L, P, _ = loc.shape
-        nws = 0 if MSDA_BWD_STRATEGY == 'scatter' else lib.rscotr_msda_bwd_workspace(B, Nk, Nq, H, L, P)
+        hs, hs_ptr, nws = None, 0, 0
+        if MSDA_BWD_STRATEGY != 'scatter':
+            nws = lib.rscotr_msda_bwd_workspace(B, Nk, Nq, H, L, P)
+            if MSDA_BWD_STRATEGY == 'tiled':
+                hs = _msda_host_shapes(spatial_shapes)
+                hs_ptr = hs.ctypes.data
+                nws = max(nws, lib.rscotr_msda_bwd_tiled_workspace(hs_ptr, B, Nk, Nq, H, D, L, P))
         ws = _WS.get(nws, value.device) if nws else None
         grad_value = torch.zeros_like(value) if ws is None else torch.empty_like(value)
         grad_loc = torch.empty_like(loc)
@@ -198,7 +222,7 @@ class _MSDA(Function):
             lib.call('rscotr_msda_bwd', value.data_ptr(), spatial_shapes.data_ptr(),
                      level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
                      grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                     B, Nk, Nq, H, D, L, P, 0 if ws is None else ws.data_ptr(), nws, _stream())
+                     B, Nk, Nq, H, D, L, P, hs_ptr, 0 if ws is None else ws.data_ptr(), nws, _stream())
         return grad_value, None, None, grad_loc, grad_attn
 
 

@@ -88,7 +88,19 @@ class GraphedTask:
             ops.DEFER.pin = False
         self.graph.replay()  # capture only records: this replay is the iteration prepare_step() announced
         self._finish()
+        self.done = torch.cuda.Event()
+        self.done.record()
         self.warm_iters = 1  # iterations applied to the weights on this batch (the warm-ups were rolled back)
+        self.first_out = self._output(batch)
+
+    def _output(self, batch):
+        # the packed loss vector is cloned (the static one is overwritten by the next replay) and read
+        # lazily: the host does not wait for the graph, it goes on to queue the next iteration
+        prefix = f"{self.task}.{batch.get('dataset_name')}"
+        lv = LazyLogVars(self.names, self.packed.clone())
+        if self.split:  # rank-averaged log variables (multitask_learner.py:299-304), one packed all-reduce
+            lv = lv.all_reduced()
+        return dict(loss=None, log_vars=lv.prefixed(prefix), num_samples=len(batch['img_metas']))
 
     def _draw(self):
         return self.model.cls_augments.draw(self.static['img'].shape[0], self.static['img'].shape[-2:])
@@ -155,14 +167,7 @@ class GraphedTask:
         self._finish()
         self.done = torch.cuda.Event()
         self.done.record()
-        # the packed loss vector is cloned (the static one is overwritten by the next replay) and read
-        # lazily: the host does not wait for the graph, it goes on to queue the next iteration
-        prefix = f"{self.task}.{batch.get('dataset_name')}"
-        lv = LazyLogVars(self.names, self.packed.clone())
-        if self.split:  # rank-averaged log variables (multitask_learner.py:299-304), one packed all-reduce
-            lv = lv.all_reduced()
-        return dict(loss=None, log_vars=lv.prefixed(prefix),
-                    num_samples=len(batch['img_metas']))
+        return self._output(batch)
 
 
 class IterBasedRunner:
@@ -219,8 +224,9 @@ class IterBasedRunner:
             if g is None and self._seen[task] == 2:
                 g = self.graphed[task] = GraphedTask(self, task, batch)
                 self.iter += g.warm_iters
-                self.log_buffer = OrderedDict()
-                return dict(loss=None, log_vars=self.log_buffer, num_samples=len(batch['img_metas']))
+                out, g.first_out = g.first_out, None
+                self.log_buffer = out['log_vars']
+                return out
             if g is not None and g.accepts(batch):
                 out = g.run(batch)
                 self.iter += 1

@@ -37,8 +37,10 @@ def main():
                 out, oout, rec, orec, P = run_step_pair(model, mcfg, task, size, seed=seed, device=dev, fp64=True)
                 rows = grad_report(model, P)
                 loose = [r for r in rows if r[1] > 1.0 and r[3] > 1e-3]
-                rep = anchor_report(model, P, orec['P64'])
+                rep = anchor_report(model, P, orec['P64'], orec['P64b'])
                 ratios = sorted(r['ep'] / max(r['eo'], 1e-30) for r in rep)
+                ratios_b = sorted(r['ep'] / max(r['eo'], r['amb'], 1e-7) for r in rep)
+                qb = lambda p: ratios_b[min(len(ratios_b) - 1, int(p * len(ratios_b)))]
                 q = lambda p: ratios[min(len(ratios) - 1, int(p * len(ratios)))]
                 print(json.dumps(dict(task=task, size=size, seed=seed, prec=lib.rscotr_gemm_get_precision(), tensors=len(rows),
                                       over_tight=len(loose), worst_tight=sorted(r[1] for r in rows)[-3:],
@@ -47,6 +49,10 @@ def main():
                                       ep_med=sorted(r['ep'] for r in rep)[len(rep) // 2], ep_max=max(r['ep'] for r in rep),
                                       eo_med=sorted(r['eo'] for r in rep)[len(rep) // 2], eo_max=max(r['eo'] for r in rep),
                                       ratio_q=[q(0.5), q(0.9), q(0.97), q(0.99), ratios[-1]],
+                                      ratio_band_q=[qb(0.5), qb(0.9), qb(0.97), qb(0.99), ratios_b[-1]],
+                                      amb_med=sorted(r['amb'] for r in rep)[len(rep) // 2],
+                                      worst_band=[(r['name'], r['ep'], r['eo'], r['amb']) for r in
+                                                  sorted(rep, key=lambda r: -r['ep'] / max(r['eo'], r['amb'], 1e-7))[:4]],
                                       worst_ratio=[(r['name'], r['ep'], r['eo']) for r in sorted(rep, key=lambda r: -r['ep'] / max(r['eo'], 1e-30))[:4]],
                                       seconds=round(time.time() - t0, 1))), flush=True)
 

@@ -34,7 +34,7 @@ def cast_tree(obj, dt):
     return obj
 
 
-def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None):
+def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None, relu_band=None):
     """The oracle's train step evaluated in fp64 on the same weights, batch and draws, under the SAME hard decisions the
     fp32 evaluation took where they are injectable (seg attention masks and det top-k ride in rnd_cpu already; the 7*B
     assignments come from the fp32 record): the reference point that tells rounding error from wrong arithmetic.
@@ -44,9 +44,14 @@ def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None):
     rnd64 = cast_tree(dict(rnd_cpu or {}), torch.float64)
     if orec32 is not None and orec32.get('match'):
         rnd64['det_match'] = orec32['match']
-    with default_dtype(torch.float64):
-        out = OM.train_step(P64, model_cfg, cast_tree(batch_cpu, torch.float64), rnd64, {})
-        out['loss'].backward()
+    from oracle import ops as O
+    O.RELU_BAND = relu_band
+    try:
+        with default_dtype(torch.float64):
+            out = OM.train_step(P64, model_cfg, cast_tree(batch_cpu, torch.float64), rnd64, {})
+            out['loss'].backward()
+    finally:
+        O.RELU_BAND = None
     return P64, out
 
 
@@ -76,6 +81,8 @@ def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2
     oout['loss'].backward()
     if fp64:
         orec['P64'], orec['out64'] = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec)
+        # the same step with every ReLU gate within RELU_BAND of zero flipped: how far coin-toss gates can move a gradient
+        orec['P64b'], _ = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec, relu_band=RELU_BAND)
     return out, oout, rec, orec, P
 
 
@@ -98,10 +105,14 @@ def grad_report(model, P):
     return rows
 
 
-def anchor_report(model, P, P64):
+RELU_BAND = 3e-6  # gates within 3e-6 of the mean |pre-activation| of zero count as coin tosses (fp32 products: ~1e-6)
+
+
+def anchor_report(model, P, P64, P64b=None):
     """Per parameter tensor: ep / eo = relative L2 distance of the product's / the fp32 oracle's gradient from the fp64
-    evaluation of the same step (same decisions).  The denominator carries a floor (1e-5 of the largest gradient
-    maximum, spread over the tensor) so that tensors whose exact gradient is zero or negligible compare as zero."""
+    evaluation of the same step (same decisions); amb = the distance of the band-flipped fp64 evaluation (P64b).  The
+    denominator carries a floor (1e-5 of the largest gradient maximum, spread over the tensor) so that tensors whose
+    exact gradient is zero or negligible compare as zero."""
     gmax = max(float(p.grad.abs().max()) for p in P64.values() if p.grad is not None)
     rows = []
     for n, p in model.named_parameters():
@@ -110,7 +121,8 @@ def anchor_report(model, P, P64):
             continue
         den = float(g64.norm()) + 1e-5 * gmax * (g64.numel() ** 0.5)
         rows.append(dict(name=n, ep=float((p.grad.detach().cpu().double() - g64).norm()) / den,
-                         eo=float((P[n].grad.double() - g64).norm()) / den))
+                         eo=float((P[n].grad.double() - g64).norm()) / den,
+                         amb=0.0 if P64b is None or P64b[n].grad is None else float((P64b[n].grad - g64).norm()) / den))
     return rows
 
 

@@ -110,11 +110,12 @@ def test_step_is_bitwise_reproducible_across_processes(cuda):
     assert outs[0] == outs[1], outs
 
 
-@pytest.mark.parametrize('strategy', ['scatter'])
+@pytest.mark.parametrize('strategy', ['scatter', 'sorted'])
 def test_scatter_strategy_is_order_dependent_by_design(strategy, cuda):
-    """The atomic-scatter fallback of the MSDA backward (ops.MSDA_BWD_STRATEGY = 'scatter'; used when no workspace is
-    given) accumulates with fp32 atomics whose order varies from run to run: the one documented order-dependent op.
-    This test pins that statement — its gradients agree to rounding (1e-5 of the tensor's maximum), not bitwise."""
+    """The two non-default strategies of the MSDA backward are order-dependent by construction: 'scatter' (no workspace)
+    accumulates with fp32 atomics, 'sorted' (round 1; no host shapes) sums each token's taps in the order LDS-atomic
+    ranks left them.  This test pins that statement — their gradients agree to rounding (1e-5 of the tensor's maximum),
+    not bitwise; the forward pass is bitwise in every mode."""
     from rscotr_amd import ops
     cfg, mcfg = load_model_cfg(tiny=False)
     model = build_model(mcfg, seed=1).to(cuda)

@@ -303,3 +303,52 @@ def test_gemm_bf16x3_slices_and_kscale(cuda, gemm_precision):
         assert _rel(out, ref) < 3e-5 and _rel(db, ref_b) < 1e-5, mode
         outs[mode] = out
     assert not torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize('M,N,K,ak,bk', [(10880, 2048, 256, 0, 0), (10880, 256, 2048, 0, 1), (2048, 1536, 384, 0, 0),
+                                         (8192, 192, 768, 0, 1), (2048, 1024, 96, 1, 0), (256, 2048, 10880, 1, 1),
+                                         (384, 1536, 2048, 1, 1), (256, 256, 10880, 1, 1), (4096, 4096, 4096, 0, 0),
+                                         (1000, 768, 3072, 0, 0)])
+def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
+    """Precision mode 3 (gemm_bf16x6_kernel: three bf16 planes per fp32 operand, six MFMAs per k-step, fp32 accumulate)
+    against fp64 next to the fp32 matrix pipe on the step's own shapes, all four operand layouts, both tile sizes, with
+    the fused epilogue: its error must be of the fp32 FMA chain's class — at most 1e-6 of max|C| up to K = 2048 (VERDICT
+    r1 item 4), never more than twice the fp32 pipe's + 5e-7 — where round 1's two-plane product has 4-6e-6."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + ak + bk)
+    A = torch.randn((K, M) if ak else (M, K), generator=g)
+    B = torch.randn((K, N) if bk else (N, K), generator=g) * 0.05
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = ((A.double().t() if ak else A.double()) @ (B.double() if bk else B.double().t()) + bias.double()).clamp(min=0) \
+        + resid.double()
+    err, outs = {}, {}
+    for mode in (0, 3):
+        gemm_precision(mode)
+        outs[mode] = ops.gemm(A.to(cuda), B.to(cuda), M, N, K, A.shape[1], B.shape[1], ak, bk, bias=bias.to(cuda), act=1,
+                              resid=resid.to(cuda))
+        err[mode] = _rel(outs[mode], ref)
+    interior = M % 64 == 0 and N % 64 == 0 and K % 16 == 0
+    assert torch.equal(outs[0], outs[3]) != interior or not interior, (err, 'mode 3 must take the split product on interior shapes')
+    assert err[3] <= 2.0 * err[0] + 5e-7, err
+    if K <= 2048:
+        assert err[3] <= 1e-6, err
+
+
+def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
+    """The dW route of mode 3: k-slices through slabs (immediate combine and accumulate into C), the bias gradient riding
+    along (row sums of the k-major A operand, taken from the fp32 registers) and per-sample k scaling (stochastic depth)."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 384, 1536, 2048
+    G, X, ks = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g), torch.rand(2, generator=g) + 0.5
+    Gs = G.double() * ks.double().repeat_interleave(K // 2)[:, None]
+    ref, ref_b = Gs.t() @ X.double(), Gs.sum(0)
+    C0 = torch.randn(M, N, generator=g)
+    for mode in (0, 3):
+        gemm_precision(mode)
+        db = torch.empty(M, device=cuda)
+        out = ops.gemm(G.to(cuda), X.to(cuda), M, N, K, M, N, 1, 1, rowsum=db, kscale=ks.to(cuda), krows_per=K // 2)
+        assert _rel(out, ref) < 2e-6 and _rel(db, ref_b) < 1e-5, mode
+        acc = C0.clone().to(cuda)
+        ops.gemm(G.to(cuda), X.to(cuda), M, N, K, M, N, 1, 1, out=acc, accumulate=True, kscale=ks.to(cuda), krows_per=K // 2)
+        assert _rel(acc, ref + C0.double()) < 2e-6, mode

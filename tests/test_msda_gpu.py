@@ -7,7 +7,7 @@ from oracle import ops as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['sorted', 'scatter'], autouse=True)
+@pytest.fixture(params=['tiled', 'sorted', 'scatter'], autouse=True)
 def bwd_strategy(request):
     """Both grad_value strategies of rscotr_msda_bwd run every test (include/rscotr.h)."""
     from rscotr_amd import ops
@@ -199,22 +199,22 @@ def test_msda_large_pyramids(cuda, bwd_strategy, shapes, expect):
     """Pyramids whose host-side bin bound (2 Nk + 2 L + 2) exceeds the LDS histogram: the kernels decide on the
     device from the level shapes whether the sorted path runs or stands down for the atomic scatter (csrc/msda.hip,
     MSDA_LDS_WORDS); either way the result equals the caller-selected scatter strategy's."""
-    if bwd_strategy != 'sorted':
-        pytest.skip('compares the sorted entry against the scatter entry itself')
+    if bwd_strategy == 'scatter':
+        pytest.skip('compares the workspace strategies against the scatter entry itself')
     from rscotr_amd import ops
     Nk = sum(h * w for h, w in shapes)
     Nq = 4000
     value, ss, lsi, loc, attn = _inputs(1, shapes, Nq, 8, 32, 4, seed=11, spread=0.05)
     go = torch.randn(1, Nq, 256, generator=torch.Generator().manual_seed(3)).to(cuda)
     res = {}
-    for strat in ('sorted', 'scatter'):
+    for strat in (bwd_strategy, 'scatter'):
         ops.MSDA_BWD_STRATEGY = strat
         v, l, a = (t.clone().to(cuda).requires_grad_(True) for t in (value, loc, attn))
         out = ops.msda(v, ss.to(cuda), lsi.to(cuda), l, a)
         out.backward(go)
         res[strat] = (out.detach(), v.grad, l.grad, a.grad)
-    ops.MSDA_BWD_STRATEGY = 'sorted'
+    ops.MSDA_BWD_STRATEGY = bwd_strategy
     assert Nk * 2 + 2 * len(shapes) + 2 > (156 * 1024) // 4  # the regime under test
-    for s_, c_ in zip(res['sorted'], res['scatter']):
+    for s_, c_ in zip(res[bwd_strategy], res['scatter']):
         assert torch.isfinite(s_).all()
         _close(c_.cpu(), s_.cpu(), rtol=1e-4, atol=1e-4 * float(c_.abs().max()) + 1e-7)

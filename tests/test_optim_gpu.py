@@ -98,26 +98,24 @@ def test_graphed_iterations_match_eager(cuda):
         opt.close()
         return model, logs
 
-    # the capturing iteration applies its batch three times (2 warm-up runs + the capture run)
-    eager_seq = batches[:2] + [batches[2]] * 3 + [batches[3]] * 3 + batches[4:]
-    m_e, logs_e = run((), eager_seq)
+    # the capturing iteration applies its batch ONCE (the two warm-up runs are rolled back): the graphed run walks the same
+    # trajectory as the eager loop, batch for batch
+    m_e, logs_e = run((), batches)
     m_g, logs_g = run(('cls', 'seg'), batches)
-    for a, b in ((logs_g[4], logs_e[8]), (logs_g[5], logs_e[9])):
+    for a, b in ((logs_g[2], logs_e[2]), (logs_g[3], logs_e[3]), (logs_g[4], logs_e[4]), (logs_g[5], logs_e[5])):
         assert list(a) == list(b)
         for k in a:
             if 'loss' not in k:
                 continue  # acc_seg is an arg-max statistic of a near-random tiny model
-            # ten training iterations amplify summation-order noise (fp32 atomics in a few reductions):
-            # two EAGER runs of the same sequence differ by ~1e-4 (cls) / ~5e-4 (seg, whose loss also
-            # passes through 9 layers of hard `sigmoid(mask) < 0.5` attention masks)
+            # (seg: the loss passes through 9 layers of hard `sigmoid(mask) < 0.5` attention masks)
             tol = 2e-3 if k.startswith('cls') else 1e-2
             assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-3), (k, a[k], b[k])
     sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
     # AdamW moves every weight by ~lr per step whatever the gradient's size, so a near-zero gradient whose
     # sign is noise can diverge by 2*lr per step; on average the two runs must coincide
     diffs = torch.cat([(sd_e[k] - sd_g[k]).abs().flatten() for k in sd_e if sd_e[k].dtype.is_floating_point])
-    assert float(diffs.max()) <= 10 * 2 * 5e-5, float(diffs.max())
-    assert float(diffs.mean()) <= 3e-5, float(diffs.mean())  # a dropped update would show as ~10 * lr
+    assert float(diffs.max()) <= 6 * 2 * 5e-5, float(diffs.max())
+    assert float(diffs.mean()) <= 2e-5, float(diffs.mean())  # a dropped update would show as ~6 * lr
 
 
 @pytest.mark.parametrize('task', ['seg', 'det'])

@@ -91,10 +91,11 @@ def test_static_det_equals_dynamic_det_at_size(which, cuda):
 @pytest.mark.parametrize('workload', ['det800', 'swinb1024'])
 def test_graph_replay_equals_eager_at_size(workload, cuda):
     """The hipGraph-replayed iterations (what bench.py times) against eager ones at the full size of configs[3] /
-    configs[4]: two runners from identical weights walk the same batches for three rounds (eager, capture, first replay).
-    The denoising noise is drawn on the device and differs between the two (the capture's warm-ups consume draws), so the
-    comparison is on the log variables that do not depend on it — every key except the `dn_` ones — at the first replay,
-    where the weights have seen two updates that differ only through the denoising losses' gradients; everything finite."""
+    configs[4]: two runners from identical weights walk the same batches for three rounds (eager, capture + first replay,
+    replay).  The denoising noise is drawn on the device and differs between the two (the capture's warm-ups consume
+    draws), so the comparison is on the log variables that do not depend on it — every key except the `dn_` ones — in the
+    round of the capture, which both runners enter with identical weights (the warm-ups are rolled back); everything
+    stays finite through the third round."""
     import importlib.util
     import os
     import numpy as np
@@ -119,9 +120,12 @@ def test_graph_replay_equals_eager_at_size(workload, cuda):
                                                  max_gt=wl['max_gt'], pool=1)
         runner = build_runner(model, cfg, loader, graph_tasks=wl['tasks'] if graphs else ())
         last = {}
-        for _ in range(3 * len(wl['tasks'])):
+        for i in range(3 * len(wl['tasks'])):
             out = runner.train_iter()
-            last[runner.last_task] = dict(out['log_vars'])
+            if i // len(wl['tasks']) == 1:
+                last[runner.last_task] = dict(out['log_vars'])
+            else:
+                assert all(v == v and abs(v) < 1e6 for v in dict(out['log_vars']).values()), (i, runner.last_task)
         torch.cuda.synchronize()
         assert set(runner.graphed) == (set(wl['tasks']) if graphs else set())
         for n, p in model.named_parameters():
@@ -137,3 +141,5 @@ def test_graph_replay_equals_eager_at_size(workload, cuda):
             if 'dn_' in k or k.endswith('.loss'):
                 continue
             assert abs(v - le[task][k]) <= 5e-3 * max(abs(le[task][k]), 1e-2), (k, v, le[task][k])
+    # (in round 2 the tasks after the first see weights that already differ through the denoising gradients of the
+    # round's earlier det update: AdamW moves every weight by ~lr whatever the gradient's size -> 5e-3, not 1e-5)
