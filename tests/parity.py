@@ -137,9 +137,22 @@ def anchor_report(model, P, P64, P64b=None):
 # implementations a handful land on the other side of zero, each moving one row of one weight gradient (the
 # failing tensors show exactly that signature: <= 0.05 % of their elements off) and, through the residual
 # stream, nudging the tensors downstream of it to ~1.1e-3.
-TIGHT_FRACTION = 0.90   # share of parameter tensors that must pass at RTOL (measured: 94-100 %, see below)
+TIGHT_FRACTION = 0.97   # share of parameter tensors that must pass at RTOL (measured over 12 cases at 256^2 / 512^2, two
+                        # seeds: 97.7-100 %; gpurun_out/r2t2_parity_stats.jsonl)
 LOOSE_L2 = 3e-2         # relative L2 bound for the remaining tensors
 LOOSE_MAX = 30.0        # and their worst element stays within 30x the tight tolerance
+
+# The fp64 anchor.  With orec['P64'] / orec['P64b'] present (run_step_pair(fp64=True)) every gradient
+# tensor of the product is also held against the SAME step evaluated in fp64 under the same injected decisions:
+#   ep = |g_product - g_fp64| / |g_fp64|,  eo = the same for the fp32 oracle,  amb = the same for the fp64 evaluation with
+#   every ReLU gate within RELU_BAND of zero flipped (what coin-toss gates can do to the tensor).
+# Measured (MI355X, 12 cases): ep / max(eo, amb, 2e-7) has median 0.03-1.0, 97th percentile 1.1-2.4, 99th <= 3.7; the tail
+# (max 5.7, one case 77) sits on tensors fed by OTHER coin-toss decisions the band does not flip (bilinear cell boundaries
+# of the deformable sampling: |frac| within fp32 rounding of 0 moves d/d(location) to the neighbouring cell's slope).
+ANCHOR_K = 4.0          # ep <= ANCHOR_K * max(eo, amb, ANCHOR_FLOOR) for at least ANCHOR_FRACTION of the tensors
+ANCHOR_FRACTION = 0.97
+ANCHOR_K_ALL = 150.0    # ... and within this factor for every tensor
+ANCHOR_FLOOR = 2e-7
 
 
 def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LOOSE_MAX):
@@ -172,6 +185,15 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
     assert len(rows) - len(loose) >= TIGHT_FRACTION * len(rows), out['grad_report']
     bad = [r for r in loose if r[3] > LOOSE_L2 or (loose_max is not None and r[1] > loose_max)]
     assert not bad, bad[:5]
+    if 'P64' in orec:
+        rep = anchor_report(model, P, orec['P64'], orec.get('P64b'))
+        ratio = sorted(((r['ep'] / max(r['eo'], r['amb'], ANCHOR_FLOOR), r['name']) for r in rep), reverse=True)
+        within = sum(1 for x, _ in ratio if x <= ANCHOR_K)
+        out['anchor_report'] = dict(tensors=len(rep), within_k=within, worst=ratio[:5],
+                                    ep_med=sorted(r['ep'] for r in rep)[len(rep) // 2],
+                                    eo_med=sorted(r['eo'] for r in rep)[len(rep) // 2])
+        assert within >= ANCHOR_FRACTION * len(rep), out['anchor_report']
+        assert ratio[0][0] <= ANCHOR_K_ALL, out['anchor_report']
     if 'attn_masks' in rec and 'attn_masks' in orec:
         # masked-attention decisions: the oracle's own masks vs the product's, bit for bit; a logit
         # within fp32 rounding of 0 may land on either side, nothing else may differ

@@ -28,22 +28,27 @@ def test_train_step_main_config_256(task, cuda):
     """The real config (600 queries, 100 CDN) at 256x256, B=2: N = 1360 encoder tokens."""
     cfg, mcfg = load_model_cfg(tiny=False)
     model = build_model(mcfg, seed=1).to(cuda)
-    out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 256, seed=11, device=cuda)
+    out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 256, seed=11, device=cuda, fp64=True)
     check_step_pair(model, out, oout, rec, orec, P)
 
 
+@pytest.mark.parametrize('prec', [0, 3])
 @pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
-def test_train_step_main_config_512(task, cuda):
+def test_train_step_main_config_512(task, prec, cuda):
     """BASELINE configs[1] itself (512x512, B=2: N = 5440 encoder tokens, 10880-row products) against the oracle under the
-    default precision mode of the GEMM (0: fp32 matrix pipe): losses, gradients of every parameter (two tiers, as at every
-    other size, minus the element-wise bound of the loose tier: with 4x the tokens of the 256^2 case more ReLU gates sit
-    within rounding distance of zero) and the Hungarian indices."""
+    default precision mode of the GEMM: losses, gradients of every parameter (two tiers against the fp32 oracle, element-wise
+    bound of the loose tier included; the fp64 anchor of tests/parity.py on top) and the Hungarian indices — under BOTH
+    fp32-accurate precision modes of the GEMM: 0 (fp32 matrix pipe) and 3 (bf16x6: three-plane split product)."""
     from rscotr_amd._lib import lib
-    assert lib.rscotr_gemm_get_precision() == 0
-    cfg, mcfg = load_model_cfg(tiny=False)
-    model = build_model(mcfg, seed=4).to(cuda)
-    out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda)
-    check_step_pair(model, out, oout, rec, orec, P, loose_max=None)
+    old = lib.rscotr_gemm_get_precision()
+    lib.call('rscotr_gemm_set_precision', prec)
+    try:
+        cfg, mcfg = load_model_cfg(tiny=False)
+        model = build_model(mcfg, seed=4).to(cuda)
+        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda, fp64=True)
+    finally:
+        lib.call('rscotr_gemm_set_precision', old)
+    check_step_pair(model, out, oout, rec, orec, P)
 
 
 @pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
