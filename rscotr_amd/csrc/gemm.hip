@@ -1169,17 +1169,24 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   Split6Cfg c{0, 1, p.K};
   static const int on = getenv("RSCOTR_BF16X6") ? atoi(getenv("RSCOTR_BF16X6")) : 1;
   static const long t128_min = getenv("RSCOTR_BF16X6_T128") ? atol(getenv("RSCOTR_BF16X6_T128")) : 512;
-  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 340;
+  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 512;
+  static const long dw_t128_min = getenv("RSCOTR_BF16X6_DW_T128") ? atol(getenv("RSCOTR_BF16X6_DW_T128")) : 24;
+  static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
   static const int gelu_ok = getenv("RSCOTR_BF16X6_GELU") ? atoi(getenv("RSCOTR_BF16X6_GELU")) : 1;
   static const int dw_ok = getenv("RSCOTR_BF16X6_DW") ? atoi(getenv("RSCOTR_BF16X6_DW")) : 1;
-  if (!on || !p.vecA || !p.vecB || p.K % 16 || p.K < 64 || p.M % 64 || p.N % 64) return c;
+  // Measured on the step (gpurun_out/r2t3_gemm_census_bf16x6.txt against profiles/r1_s7_gemm_census_fp32.txt): the split
+  // product wins where the MFMA work dominates — the encoder FFN products (117 -> 85 us, 125 -> 100 us), their weight
+  // gradients (124 -> 75 us), the 10880- / 2048-row products with K >= 256 (5-15 %) — and loses on small outputs (256 x 256
+  // weight gradients: 22.6 -> 32.5 us: too few tiles to hide the staging), on K < 192 (conversion not amortised) and where
+  // the epilogue's memory traffic bounds the launch anyway.
+  if (!on || !p.vecA || !p.vecB || p.K % 16 || p.K < k_min || p.M % 64 || p.N % 64) return c;
   if (!gelu_ok && (p.act == ACT_GELU || p.act == ACT_GELU_GRAD || p.pre)) return c;
   const long t64 = (long)(p.M / 64) * (p.N / 64);
   const long t128 = (p.M % 128 == 0 && p.N % 128 == 0) ? (long)(p.M / 128) * (p.N / 128) : 0;
   if (a_kmajor && b_kmajor) {  // weight gradients: small outputs, long reductions -> k-slices through slabs
-    if (!dw_ok || p.rowscale || p.K < 1024) return c;
-    const int bm = t128 >= 16 ? 128 : 64;
-    const long tiles = bm == 128 ? t128 : t64;
+    if (!dw_ok || p.rowscale || p.K < 1024 || t128 < dw_t128_min) return c;
+    const int bm = 128;
+    const long tiles = t128;
     if (tiles > 2048) return c;
     long sp = std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, p.K / 256));
     const int64_t per = ((int64_t)p.M * p.N + p.M) * 4;

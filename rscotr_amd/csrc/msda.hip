@@ -323,13 +323,13 @@ constexpr int MSDA_MAXL = 16;    // levels
 // device); the kernels know NE = sum (H_l + 1)(W_l + 1) (~1.03 Nk for image pyramids) and all take the same
 // decision: NE > lds_words -> the sorted path stands down and the sample kernel scatters with atomics instead.
 constexpr int MSDA_LDS_WORDS = (156 * 1024) / 4;
-constexpr int MSDA_MAXCHUNK = 16;  // sample chunks per (b,h) in the histogram pass
+constexpr int MSDA_MAXCHUNK = 64;  // sample chunks (one wavefront each) per (b,h) in the histogram pass
 
 struct MsdaWs {
   long chunkcnt;  // word offset of chunkcnt[BH][C][NEmax] (cnt[BH][NEmax] sits at offset 0)
   long body;      // word offset of the first per-(b,h) block
   long per_bh;    // words per (b,h) block
-  long start, keyrank, sorted, itemoff, items, nitems;  // word offsets inside a bh block
+  long start, keyrank, sorted, itemoff, items, nitems, cpart, mclist;  // word offsets inside a bh block
   int NEmax, maxItems, C, CH;
   int lds_words;  // bins the LDS histogram of the hist / plan kernels can hold (<= NEmax)
 };
@@ -341,7 +341,7 @@ static MsdaWs msda_ws_layout(int BH, int Nk, int Nq, int L, int P) {
   w.lds_words = std::min(w.NEmax, MSDA_LDS_WORDS);
   w.CH = msda_ch();
   w.maxItems = (int)(Nk + (S * 4 + w.CH - 1) / w.CH + 1);
-  w.C = (int)std::max<long>(1, std::min<long>(MSDA_MAXCHUNK, S / 2048));
+  w.C = (int)std::max<long>(1, std::min<long>(MSDA_MAXCHUNK, S / 1024));
   w.chunkcnt = ((long)BH * w.NEmax + 3) & ~3L;
   w.body = (w.chunkcnt + (long)BH * w.C * w.NEmax + 3) & ~3L;
   long o = 0;
@@ -354,6 +354,9 @@ static MsdaWs msda_ws_layout(int BH, int Nk, int Nq, int L, int P) {
   o = (o + 1) & ~1L;
   w.items = o; o += 2L * w.maxItems;
   w.nitems = o; o += 2;
+  o = (o + 3) & ~3L;
+  w.cpart = o; o += (long)w.maxItems * 64;  // one partial row (<= 64 channels) per work item of a multi-chunk token
+  w.mclist = o; o += Nk + 2;                // [0] = number of multi-chunk tokens, then their ids (ascending)
   w.per_bh = (o + 3) & ~3L;
   return w;
 }
@@ -377,9 +380,12 @@ __device__ __forceinline__ void load_geom(LevelGeom* g, const int64_t* shapes, c
   __syncthreads();
 }
 
-// grid (C, BH): LDS histogram of one chunk of the samples of (b,h) over the extended bins; the
-// LDS atomic's return value is the sample's rank inside (chunk, bin).
-__global__ __launch_bounds__(256) void msda_hist_kernel(const int64_t* __restrict__ shapes,
+// grid (C, BH), ONE wavefront per workgroup: LDS histogram of one chunk of the samples of (b,h) over the extended bins;
+// the LDS atomic's return value is the sample's rank inside (chunk, bin).  One wavefront walks its chunk in program order,
+// so the ranks depend on nothing but the data (the LDS serialises the equal-bin lanes of one instruction in a fixed
+// order): the sorted record order, hence the summation order of the pull kernel, is the same in every run.  (With four
+// wavefronts per chunk — round 1 — their atomics interleaved by timing and grad_value was reproducible to rounding only.)
+__global__ __launch_bounds__(64) void msda_hist_kernel(const int64_t* __restrict__ shapes,
                                                         const int64_t* __restrict__ lsi,
                                                         const float* __restrict__ loc, int* __restrict__ ws,
                                                         MsdaWs W, int Nq, int H, int L, int P) {
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void msda_hist_kernel(const int64_t* __restric
   load_geom(&g, shapes, lsi, L);
   const int NE = g.ext[L];
   if (NE > W.lds_words) return;  // scatter fallback (see MSDA_LDS_WORDS)
-  for (int i = threadIdx.x; i < NE; i += 256) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < NE; i += 64) s_cnt[i] = 0;
   __syncthreads();
   const int LP = L * P;
   const long S = (long)Nq * LP;
@@ -396,23 +402,38 @@ __global__ __launch_bounds__(256) void msda_hist_kernel(const int64_t* __restric
   const int b = bh / H, h = bh % H;
   int* base = ws + W.body + (long)bh * W.per_bh;
   const long s0 = S * c / W.C, s1 = S * (c + 1) / W.C;
-  for (long sid = s0 + threadIdx.x; sid < s1; sid += 256) {
-    const int q = (int)(sid / LP), lp = (int)(sid - (long)q * LP), l = lp / P;
-    const float2 xy = *reinterpret_cast<const float2*>(loc + ((((long)b * Nq + q) * H + h) * LP + lp) * 2);
-    const int Hl = g.Hl[l], Wl = g.Wl[l];
-    const float h_im = xy.y * (float)Hl - 0.5f, w_im = xy.x * (float)Wl - 0.5f;
-    const bool in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
-    int key = -1, rank = 0;
-    if (in) {
-      const int ye = (int)floorf(h_im) + 1, xe = (int)floorf(w_im) + 1;
-      key = g.ext[l] + ye * (Wl + 1) + xe;
-      rank = atomicAdd(&s_cnt[key], 1);
+  // four rounds of locations in flight per wavefront (the chain load -> LDS atomic -> store is latency-bound otherwise)
+  for (long r0 = s0; r0 < s1; r0 += 4 * 64) {
+    float2 xy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long sid = r0 + u * 64 + threadIdx.x;
+      xy[u] = make_float2(-9.f, -9.f);
+      if (sid < s1) {
+        const int q = (int)(sid / LP), lp = (int)(sid - (long)q * LP);
+        xy[u] = *reinterpret_cast<const float2*>(loc + ((((long)b * Nq + q) * H + h) * LP + lp) * 2);
+      }
     }
-    *reinterpret_cast<int2*>(base + W.keyrank + 2 * sid) = make_int2(key, rank);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long sid = r0 + u * 64 + threadIdx.x;
+      if (sid >= s1) continue;
+      const int lp = (int)(sid % LP), l = lp / P;
+      const int Hl = g.Hl[l], Wl = g.Wl[l];
+      const float h_im = xy[u].y * (float)Hl - 0.5f, w_im = xy[u].x * (float)Wl - 0.5f;
+      const bool in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
+      int key = -1, rank = 0;
+      if (in) {
+        const int ye = (int)floorf(h_im) + 1, xe = (int)floorf(w_im) + 1;
+        key = g.ext[l] + ye * (Wl + 1) + xe;
+        rank = atomicAdd(&s_cnt[key], 1);
+      }
+      *reinterpret_cast<int2*>(base + W.keyrank + 2 * sid) = make_int2(key, rank);
+    }
   }
   __syncthreads();
   int* out = ws + W.chunkcnt + ((long)bh * W.C + c) * W.NEmax;
-  for (int i = threadIdx.x; i < NE; i += 256) out[i] = s_cnt[i];
+  for (int i = threadIdx.x; i < NE; i += 64) out[i] = s_cnt[i];
 }
 
 // grid (ceil(NEmax/256), BH): per bin, exclusive prefix over the chunks (in place) and the total
@@ -504,6 +525,7 @@ __global__ __launch_bounds__(1024) void msda_plan_kernel(const int64_t* __restri
     }
     int total;
     int run = block_exclusive_scan(sum, s_part, &total);
+    int nmc = 0;
     for (int tok = t0; tok < t1; ++tok) {
       int l = 0;
       while (l + 1 < L && tok >= g.lsi[l + 1]) ++l;
@@ -514,12 +536,16 @@ __global__ __launch_bounds__(1024) void msda_plan_kernel(const int64_t* __restri
       const int nch = max(1, (taps + W.CH - 1) / W.CH);
       itemoff[tok] = run;
       for (int j = 0; j < nch; ++j) items[run + j] = make_int2(tok, j);
-      if (nch > 1) {  // chunks of this token combine with atomics: start from zero
-        float* gv = grad_value + (((long)b * Nk + tok) * H + h) * D;
-        for (int c = 0; c < D; ++c) gv[c] = 0.f;
-      }
       run += nch;
+      nmc += nch > 1;
     }
+    // tokens whose list was cut into several items, in ascending order (the chunk-combine kernel walks this list)
+    int mtotal;
+    int mrun = block_exclusive_scan(nmc, s_part, &mtotal);
+    int* mclist = base + W.mclist;
+    for (int tok = t0; tok < t1; ++tok)
+      if (itemoff[tok] + 1 < ((tok + 1 < t1) ? itemoff[tok + 1] : run)) mclist[1 + mrun++] = tok;
+    if (tid == 0) mclist[0] = mtotal;
     if (tid == 0) {
       itemoff[Nk] = total;
       base[W.nitems] = total;
@@ -567,7 +593,7 @@ template <int D, int U>
 __global__ __launch_bounds__(256) void msda_pull_kernel(const int64_t* __restrict__ shapes,
                                                         const int64_t* __restrict__ lsi,
                                                         const float* __restrict__ grad_out,
-                                                        float* __restrict__ grad_value, const int* __restrict__ ws,
+                                                        float* __restrict__ grad_value, int* __restrict__ ws,
                                                         MsdaWs W, int Nk, int Nq, int H, int L, int blocks_per_bh) {
   constexpr int GPB = 256 / D;  // lane groups per workgroup
   __shared__ LevelGeom g;
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(256) void msda_pull_kernel(const int64_t* __restric
   if (g.ext[L] > W.lds_words) return;
   const int bh = blockIdx.x / blocks_per_bh, blk = blockIdx.x - bh * blocks_per_bh;
   const int b = bh / H, h = bh % H;
-  const int* base = ws + W.body + (long)bh * W.per_bh;
+  int* base = ws + W.body + (long)bh * W.per_bh;
   const int* cnt = ws + (long)bh * W.NEmax;
   const int grp = threadIdx.x / D, ln = threadIdx.x % D;
   const int nitems = base[W.nitems];
@@ -665,11 +691,35 @@ __global__ __launch_bounds__(256) void msda_pull_kernel(const int64_t* __restric
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (!live[u]) continue;
-    float* dst = grad_value + (((long)b * Nk + it[u].x) * H + h) * D + ln;
-    if (nch[u] > 1)
-      unsafeAtomicAdd(dst, acc[u]);  // chunks of a long list meet in the zeroed row (msda_plan_kernel)
-    else
-      *dst = acc[u];
+    if (nch[u] > 1) {  // chunk of a long list: partial row, folded in chunk order by msda_chunk_combine_kernel (no atomics)
+      const int item = (blk * U + u) * GPB + grp;
+      reinterpret_cast<float*>(base + W.cpart)[(long)item * D + ln] = acc[u];
+    } else {
+      grad_value[(((long)b * Nk + it[u].x) * H + h) * D + ln] = acc[u];
+    }
+  }
+}
+
+// grad_value rows of the tokens whose tap list was cut into several work items: partial rows summed in chunk order.
+// grid (blocks, BH): D lanes per token of the (b,h)'s multi-chunk list (msda_plan_kernel).
+template <int D>
+__global__ __launch_bounds__(256) void msda_chunk_combine_kernel(const int64_t* __restrict__ shapes, float* __restrict__ grad_value,
+                                                                 const int* __restrict__ ws, MsdaWs W, int Nk, int H, int L) {
+  int NE = 0;
+  for (int l = 0; l < L; ++l) NE += ((int)shapes[2 * l] + 1) * ((int)shapes[2 * l + 1] + 1);
+  if (NE > W.lds_words) return;  // the sorted path stood down
+  constexpr int TPB = 256 / D;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int* base = ws + W.body + (long)bh * W.per_bh;
+  const int* mclist = base + W.mclist;
+  const int n = mclist[0], ln = threadIdx.x % D;
+  const float* part = reinterpret_cast<const float*>(base + W.cpart);
+  for (int k = blockIdx.x * TPB + threadIdx.x / D; k < n; k += gridDim.x * TPB) {
+    const int tok = mclist[1 + k];
+    const int i0 = base[W.itemoff + tok], i1 = base[W.itemoff + tok + 1];
+    float v = 0.f;
+    for (int j = i0; j < i1; ++j) v += part[(long)j * D + ln];
+    grad_value[(((long)b * Nk + tok) * H + h) * D + ln] = v;
   }
 }
 
@@ -688,9 +738,9 @@ __global__ __launch_bounds__(256) void msda_pull_kernel(const int64_t* __restric
 //   2. msda_tile_acc_kernel: one workgroup per (b, h, tile) with the block's accumulators in LDS.  Its four wavefronts own
 //      the four tap parities (x & 1, y & 1) — the 2x2 footprint of a sample has exactly one tap of each parity — so no two
 //      wavefronts ever touch the same accumulator; inside a wavefront the records are processed in list order, 64 / (D/4)
-//      samples per step, D/4 lanes x float4 per sample: grad_out row gather (L2-resident: one head per XCD) and four LDS
-//      atomic adds (ds_add_f32; same-address lanes of one instruction are serialised by the LDS in lane order).  The block
-//      is then written to a partial buffer.
+//      samples per step, D/4 lanes x float4 per sample: grad_out row gather (L2-resident: one head per XCD) and a plain
+//      LDS read-add-write of the cell's row; the samples of one step that hit the same cell are applied in sample order
+//      (rank among equal cells from wave shuffles, one round per rank).  The block is then written to a partial buffer.
 //   3. msda_tile_combine_kernel: grad_value[token] = its own tile's cell + the halo cells of the left / upper / upper-left
 //      neighbour tiles, fixed order.
 // The result is bit-reproducible; traffic: 16-byte records written + read once, partial blocks ~1.2x grad_value.
@@ -872,7 +922,7 @@ __global__ __launch_bounds__(256) void msda_tile_acc_kernel(const float* __restr
   const int tl = tile - T.tbase[l], ty = tl / ntx, tx = tl - ty * ntx;
   const int Wl = T.Wl[l], Hl = T.Hl[l];
   const int bw = ts + 1, ncell = bw * bw;
-  float* acc = smem;                                          // [ncell][D], channel positions skewed per cell (banks)
+  float* acc = smem;                                          // [ncell][D]
   int* s_pre = reinterpret_cast<int*>(smem + 17 * 17 * D);    // [K + 1] exclusive prefix of the segment lengths
   int* s_adr = s_pre + NCH + 1;                               // [K] first record of the segment
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -946,21 +996,36 @@ __global__ __launch_bounds__(256) void msda_tile_acc_kernel(const float* __restr
   auto accumulate = [&](const TileRec (&r)[U], const float4 (&g)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!r[u].ok) continue;
-      const int lx = (r[u].r.x >> 20) & 31, ly = (r[u].r.x >> 25) & 31;  // local top-left cell + 1
-      const int dx = px ^ ((lx + 1) & 1), dy = py ^ ((ly + 1) & 1);      // the tap of this wavefront's parity (ts is even)
-      const int cx = lx - 1 + dx, cy = ly - 1 + dy;
-      const int x = (tx << tsh) + cx, y = (ty << tsh) + cy;
-      if (x < 0 || y < 0 || x >= Wl || y >= Hl) continue;
-      const float a = __int_as_float(r[u].r.y), lw = __int_as_float(r[u].r.z), lh = __int_as_float(r[u].r.w);
-      const float w = a * (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
-      const int cell = cy * bw + cx;
-      float* dst = acc + cell * D;
-      const int sk = sub + G * (cell & 3);
-      atomicAdd(dst + ((sk + 0 * G) & (D - 1)), w * g[u].x);
-      atomicAdd(dst + ((sk + 1 * G) & (D - 1)), w * g[u].y);
-      atomicAdd(dst + ((sk + 2 * G) & (D - 1)), w * g[u].z);
-      atomicAdd(dst + ((sk + 3 * G) & (D - 1)), w * g[u].w);
+      int cell = -1;
+      float w = 0.f;
+      if (r[u].ok) {
+        const int lx = (r[u].r.x >> 20) & 31, ly = (r[u].r.x >> 25) & 31;  // local top-left cell + 1
+        const int dx = px ^ ((lx + 1) & 1), dy = py ^ ((ly + 1) & 1);      // the tap of this wavefront's parity (ts is even)
+        const int cx = lx - 1 + dx, cy = ly - 1 + dy;
+        const int x = (tx << tsh) + cx, y = (ty << tsh) + cy;
+        if (x >= 0 && y >= 0 && x < Wl && y < Hl) {
+          const float a = __int_as_float(r[u].r.y), lw = __int_as_float(r[u].r.z), lh = __int_as_float(r[u].r.w);
+          w = a * (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+          cell = cy * bw + cx;
+        }
+      }
+      // The SPW samples of this step may hit the same cell: they are applied in sample order, one round per rank among
+      // the samples of equal cell (plain LDS read-add-write: no LDS float atomics — those run at about one lane per
+      // clock per CU on gfx950 and made this kernel 10x slower).  Nearly always one round.
+      int rank = 0;
+#pragma unroll
+      for (int g2 = 0; g2 < SPW; ++g2) {
+        const int c2 = __shfl(cell, g2 * G, 64);
+        if (g2 < grp && c2 == cell) ++rank;
+      }
+      for (int rd = 0; __any(cell >= 0 && rank >= rd); ++rd) {
+        if (cell >= 0 && rank == rd) {
+          float4* dst = reinterpret_cast<float4*>(acc + cell * D + sub * 4);
+          float4 v = *dst;
+          v.x += w * g[u].x; v.y += w * g[u].y; v.z += w * g[u].z; v.w += w * g[u].w;
+          *dst = v;
+        }
+      }
     }
   };
   if (niter > 0) {  // three-stage software pipeline: records two iterations ahead, grad_out rows one iteration ahead
@@ -979,10 +1044,7 @@ __global__ __launch_bounds__(256) void msda_tile_acc_kernel(const float* __restr
   }
   __syncthreads();
   float* prow = part + ((long)bh * T.prows + T.pbase[l] + (long)tl * ncell) * D;
-  for (int i = tid; i < ncell * D; i += 256) {
-    const int cell = i / D, c = i - cell * D;
-    prow[i] = acc[cell * D + (((c >> 2) + (c & 3) * G + G * (cell & 3)) & (D - 1))];
-  }
+  for (int i = tid; i < ncell * D; i += 256) prow[i] = acc[i];
 }
 
 // grad_value row of every token = own tile's cell + the neighbours' halo cells that alias it, fixed order
@@ -1095,7 +1157,7 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
     hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_plan_kernel<D>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
   }
-  msda_hist_kernel<<<dim3(W.C, BH), 256, hist_lds, s>>>(shapes, lsi, loc, ws, W, Nq, H, L, P);
+  msda_hist_kernel<<<dim3(W.C, BH), 64, hist_lds, s>>>(shapes, lsi, loc, ws, W, Nq, H, L, P);
   if (may_stand_down) {
     // grad_value zeroed for the scatter the sample kernel falls back to; on the sorted path the pull kernel overwrites it
     hipMemsetAsync(gv, 0, (size_t)B * Nk * H * D * sizeof(float), s);
@@ -1117,6 +1179,7 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
     const int bpb = (W.maxItems + 2 * GPB - 1) / (2 * GPB);
     msda_pull_kernel<D, 2><<<dim3((unsigned)((long)BH * bpb)), 256, 0, s>>>(shapes, lsi, go, gv, ws, W, Nk, Nq, H, L, bpb);
   }
+  msda_chunk_combine_kernel<D><<<dim3(64, BH), 256, 0, s>>>(shapes, gv, ws, W, Nk, H, L);
 }
 
 #define RSCOTR_DISPATCH_DP(D, P, CALL)                         \
@@ -1167,12 +1230,6 @@ extern "C" int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L
   return (int64_t)(W.body + (long)B * H * W.per_bh) * 4;
 }
 
-// 0 = sorted (round 1), 1 = tiled (deterministic; needs the host copy of the level shapes)
-static int msda_bwd_mode() {
-  static const int v = [] { const char* e = getenv("RSCOTR_MSDA_BWD"); return (e && !strcmp(e, "sorted")) ? 0 : 1; }();
-  return v;
-}
-
 extern "C" int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L,
                                                    int P) {
   MsdaTiles T;
@@ -1199,7 +1256,7 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
   // algorithmic bytes: read value, read-modify-write grad_value, read loc/attn/grad_out, write grad_loc/grad_attn
   ProfScope prof(PROF_MSDA_BWD, 4.0 * B * (3.0 * Nk * H * D + (double)Nq * H * L * P * 6 + (double)Nq * H * D), s,
                  "rscotr_msda_bwd<%d, %d> (hist + sample + plan + fill + pull kernels)", D, P);
-  if (workspace && shapes_host && msda_bwd_mode() == 1 && Nk > 0) {
+  if (workspace && shapes_host && Nk > 0) {
     MsdaTiles T;
     const int64_t need_t = rscotr_msda_bwd_tiled_workspace(shapes_host, B, Nk, Nq, H, D, L, P);
     if (need_t > 0 && workspace_bytes >= need_t && msda_tiles_build(&T, shapes_host, L, Nk)) {

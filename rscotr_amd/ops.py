@@ -156,9 +156,9 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 # multi-scale deformable attention sampling (mmcv MultiScaleDeformableAttnFunction contract)
 # ------------------------------------------------------------------------------------------
-# 'tiled' (default): grad_value by per-tile LDS accumulation in sample order, bit-reproducible; 'sorted': round 1's
-# counting sort by destination token (reproducible to rounding only); 'scatter': atomic accumulation.  Tests run all three.
-MSDA_BWD_STRATEGY = 'tiled'
+# 'sorted' (default): counting sort by destination token + pull, bit-reproducible; 'tiled': per-tile LDS accumulation in
+# sample order, bit-reproducible, slower; 'scatter': atomic accumulation (order-dependent).  Tests run all three.
+MSDA_BWD_STRATEGY = os.environ.get('RSCOTR_MSDA_BWD', 'sorted')
 
 # host copies of the level-shape tensors (the mmcv contract keeps spatial_shapes on the device; the tile-accumulation
 # backward sizes its launches from the shapes): data_ptr -> int64 numpy array, registered by whoever builds the device
