@@ -134,6 +134,14 @@ int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C, int M, in
                              float* rowsum, const float* kscale, int krows_per_scale, float* slab_region,
                              int64_t slab_bytes, int32_t* splits_out, void* stream);
 int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream);
+/* Grouped launch of deferred weight gradients: n problems dW_i = A_i^T B_i (both operands k-major) with small outputs run
+ * as ONE launch on 64 x 64 tiles x k-slices; every problem leaves `splits` slabs (+ row-sum partials when rs_slabs != 0)
+ * for rscotr_splitk_flush.  table = device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb,
+ * ksplit_len (multiple of 16 unless splits == 1), splits, first workgroup, krows_per_scale, 0, 0}; problem i occupies
+ * 8 * ceil(tiles / 8) * splits workgroups (splits > 1) or tiles (splits == 1), tiles = ceil(M / 64) * ceil(N / 64);
+ * total_wgs = their sum.  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient
+ * GEMMs behind mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules). */
+int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, void* stream);
 
 /* nb0 * nb1 independent products of one shape, problem (b0, b1) at element offsets b0*s?0 + b1*s?1 of A, B, C
  * (b0 = image, b1 = head: the per-head slices of (B, L, heads*32) tensors are addressed in place).  No bias /

@@ -37,7 +37,7 @@
 #include <set>
 
 #ifndef RSCOTR_GEMM_PREC_DEFAULT
-#define RSCOTR_GEMM_PREC_DEFAULT 0
+#define RSCOTR_GEMM_PREC_DEFAULT 3
 #endif
 
 namespace rscotr {
@@ -369,11 +369,13 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n) {
 // cycles instead of 512 per tile and k-tile.  The dropped lo*lo term and the residual of the split are ~2^-17 relative
 // per product (measured: 4-5e-6 of max|C| against 4e-7..2e-6 for fp32 FMA; scripts/lab/bf16x3_lab.hip).  Loads,
 // split-K, k-groups, the row sums (taken from the fp32 registers) and the epilogue are shared.
-template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC = 0>
-__global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
+// SLAB: always leave the result as split-K slabs / row-sum partials, also for a single k-slice (the grouped launch of
+// deferred weight gradients: several problems may share a destination, the combine launch orders them).
+template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC, bool SLAB>
+__device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const int gx, const int by) {
   static_assert(WM * WN == 4, "4 wavefronts per group");
   if (p.nb1 > 0) {  // batched: (b0, b1) = e.g. (image, head) of an attention product
-    const int b01 = blockIdx.y / p.nb2, b2 = blockIdx.y - b01 * p.nb2;
+    const int b01 = by / p.nb2, b2 = by - b01 * p.nb2;
     const int b0 = b01 / p.nb1, b1 = b01 - b0 * p.nb1;
     p.A += b0 * p.sA0 + b1 * p.sA1 + b2 * p.sA2;
     p.B += b0 * p.sB0 + b1 * p.sB1 + b2 * p.sB2;
@@ -400,12 +402,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   int tile, split = 0;
   if (p.splits == 1) {
-    tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    tile = xcd_swizzle(bx, gx);
   } else {
     // split-K: every XCD (workgroup id % 8) owns a contiguous run of tiles with ALL their splits, so the
     // slabs of a tile are written and summed through one L2; inside the run the order is split-major
     // (neighbouring workgroups = neighbouring tiles on the same k-slice share operand panels).
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int x = bx & 7, j = bx >> 3;
     const int q = p.tiles >> 3, r = p.tiles & 7, run = q + (r ? 1 : 0);
     const int nt = q + (x < r ? 1 : 0);
     split = j / run;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
       }
       const int m = m0 + tid;
       if (m < p.M) {
-        if (p.splits > 1) p.rs_slabs[(long)split * p.M + m] = v;
+        if (p.splits > 1 || SLAB) p.rs_slabs[(long)split * p.M + m] = v;
         else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
       }
     }
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
   }
 
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  if (p.splits > 1) {
+  if (p.splits > 1 || SLAB) {
     float* slab = p.slabs + (long)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -617,6 +619,56 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
         }
       }
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC = 0>
+__global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
+  gemm_f32_body<BM, BN, WM, WN, AK, BK_, EDGE, KG, PREC, false>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped launch of deferred weight gradients (rscotr_gemm_dw_group): MANY dW = A^T B problems with small outputs (the
+// 256 x 256 projections of the encoder / decoders, the Swin stage 1-2 Linears: ~110 launches of 8-40 us per co-training
+// round, each a short grid that ramps up and drains alone) run as ONE launch.  Operands are the k-major activations /
+// gradients kept alive until the end of backward; every problem is cut into 64 x 64 tiles x k-slices of about equal length
+// (so few slices per problem: the slab traffic of 31-slice launches goes away), slabs + row-sum partials go to the deferred
+// combine (rscotr_splitk_flush), which orders problems that share a destination.
+// table: device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len, splits,
+// first workgroup, krows_per, 0, 0}; a problem occupies 8 * ceil(tiles / 8) * splits consecutive workgroups (splits > 1) or
+// `tiles` workgroups (one k-slice), tiles = ceil(M / 64) * ceil(N / 64).
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
+  // the problem of this workgroup: binary search over the first-workgroup column (every thread, uniform: no static LDS in
+  // front of the dynamic region the body carves with 16-byte accesses)
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)table[(long)mid * 16 + 12] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* t = table + (long)lo * 16;
+  GemmParams p;
+  p.A = reinterpret_cast<const float*>(t[0]);
+  p.B = reinterpret_cast<const float*>(t[1]);
+  p.slabs = reinterpret_cast<float*>(t[2]);
+  p.rs_slabs = reinterpret_cast<float*>(t[3]);
+  p.kscale = reinterpret_cast<const float*>(t[4]);
+  p.M = (int)t[5]; p.N = (int)t[6]; p.K = (int)t[7]; p.lda = (int)t[8]; p.ldb = (int)t[9];
+  p.ksplit_len = (int)t[10]; p.splits = (int)t[11];
+  p.krows_per = (int)t[13];
+  p.C = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr; p.rowscale = nullptr;
+  p.ldc = p.N; p.act = ACT_NONE; p.accumulate = 0; p.rows_per = 1; p.rowsum_acc = 0;
+  p.rowsum = p.rs_slabs;  // non-null = the row sums are wanted (they go to rs_slabs)
+  p.vecA = ((t[0] & 15) == 0) && (p.lda % 4 == 0);
+  p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
+  p.vecC = 0;
+  p.nb1 = 0; p.nb2 = 1;
+  p.tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const int first = (int)t[12];
+  const int nblk = 8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * p.splits;
+  if (p.splits > 1) {
+    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, nblk, 0);
+  } else {  // one k-slice: the body's single-slice tile order, result still as slab 0
+    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, p.tiles, 0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2039,6 +2091,16 @@ extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C
   tl_defer = 0;
   *splits_out = tl_last_splits;
   return e;
+}
+
+// Grouped launch of deferred weight gradients: see gemm_f32_group_kernel.  table: device (n, 16) int64 (layout there),
+// total_wgs = sum of the problems' workgroup counts.
+extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, void* stream) {
+  if (n < 0 || total_wgs < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_dw_group: negative count");
+  if (n == 0 || total_wgs == 0) return RSCOTR_OK;
+  if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
+  gemm_f32_group_kernel<<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
+  return check_launch("rscotr_gemm_dw_group");
 }
 
 namespace rscotr {

@@ -326,8 +326,57 @@ class _DeferredCombine:
         # dropped oldest-first once more than MAX_TABLES signatures have been seen
         self.pin = False
         self.pinned = set()
+        # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
+        # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
+        self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
+        self.group, self.group_keep, self.group_cache = [], [], {}
+        self.pinned_pool, self.pinned_live = [], []
 
     MAX_TABLES = 64
+    GROUP_MAX_OUT = int(os.environ.get('RSCOTR_DW_GROUP_MAX', 160000))     # M * N of a grouped problem
+    GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 3072))    # workgroups a grouped launch aims at
+
+    def _plan_group(self):
+        """Slices and slab regions of the pending grouped problems -> (device table, total workgroups, combine entries)."""
+        import numpy as np
+        probs = self.group
+        tiles = [((M + 63) // 64) * ((N + 63) // 64) for (_, _, _, _, _, M, N, K, _, _, _) in probs]
+        work = sum(t * p[7] for t, p in zip(tiles, probs))
+        klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
+        rows, ents, first = [], [], 0
+        dev = self.group_keep[0].device
+        for t, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, probs):
+            sp = max(1, -(-K // klen_t))
+            klen = -(-(-(-K // sp)) // 16) * 16
+            sp = -(-K // klen)
+            if sp == 1:
+                klen = K
+            slab = self.reserve(sp * (M * N + M) * 4, dev)
+            rs_slab = slab + sp * M * N * 4 if rs else 0
+            rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), 0, 0))
+            ents.append((slab, rs_slab, out, rs, M, N, N, sp))
+            first += (8 * ((t + 7) // 8) * sp) if sp > 1 else t
+        table = self._upload(np.asarray(rows, dtype=np.int64), dev)
+        return table, first, ents
+
+    def prepare_capture(self, n=4):
+        """Pinned staging buffers for tables that have to be built WHILE a hipGraph is being captured (the grouped launch's
+        table holds activation addresses, which differ between the warm-up iterations and the capture): a pageable
+        host-to-device copy is not capturable, a pinned one is — and the replayed copy node re-reads the pinned buffer,
+        which therefore lives as long as the cache entry."""
+        while len(self.pinned_pool) < n:
+            self.pinned_pool.append(torch.empty((4096, 16), dtype=torch.int64).pin_memory())
+
+    def _upload(self, arr, dev):
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            assert arr.shape[0] <= 4096 and self.pinned_pool, 'DEFER.prepare_capture() must run before a capture'
+            host = self.pinned_pool.pop()
+            host[:arr.shape[0]].copy_(torch.from_numpy(arr))
+            d = torch.empty(arr.shape, dtype=torch.int64, device=dev)
+            d.copy_(host[:arr.shape[0]], non_blocking=True)
+            self.pinned_live.append(host)
+            return d
+        return torch.from_numpy(arr).to(dev)
 
     def _remember(self, cache, sig, hit):
         if self.pin:
@@ -354,10 +403,11 @@ class _DeferredCombine:
             self.cur, self.off = self.cur + 1, 0
 
     def pending(self):
-        return bool(self.entries or self.ln_entries)
+        return bool(self.entries or self.ln_entries or self.group)
 
     def drop(self):
         self.entries, self.notify, self.ln_entries = [], [], []
+        self.group, self.group_keep = [], []
         self.cur = self.off = 0
 
     @staticmethod
@@ -390,7 +440,23 @@ class _DeferredCombine:
             lib.call('rscotr_layernorm_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
         self.ln_entries = []
 
+    def _flush_group(self):
+        sig = (tuple(self.group), self.cur, self.off)  # (the slab regions continue where this pass's reserves stand)
+        hit = self.group_cache.get(sig)
+        if hit is None:
+            table, total, ents = self._plan_group()
+            hit = (table, total, ents, self.cur, self.off)
+        else:
+            self.cur, self.off = hit[3], hit[4]
+        self._remember(self.group_cache, sig, hit)
+        table, total, ents = hit[0], hit[1], hit[2]
+        lib.call('rscotr_gemm_dw_group', table.data_ptr(), len(self.group), total, _stream())
+        self.entries.extend(ents)
+        self.group, self.group_keep = [], []
+
     def flush(self):
+        if self.group:
+            self._flush_group()
         if self.ln_entries:
             self._flush_ln()
         if self.entries:
@@ -434,20 +500,28 @@ DEFER = _DeferredCombine()
 
 
 def flush_deferred():
-    """Combine the pending split-K weight gradients / LayerNorm parameter gradients into the arena (no-op when
-    nothing is pending)."""
-    if DEFER.entries or DEFER.ln_entries or DEFER.notify:
+    """Compute the grouped weight gradients and combine the pending split-K weight gradients / LayerNorm parameter
+    gradients into the arena (no-op when nothing is pending)."""
+    if DEFER.pending() or DEFER.notify:
         DEFER.flush()
 
 
 def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
     """-> True if the contraction was issued as slabs for the deferred combine."""
     sink = GRAD_SINK
-    if sink is None or not DEFER.enabled or SIDE is not None or nws == 0 or N % 4 or out.data_ptr() % 16:
+    if sink is None or not DEFER.enabled or SIDE is not None or N % 4 or out.data_ptr() % 16:
         return False
     fg = sink.flat_g
     lo = fg.data_ptr()
     if not (lo <= out.data_ptr() < lo + fg.numel() * 4):
+        return False
+    if DEFER.group_enabled and M * N <= DEFER.GROUP_MAX_OUT and K >= 16:
+        # small output: joins the grouped launch at the end of backward (operands stay alive until then)
+        DEFER.group.append((A.data_ptr(), B.data_ptr(), out.data_ptr(), _ptr(rowsum), _ptr(kscale), M, N, K, lda, ldb,
+                            int(krows_per)))
+        DEFER.group_keep.extend(t for t in (A, B, kscale) if t is not None)
+        return True
+    if nws == 0:
         return False
     import ctypes
     ptr = DEFER.reserve(nws, A.device)
@@ -474,7 +548,7 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     nws = _gemm_ws_bytes.get(key)
     if nws is None:
         nws = _gemm_ws_bytes[key] = lib.rscotr_gemm_f32_workspace(M, N, K)
-    if (nws and accumulate and a_kmajor and b_kmajor and bias is None and act == ACT_NONE and resid is None and pre is None
+    if (accumulate and a_kmajor and b_kmajor and bias is None and act == ACT_NONE and resid is None and pre is None
             and rowscale is None and (rowsum is None or rowsum_accumulate) and PROFILE is None
             and _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws)):
         return out

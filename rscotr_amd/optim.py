@@ -173,7 +173,7 @@ class FlatAdamW:
     def grad_written(self, i):
         # while split-K weight gradients wait for their deferred combine (ops.DEFER), "written" is not true yet for any
         # of them: the notifications are replayed by ops.flush_deferred()
-        if ops.DEFER.entries or ops.DEFER.ln_entries:
+        if ops.DEFER.pending():
             ops.DEFER.notify.append(i)
         else:
             self._on_ready(i)

@@ -137,10 +137,10 @@ def test_deferred_splitk_combine_matches_immediate(cuda, task):
             opt.zero_grad()
             out = model.train_step(dict(batch, rnd=rnd))
             out['loss'].backward()
-            pending = len(ops.DEFER.entries)
+            pending = len(ops.DEFER.entries) + len(ops.DEFER.group)  # split-K slabs waiting for the combine + grouped problems
             assert (pending > 20) == mode, pending
             ops.flush_deferred()
-            assert not ops.DEFER.entries and not ops.DEFER.notify
+            assert not ops.DEFER.pending() and not ops.DEFER.notify
             res[mode] = (opt.flat_g.clone(), float(opt.grad_norm() if False else opt.flat_g.norm()))
     finally:
         ops.DEFER.enabled = True
