@@ -168,6 +168,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')  # no version banner on stdout next to the JSON line
         dist.init_process_group('nccl', device_id=dev)
 
     import copy
@@ -390,8 +391,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -43,6 +43,12 @@ class GradSync:
         self.fires = {}       # task -> {param index: gradient-ready notifications per step}
         self._order, self._next, self._warned = [], 0, False
         optimizer.ready_callbacks.append(self._on_ready)
+        # Overlap needs the gradients to LAND while backward is still running, but the direct-write path defers them
+        # (split-K combines, LayerNorm folds and the grouped weight gradients wait for ops.flush_deferred()).  The
+        # discovery step also counts the grad_written() calls per parameter; from then on the deferred work is flushed
+        # every time a bucket has seen all of its writes, which completes that bucket and launches its all-reduce.
+        optimizer.written_callbacks.append(self._on_written)
+        self.vfires, self.vfired, self._vpending = {}, None, None
 
     def _on_ready(self, i):
         """A gradient contribution of parameter i is complete (AccumulateGrad ran, or a backward
@@ -76,12 +82,24 @@ class GradSync:
             raise RuntimeError(f'gradient bucket plans of task {task!r} differ across ranks: the ranks did not run the '
                                'same task / parameter subset this iteration')
 
+    def _on_written(self, i):
+        if self.vfired is not None:
+            self.vfired[i] = self.vfired.get(i, 0) + 1
+        elif self._vpending is not None:
+            b = self._bucket_of.get(i) if self._bucket_of is not None else None
+            if b is not None:
+                k = id(b)
+                self._vpending[k] -= 1
+                if self._vpending[k] == 0:
+                    from . import ops
+                    ops.flush_deferred()
+
     def reduce_task(self, task):
         """Exchange the task's gradient buckets now (no overlap with backward) and make the current stream
         wait for them: the hipGraph-replayed iterations call this between backward (in the graph) and the
         optimizer step."""
         self.handles = []
-        for b in self.plans[task]:
+        for b in reversed(self.plans[task]):  # the one launch order of every path: back to front
             self._launch(b)
         for h in self.handles:
             h.wait()
@@ -119,7 +137,11 @@ class GradSync:
         plan = self.plans.get(task)
         if plan is None:
             self.fired, self._bucket_of = {}, None
+            self.vfired, self._vpending = {}, None
         else:
+            vf = self.vfires.get(task, {})
+            self.vfired = None
+            self._vpending = {id(b): sum(vf.get(i, 0) for i in b['params']) for b in plan}
             self.fired = None
             self._bucket_of = {}
             fires = self.fires[task]
@@ -134,9 +156,10 @@ class GradSync:
         if self.fired is not None:  # discovery step: plan from what fired, reduce everything now
             self.plans[task] = self._build_plan(self.fired)
             self.fires[task] = dict(self.fired)
-            self.fired = None
+            self.vfires[task] = dict(self.vfired or {})
+            self.fired = self.vfired = None
             self._check_plan(task)
-            for b in self.plans[task]:
+            for b in reversed(self.plans[task]):
                 self._launch(b)
         elif self._bucket_of is not None:
             # backward is over: whatever has not been launched (a parameter fired fewer times than in the discovery
@@ -154,7 +177,7 @@ class GradSync:
         for h in self.handles:
             h.wait()
         self.handles = []
-        self._bucket_of = None
+        self._bucket_of = self._vpending = None
 
     def describe(self):
         return {t: dict(buckets=len(p), mbytes=sum(b['hi'] - b['lo'] for b in p) * 4 / 2 ** 20)

@@ -141,6 +141,7 @@ class FlatAdamW:
         # gradient-ready notifications: autograd's AccumulateGrad (post hook) or the direct-write path
         # of rscotr_amd.ops (GRAD_SINK) both end in _on_ready(i)
         self.ready_callbacks = []
+        self.written_callbacks = []  # grad_written(i) observers (GradSync: flush the deferred work bucket by bucket)
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                        for i, p in enumerate(params) if p.requires_grad]
         self._by_ptr = {p.data_ptr(): i for i, p in enumerate(params) if p.requires_grad and p.numel() > 0}
@@ -177,6 +178,8 @@ class FlatAdamW:
             ops.DEFER.notify.append(i)
         else:
             self._on_ready(i)
+        for cb in self.written_callbacks:
+            cb(i)
 
     def close(self):
         if ops.GRAD_SINK is self:

@@ -59,17 +59,41 @@ class GraphedTask:
         self.done = None
         self.weight = self.model.task_weight[task]
         self.table = self.opt.new_host_table()  # this graph's own pinned optimizer table
-        # distributed: the graph holds forward + backward only; the gradient buckets are exchanged (RCCL) and
-        # the optimizer launched eagerly after each replay — no collective is captured
-        self.split = runner.sync is not None
+        # Distributed, two forms.  `exchange_in_graph` (default): the whole iteration INCLUDING the RCCL collectives is one
+        # hipGraph — backward launches each gradient bucket's all-reduce from its hooks as soon as the bucket is complete
+        # (torch captures the collective on RCCL's stream with event edges to and from the compute stream), so in the
+        # replayed graph the exchange of bucket k runs under the backward kernels of bucket k+1, and clip + AdamW follow the
+        # last wait inside the graph.  `split` (RSCOTR_DIST_CAPTURE=0, or if capturing the collectives fails): the graph
+        # holds forward + backward only; buckets, log vector and optimizer are issued eagerly after each replay.
+        self.exchange_in_graph = runner.sync is not None and os.environ.get('RSCOTR_DIST_CAPTURE', '1') != '0'
+        self.split = runner.sync is not None and not self.exchange_in_graph
+        try:
+            self._warm_and_capture()
+        except Exception as e:  # noqa: BLE001 — any failure of the collective capture: fall back to the split form
+            if not self.exchange_in_graph:
+                raise
+            import warnings
+            warnings.warn(f'capturing the RCCL collectives of task {task!r} failed ({type(e).__name__}: {e}); '
+                          'falling back to graph(forward + backward) + eager exchange')
+            torch.cuda.synchronize()
+            self.exchange_in_graph, self.split = False, True
+            self._warm_and_capture()
+        self.graph.replay()  # capture only records: this replay is the iteration prepare_step() announced
+        self._finish()
+        self.done = torch.cuda.Event()
+        self.done.record()
+        self.warm_iters = 1  # iterations applied to the weights on this batch (the warm-ups were rolled back)
+        self.first_out = self._output(batch)
+
+    def _warm_and_capture(self):
         # warm-up (allocator, workspaces, lazy inits), then capture — both on the runner's stream, which is
         # the current stream here
         side = torch.cuda.current_stream()
         # the two warm-up iterations must not move the training trajectory (the reference applies ONE update per batch):
-        # weights, moments and step counts are put back afterwards; only the first replay below counts
+        # weights, moments and step counts are put back afterwards; only the first replay counts
         snap = self.opt.snapshot()
         ops.DEFER.pin = True  # the flush tables looked up from here on are baked into the graph by address
-        ops.DEFER.prepare_capture()
+        ops.DEFER.prepare_capture(8)
         try:
             for _ in range(2):
                 self.opt.prepare_step(self.table)
@@ -77,22 +101,25 @@ class GraphedTask:
                 self._finish()
                 side.synchronize()  # the pinned optimizer table is refilled by the next prepare_step()
             torch.cuda.synchronize()
+            if self.runner.sync is not None:
+                # Let the process group's watchdog retire every collective issued so far before a stream goes into
+                # capture: it polls the end events of its pending works every 100 ms, and HIP refuses an event query
+                # ("operation not permitted on an event last recorded in a capturing stream") when the stream the event
+                # was recorded on is capturing at that moment — which aborts the process from the watchdog thread.
+                time.sleep(0.35)
             self.opt.restore(snap)
-            del snap
             self.graph = torch.cuda.CUDAGraph()
             self.opt.prepare_step(self.table)
             # thread_local: the RCCL watchdog thread polls its events while this thread captures; under the default
             # global mode that poll is "not permitted when stream is capturing" and kills the process group
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
                 self._body()
+        except Exception:
+            ops.DEFER.drop()
+            self.opt.restore(snap)
+            raise
         finally:
             ops.DEFER.pin = False
-        self.graph.replay()  # capture only records: this replay is the iteration prepare_step() announced
-        self._finish()
-        self.done = torch.cuda.Event()
-        self.done.record()
-        self.warm_iters = 1  # iterations applied to the weights on this batch (the warm-ups were rolled back)
-        self.first_out = self._output(batch)
 
     def _output(self, batch):
         # the packed loss vector is cloned (the static one is overwritten by the next replay) and read
@@ -117,6 +144,9 @@ class GraphedTask:
         loss, self.names, packed = self.model.pack_losses(losses)
         self.packed = packed * self.weight
         self.opt.zero_grad()
+        sync = self.runner.sync if self.exchange_in_graph else None
+        if sync is not None:
+            sync.begin_step(self.task)
         # weight-gradient contractions on a second stream, joined before anything reads the arena.  Off by
         # default: inside a hipGraph the forked branch brought nothing on ROCm 7.2 (71.9 ms/round without,
         # 72-73 with; profiles/README.md) — the replay does not overlap the two branches.
@@ -130,6 +160,11 @@ class GraphedTask:
                 ops.side_join()
                 ops.side_enable(False)
         ops.flush_deferred()  # one combine launch for every split-K weight gradient of this backward pass
+        if sync is not None:
+            sync.finish_step(self.task)  # leftover buckets in the fixed order, then the waits (event edges in the graph)
+            import torch.distributed as dist
+            self.packed = self.packed / dist.get_world_size()
+            dist.all_reduce(self.packed)  # rank-averaged log variables (multitask_learner.py:299-304)
         if not self.split:
             self.opt.launch_step(self.table)
 

@@ -98,11 +98,53 @@ def _worker(rank, world, port, q):
         for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
             want = torch.zeros_like(p) if pr.grad is None else pr.grad
             assert torch.allclose(p.grad, want, atol=1e-6), ('fixed order', n)
+        # Bucket-aligned flush (the overlap of the direct-write path): gradients written straight into the arena are
+        # announced through grad_written(); while deferred work is pending the notifications wait for ops.flush_deferred(),
+        # and GradSync flushes as soon as a bucket has seen all the writes the discovery step counted for it — the
+        # bucket's all-reduce is then launched from INSIDE backward, not after it.
+        from rscotr_amd import ops as _ops
+        names_i = {g['name']: i for i, g in enumerate(opt.groups)}
+        task_params = [names_i[n] for n, _ in model.named_parameters() if not n.startswith(('never', 'head_a'))]
+        sync.plans.pop('c', None)
+        opt.zero_grad()
+        sync.begin_step('c')  # discovery of a third "task" whose gradients all arrive through grad_written()
+        for i in task_params:
+            opt.grad_written(i)
+        sync.finish_step('c')
+        assert sync.vfires['c'] == {i: 1 for i in task_params}
+        launched = []
+        sync._launch = lambda b: (launched.append(b['lo']), real_launch(b))[1]
+        opt.zero_grad()
+        sync.begin_step('c')
+        _ops.DEFER.ln_entries.append((0, 0, 0, 0, 0))  # something is pending: notifications are deferred
+        flushes = []
+        real_flush = _ops.flush_deferred
+
+        def fake_flush():  # what ops.flush_deferred does for the notifications, without launching HIP kernels
+            flushes.append(len(launched))
+            _ops.DEFER.ln_entries.clear()
+            pend, _ops.DEFER.notify = _ops.DEFER.notify, []
+            for j in pend:
+                opt._on_ready(j)
+        _ops.flush_deferred = fake_flush
+        try:
+            last_bucket = sync.plans['c'][-1]
+            for i in reversed(task_params):  # back to front, as backward produces them
+                opt.grad_written(i)
+                if i == last_bucket['params'][0]:
+                    assert flushes and launched[:1] == [last_bucket['lo']], (flushes, launched)  # flushed + launched mid-way
+                    _ops.DEFER.ln_entries.append((0, 0, 0, 0, 0))
+        finally:
+            _ops.flush_deferred = real_flush
+            _ops.DEFER.ln_entries.clear()
+        sync.finish_step('c')
+        sync._launch = real_launch
+        assert launched == [b['lo'] for b in reversed(sync.plans['c'])], launched
         # reduce_mean of a small device vector (det loss normalisers)
         from rscotr_amd import ops
         assert torch.allclose(ops.dist_mean_tensor(torch.tensor([2.0 * rank, 4.0])), torch.tensor([1.0, 4.0]))
         plans = sync.describe()
-        assert set(plans) == {'a', 'b'} and plans['a']['buckets'] >= 2
+        assert set(plans) == {'a', 'b', 'c'} and plans['a']['buckets'] >= 2
         # a parameter no task touches never enters a plan; head_b is not in task a's plan
         names = {i: g['name'] for i, g in enumerate(opt.groups)}
         in_a = {names[i] for b in sync.plans['a'] for i in b['params']}
