@@ -233,14 +233,29 @@ class IterBasedRunner:
         self.stream = torch.cuda.Stream() if (self.graph_tasks and torch.cuda.is_available()) else None
         self._it = None
         self.log_buffer = OrderedDict()
+        # hook surface of mmcv's runner that rscotr_amd.engine.MultiDatasetsEvalHook uses
+        self.hooks, self.epoch, self.meta, self.work_dir = [], 0, {}, None
+        self.log_buffer_output, self.log_buffer_ready = OrderedDict(), False
+
+    def register_hook(self, hook):
+        self.hooks.append(hook)
+        if hasattr(hook, 'before_run'):
+            hook.before_run(self)
 
     def train_iter(self):
+        for h in self.hooks:
+            if hasattr(h, 'before_train_iter'):
+                h.before_train_iter(self)
         if self.stream is None:
-            return self._train_iter()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
             out = self._train_iter()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                out = self._train_iter()
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for h in self.hooks:
+            if hasattr(h, 'after_train_iter'):
+                h.after_train_iter(self)
         return out
 
     def _train_iter(self):
