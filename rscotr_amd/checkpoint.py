@@ -65,7 +65,7 @@ def swin_converter(ckpt, prefix='backbone.'):
 
 def load_pretrained_backbone(model, path, convert_weights=True, map_location='cpu'):
     """Load an (official or mmdet-layout) Swin checkpoint into `model.backbone`; returns torch's load report."""
-    sd = torch.load(path, map_location=map_location)
+    sd = torch.load(path, map_location=map_location, weights_only=True)
     for key in ('state_dict', 'model'):
         if isinstance(sd, dict) and key in sd:
             sd = sd[key]

@@ -348,7 +348,7 @@ class MTL(nn.Module):
             print('You did not set task_pretrain, hence it is skipped.')
             return None
         rule = self.task_pretrain.get('rule', None)
-        sd = torch.load(self.task_pretrain['pretrained'], map_location='cpu')
+        sd = torch.load(self.task_pretrain['pretrained'], map_location='cpu', weights_only=True)
         if 'state_dict' in sd:
             sd = sd['state_dict']
         if rule == 'dino_mmdet':

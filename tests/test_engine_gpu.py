@@ -76,8 +76,7 @@ def test_multi_dataset_test_and_eval_hook(cuda, tmp_path):
     want = (out['resisc.accuracy_top-1'] + 100 * out['dior.bbox_mAP'] + 0.5 * out['potsdam.mIoU']) / 3
     assert hook.best_score >= want - 1e-9 and hook.best_ckpt_path is not None
     fresh = build_model(mcfg, seed=9).to(cuda)
-    meta = load_checkpoint(fresh, hook.best_ckpt_path)
-    assert meta.get('meta', meta).get('iter') in (3, 6) or True
+    load_checkpoint(fresh, hook.best_ckpt_path)
     sd, fd = model.state_dict(), fresh.state_dict()
     if hook.best_ckpt_path.endswith('iter_6.pth'):  # the best evaluation was the last: weights equal the live model's
         assert all(torch.equal(sd[k], fd[k]) for k in sd)
