@@ -137,8 +137,10 @@ int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, voi
 /* Grouped launch of deferred weight gradients: n problems dW_i = A_i^T B_i (both operands k-major) with small outputs run
  * as ONE launch on 64 x 64 tiles x k-slices; every problem leaves `splits` slabs (+ row-sum partials when rs_slabs != 0)
  * for rscotr_splitk_flush.  table = device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb,
- * ksplit_len (multiple of 16 unless splits == 1), splits, first workgroup, krows_per_scale, 0, 0}; problem i occupies
- * 8 * ceil(tiles / 8) * splits workgroups (splits > 1) or tiles (splits == 1), tiles = ceil(M / 64) * ceil(N / 64);
+ * ksplit_len (multiple of 16 unless splits == 1), splits, first workgroup, krows_per_scale, split-product flag (1: M, N
+ * multiples of 64, K and ksplit_len multiples of 16, 16-byte aligned operands -> bf16x6 tiles; 0: fp32 tiles with bounds
+ * handling), 0}; problem i occupies
+ * 8 * ceil(tiles / 8) * splits workgroups, tiles = ceil(M / 64) * ceil(N / 64);
  * total_wgs = their sum.  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient
  * GEMMs behind mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules). */
 int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, void* stream);

@@ -627,51 +627,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Grouped launch of deferred weight gradients (rscotr_gemm_dw_group): MANY dW = A^T B problems with small outputs (the
-// 256 x 256 projections of the encoder / decoders, the Swin stage 1-2 Linears: ~110 launches of 8-40 us per co-training
-// round, each a short grid that ramps up and drains alone) run as ONE launch.  Operands are the k-major activations /
-// gradients kept alive until the end of backward; every problem is cut into 64 x 64 tiles x k-slices of about equal length
-// (so few slices per problem: the slab traffic of 31-slice launches goes away), slabs + row-sum partials go to the deferred
-// combine (rscotr_splitk_flush), which orders problems that share a destination.
-// table: device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len, splits,
-// first workgroup, krows_per, 0, 0}; a problem occupies 8 * ceil(tiles / 8) * splits consecutive workgroups (splits > 1) or
-// `tiles` workgroups (one k-slice), tiles = ceil(M / 64) * ceil(N / 64).
-__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
-  // the problem of this workgroup: binary search over the first-workgroup column (every thread, uniform: no static LDS in
-  // front of the dynamic region the body carves with 16-byte accesses)
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int)table[(long)mid * 16 + 12] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const int64_t* t = table + (long)lo * 16;
-  GemmParams p;
-  p.A = reinterpret_cast<const float*>(t[0]);
-  p.B = reinterpret_cast<const float*>(t[1]);
-  p.slabs = reinterpret_cast<float*>(t[2]);
-  p.rs_slabs = reinterpret_cast<float*>(t[3]);
-  p.kscale = reinterpret_cast<const float*>(t[4]);
-  p.M = (int)t[5]; p.N = (int)t[6]; p.K = (int)t[7]; p.lda = (int)t[8]; p.ldb = (int)t[9];
-  p.ksplit_len = (int)t[10]; p.splits = (int)t[11];
-  p.krows_per = (int)t[13];
-  p.C = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr; p.rowscale = nullptr;
-  p.ldc = p.N; p.act = ACT_NONE; p.accumulate = 0; p.rows_per = 1; p.rowsum_acc = 0;
-  p.rowsum = p.rs_slabs;  // non-null = the row sums are wanted (they go to rs_slabs)
-  p.vecA = ((t[0] & 15) == 0) && (p.lda % 4 == 0);
-  p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
-  p.vecC = 0;
-  p.nb1 = 0; p.nb2 = 1;
-  p.tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  const int first = (int)t[12];
-  const int nblk = 8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * p.splits;
-  if (p.splits > 1) {
-    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, nblk, 0);
-  } else {  // one k-slice: the body's single-slice tile order, result still as slab 0
-    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, p.tiles, 0);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // bf16x3 kernel for the large row-major x row-major products (precision modes 1 and 2): 128x128 output tile, 32 k per
 // barrier, 4 wavefronts x (2 x 2) MFMA tiles -> 24 v_mfma_f32_32x32x16_bf16 (768 matrix-pipe cycles) per wavefront
 // between two barriers; the 64x64x16 tiling of gemm_f32_kernel<..., PREC = 1> leaves 96, which the staging cannot
@@ -1064,21 +1019,29 @@ struct SplitOperand {
 };
 
 template <int BM, int BN, bool AKM, bool BKM, int PIPE>
-__global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
+constexpr int bf16x6_lds_words() {
+  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3>::WORDS + SplitOperand<BN, BKM, 3>::WORDS);
+}
+
+// SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
+// lds: bf16x6_lds_words() dwords, 16-byte aligned.
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB>
+__device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
   constexpr int NPL = 3, SBK = 16;
   constexpr int MT = BM / 64, NT = BN / 64;
   using OA = SplitOperand<BM, AKM, NPL>;
   using OB = SplitOperand<BN, BKM, NPL>;
   constexpr int NBUF = PIPE ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned sA[NBUF][OA::WORDS], sB[NBUF][OB::WORDS];
+  unsigned* sA[2] = {lds, lds + (NBUF - 1) * OA::WORDS};
+  unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = p.N / BN;
   int tile, split = 0;
   if (p.splits == 1) {
-    tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    tile = xcd_swizzle(bx, gx);
   } else {  // an XCD owns a run of tiles with all their splits (as gemm_f32_kernel)
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int x = bx & 7, j = bx >> 3;
     const int q = p.tiles >> 3, r = p.tiles & 7, run = q + (r ? 1 : 0);
     const int nt = q + (x < r ? 1 : 0);
     split = j / run;
@@ -1137,10 +1100,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
     if (nk > 1) fetch(1);
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
-      const int cur = t & 1;
-      mma(sA[cur], sB[cur]);
+      const bool odd = t & 1;  // (selects, not a runtime-indexed pointer array: the accesses must stay LDS accesses)
+      mma(odd ? sA[1] : sA[0], odd ? sB[1] : sB[0]);
       if (t + 1 < nk) {  // registers hold tile t+1: split / pack / write to the other stage, then fetch tile t+2
-        stage(sA[cur ^ 1], sB[cur ^ 1]);
+        stage(odd ? sA[0] : sA[1], odd ? sB[0] : sB[1]);
         if (t + 2 < nk) fetch(t + 2);
       }
       __syncthreads();
@@ -1158,21 +1121,21 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
 
   if (AKM && do_rs) {  // thread t summed rows (t % (BM/4)) * 4 .. + 3 over the k-pairs it staged: fold the 8 k-lanes
     __syncthreads();
-    float4* red = reinterpret_cast<float4*>(sA[0]);
+    float4* red = reinterpret_cast<float4*>(lds);
     if (tid < 8 * BM / 4) red[tid] = rs;  // [k-lane][BM / 4]
     __syncthreads();
     if (tid < BM) {
-      const float* rf = reinterpret_cast<const float*>(sA[0]);
+      const float* rf = reinterpret_cast<const float*>(lds);
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) v += rf[k * BM + tid];
       const int m = m0 + tid;
-      if (p.splits > 1) p.rs_slabs[(long)split * p.M + m] = v;
+      if (p.splits > 1 || SLAB) p.rs_slabs[(long)split * p.M + m] = v;
       else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
     }
   }
 
-  if (p.splits > 1) {
+  if (p.splits > 1 || SLAB) {
     float* slab = p.slabs + (long)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1212,6 +1175,65 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
     }
 }
 
+template <int BM, int BN, bool AKM, bool BKM, int PIPE>
+__global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE>()];
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false>(p, blockIdx.x, gridDim.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped launch of deferred weight gradients (rscotr_gemm_dw_group): MANY dW = A^T B problems with small outputs (the
+// 256 x 256 projections of the encoder / decoders, the Swin stage 1-2 Linears: ~110 launches of 8-40 us per co-training
+// round, each a short grid that ramps up and drains alone) run as ONE launch.  Operands are the k-major activations /
+// gradients kept alive until the end of backward; every problem is cut into 64 x 64 tiles x k-slices of about equal length
+// (so few slices per problem: the slab traffic of 31-slice launches goes away), slabs + row-sum partials go to the deferred
+// combine (rscotr_splitk_flush), which orders problems that share a destination.
+// table: device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len, splits,
+// first workgroup, krows_per, split-product flag, 0}; a problem occupies 8 * ceil(tiles / 8) * splits consecutive workgroups,
+// tiles = ceil(M / 64) * ceil(N / 64) (every problem starts on a multiple of 8: workgroup id % 8 is the XCD).
+constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<64, 64, true, true, 1>();  // 24 KB (>= the fp32 body's 17 KB)
+static_assert(bf16x6_lds_words<128, 128, true, true, 0>() == bf16x6_lds_words<64, 64, true, true, 1>(), "one LDS size for both tilings");
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
+  extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+  // the problem of this workgroup: binary search over the first-workgroup column (every thread, uniform: no static LDS in
+  // front of the dynamic region the body carves with 16-byte accesses)
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)table[(long)mid * 16 + 12] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* t = table + (long)lo * 16;
+  GemmParams p;
+  p.A = reinterpret_cast<const float*>(t[0]);
+  p.B = reinterpret_cast<const float*>(t[1]);
+  p.slabs = reinterpret_cast<float*>(t[2]);
+  p.rs_slabs = reinterpret_cast<float*>(t[3]);
+  p.kscale = reinterpret_cast<const float*>(t[4]);
+  p.M = (int)t[5]; p.N = (int)t[6]; p.K = (int)t[7]; p.lda = (int)t[8]; p.ldb = (int)t[9];
+  p.ksplit_len = (int)t[10]; p.splits = (int)t[11];
+  p.krows_per = (int)t[13];
+  p.C = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr; p.rowscale = nullptr;
+  p.ldc = p.N; p.act = ACT_NONE; p.accumulate = 0; p.rows_per = 1; p.rowsum_acc = 0;
+  p.rowsum = p.rs_slabs;  // non-null = the row sums are wanted (they go to rs_slabs)
+  p.vecA = ((t[0] & 15) == 0) && (p.lda % 4 == 0);
+  p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
+  p.vecC = 0;
+  p.nb1 = 0; p.nb2 = 1;
+  const int flag = (int)t[14];  // 0: fp32 64 x 64 tiles (ragged), 1: bf16x6 64 x 64, 2: bf16x6 128 x 128 (interior problems)
+  p.tiles = flag == 2 ? (p.M / 128) * (p.N / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const int first = (int)t[12];
+  const int nblk = 8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * p.splits;
+  const int gx = p.splits > 1 ? nblk : p.tiles;  // (one k-slice: the body's single-slice tile order, result still as slab 0)
+  if ((int)blockIdx.x - first >= gx) return;    // padding workgroups: every problem starts on a multiple of 8 (XCD affinity)
+  if (flag == 2) {  // interior problems (k-slices multiples of 16, 16-byte loads): the bf16x6 split product
+    gemm_bf16x6_body<128, 128, true, true, 0, true>(p, (int)blockIdx.x - first, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  } else if (flag == 1) {
+    gemm_bf16x6_body<64, 64, true, true, 1, true>(p, (int)blockIdx.x - first, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  } else {      // ragged problem: fp32 matrix pipe with bounds handling
+    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, gx, 0);
+  }
+}
+
 // Tile / slice choice of the bf16x6 kernel for one problem; bm == 0: not its domain (the fp32 pipe takes it).
 struct Split6Cfg {
   int bm, splits, klen;
@@ -1224,6 +1246,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 512;
   static const long dw_t128_min = getenv("RSCOTR_BF16X6_DW_T128") ? atol(getenv("RSCOTR_BF16X6_DW_T128")) : 24;
   static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
+  static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;
   static const int gelu_ok = getenv("RSCOTR_BF16X6_GELU") ? atoi(getenv("RSCOTR_BF16X6_GELU")) : 1;
   static const int dw_ok = getenv("RSCOTR_BF16X6_DW") ? atoi(getenv("RSCOTR_BF16X6_DW")) : 1;
   // Measured on the step (gpurun_out/r2t3_gemm_census_bf16x6.txt against profiles/r1_s7_gemm_census_fp32.txt): the split
@@ -1253,6 +1276,19 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   if (p.kscale) return c;
   if (t128 >= t128_min) c.bm = 128;
   else if (t64 >= t64_min && p.K <= 4096) c.bm = 64;
+  else if (mid_split && t64 >= 128 && p.K >= 1024) {
+    // mid-size outputs with a long reduction (Swin stage 3: 2048 x 384 x 1536): too few 64 x 64 tiles for the chip, so the
+    // reduction is cut into k-slices whose slabs the combine launch sums and runs the epilogue on
+    long sp = std::min<long>((512 + t64 - 1) / t64, p.K / 256);
+    const int64_t per = ((int64_t)p.M * p.N + p.M) * 4;
+    sp = std::min<long>(sp, ws_bytes / per);
+    if (sp >= 2) {
+      int klen = (int)((p.K + sp - 1) / sp);
+      klen = (klen + 15) / 16 * 16;
+      c.bm = 64; c.klen = klen; c.splits = (p.K + klen - 1) / klen;
+      if (c.splits == 1) c.klen = p.K;
+    }
+  }
   return c;
 }
 
@@ -1900,6 +1936,8 @@ extern "C" int64_t rscotr_gemm_f32_workspace(int M, int N, int K) {
     const long t128 = (M % 128 == 0 && N % 128 == 0) ? (long)(M / 128) * (N / 128) : 0;
     const long tiles = t128 >= 16 ? t128 : (long)(M / 64) * (N / 64);
     sp = std::max<int64_t>(sp, std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, K / 256)));  // as a weight gradient
+    const long t64 = (long)(M / 64) * (N / 64);
+    if (t64 >= 128 && t64 < 512) sp = std::max<int64_t>(sp, std::min<long>((512 + t64 - 1) / t64, K / 256));  // mid-size k-slices
   }
   const int pm = g_gemm_prec.load(std::memory_order_relaxed);
   if ((pm == 1 || pm == 2) && M % 128 == 0 && N % 128 == 0 && K % 32 == 0) {
@@ -2099,7 +2137,8 @@ extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, 
   if (n < 0 || total_wgs < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_dw_group: negative count");
   if (n == 0 || total_wgs == 0) return RSCOTR_OK;
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
-  gemm_f32_group_kernel<<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
+  static_assert(GROUP_LDS_BYTES >= gemm_lds_bytes<64, 64, 1, 0>(), "group LDS covers both bodies");
+  gemm_f32_group_kernel<<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
   return check_launch("rscotr_gemm_dw_group");
 }
 

@@ -329,6 +329,7 @@ class _DeferredCombine:
         # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
         # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
         self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
+        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '2'))  # 0: fp32 tiles only, 1: + bf16x6 64x64, 2: + bf16x6 128x128
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.pinned_pool, self.pinned_live = [], []
 
@@ -340,22 +341,30 @@ class _DeferredCombine:
         """Slices and slab regions of the pending grouped problems -> (device table, total workgroups, combine entries)."""
         import numpy as np
         probs = self.group
-        tiles = [((M + 63) // 64) * ((N + 63) // 64) for (_, _, _, _, _, M, N, K, _, _, _) in probs]
-        work = sum(t * p[7] for t, p in zip(tiles, probs))
+
+        def kind(p):  # 2: bf16x6 on 128 x 128 tiles, 1: bf16x6 on 64 x 64 tiles (interior problems), 0: fp32 tiles (ragged)
+            a, b, _, _, _, M, N, K, lda, ldb, _ = p
+            ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
+            return 0 if not ok or M % 64 or N % 64 else (2 if self.group_x6 >= 2 and M % 128 == 0 and N % 128 == 0 else 1)
+        kinds = [kind(p) for p in probs]
+        tiles = [(M // 128) * (N // 128) if k == 2 else ((M + 63) // 64) * ((N + 63) // 64)
+                 for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
+        # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
+        work = sum(t * p[7] * (4 if k == 2 else 1) for t, k, p in zip(tiles, kinds, probs))
         klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
         rows, ents, first = [], [], 0
         dev = self.group_keep[0].device
-        for t, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, probs):
-            sp = max(1, -(-K // klen_t))
+        for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
+            sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
             klen = -(-(-(-K // sp)) // 16) * 16
             sp = -(-K // klen)
             if sp == 1:
                 klen = K
             slab = self.reserve(sp * (M * N + M) * 4, dev)
             rs_slab = slab + sp * M * N * 4 if rs else 0
-            rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), 0, 0))
+            rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), x6, 0))
             ents.append((slab, rs_slab, out, rs, M, N, N, sp))
-            first += (8 * ((t + 7) // 8) * sp) if sp > 1 else t
+            first += 8 * ((t + 7) // 8) * sp
         table = self._upload(np.asarray(rows, dtype=np.int64), dev)
         return table, first, ents
 

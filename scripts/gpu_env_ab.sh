@@ -1,12 +1,9 @@
 #!/bin/bash
-# bench + GEMM census under different environment settings: bash scripts/gpu_env_ab.sh <tag> "NAME=V ..." "NAME=V ..." ...
+# plain bench under several environments: bash scripts/gpu_env_ab.sh "<env A>" "<env B>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R; mkdir -p gpurun_out
-export TMPDIR=/tmp
-T=$1; shift
-i=0
-for E in "$@"; do
-  env $E timeout 300 python scripts/gemm_shapes.py > gpurun_out/${T}_shapes_$i.txt 2>&1
-  (echo "$E"; env $E timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-300) > gpurun_out/${T}_bench_$i.txt
-  i=$((i+1))
+cd $R
+for e in "$@"; do
+  for rep in 1 2; do
+    echo "== $e : $(env $e timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"
+  done
 done
