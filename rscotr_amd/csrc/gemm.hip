@@ -849,9 +849,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_big_kernel(GemmParams p) {
 
 // Is the problem one for gemm_bf16x3_big_kernel?  (row-major x row-major, interior for 128 x 128 x 32, enough tiles)
 // k-slices: grids shorter than the chip with a long reduction.  Row-major-output products: two slices (the combine runs
-// the epilogue; a more general rule — up to 256 workgroups, >= 512 k per slice, also for 43..127-tile shapes — broke the
-// 512^2 seg parity (140-440 of 459 gradient tensors outside the tight tier, not yet understood: RSCOTR_BF16X3_SPLIT=0
-// restored 10-12) and was withdrawn); weight gradients: ~256 workgroups, >= 256 k per slice.
+// the epilogue; a more general rule — up to 256 workgroups, >= 512 k per slice, also for 43..127-tile shapes — was
+// withdrawn in round 1 because the two-term split's rounding (4e-6) flips ReLU gates and seg attention-mask bits of
+// the 512^2 step often enough to leave the 1e-3 gradient tier; the fp64-anchored gate of round 2 shows the same for
+// every two-term routing, which is why the default is the three-term mode 3); weight gradients: ~256 workgroups,
+// >= 256 k per slice.
 static int bf16x3_big_splits(int M, int N, int K, bool dw = false) {
   // off by default: with the slices on, the 512^2 seg parity depends on what earlier processes left in device memory
   // (10-12 of 459 gradient tensors outside the tight tier on a fresh box or with the slices off, 140-440 after other
@@ -1191,8 +1193,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
 // table: device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len, splits,
 // first workgroup, krows_per, split-product flag, 0}; a problem occupies 8 * ceil(tiles / 8) * splits consecutive workgroups,
 // tiles = ceil(M / 64) * ceil(N / 64) (every problem starts on a multiple of 8: workgroup id % 8 is the XCD).
-constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<64, 64, true, true, 1>();  // 24 KB (>= the fp32 body's 17 KB)
-static_assert(bf16x6_lds_words<128, 128, true, true, 0>() == bf16x6_lds_words<64, 64, true, true, 1>(), "one LDS size for both tilings");
+constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<128, 128, true, true, 0>();  // 24 KB (>= the fp32 body's 17 KB)
+// X6 = false: fp32 matrix pipe on 64 x 64 tiles with bounds handling (any problem); X6 = true: the bf16x6 split product on
+// 128 x 128 tiles (interior problems: M, N multiples of 128, k-slices multiples of 16, 16-byte aligned operands).  Two
+// instantiations rather than one kernel with both bodies: the 128 x 128 body's registers (114 + 64 accumulators) would
+// halve the residency of the fp32 body's workgroups (measured: 950 -> 1500 us for the launch).
+template <bool X6>
 __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
   extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
   // the problem of this workgroup: binary search over the first-workgroup column (every thread, uniform: no static LDS in
@@ -1219,17 +1225,14 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
   p.vecC = 0;
   p.nb1 = 0; p.nb2 = 1;
-  const int flag = (int)t[14];  // 0: fp32 64 x 64 tiles (ragged), 1: bf16x6 64 x 64, 2: bf16x6 128 x 128 (interior problems)
-  p.tiles = flag == 2 ? (p.M / 128) * (p.N / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  p.tiles = X6 ? (p.M / 128) * (p.N / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int first = (int)t[12];
   const int nblk = 8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * p.splits;
   const int gx = p.splits > 1 ? nblk : p.tiles;  // (one k-slice: the body's single-slice tile order, result still as slab 0)
   if ((int)blockIdx.x - first >= gx) return;    // padding workgroups: every problem starts on a multiple of 8 (XCD affinity)
-  if (flag == 2) {  // interior problems (k-slices multiples of 16, 16-byte loads): the bf16x6 split product
+  if constexpr (X6) {
     gemm_bf16x6_body<128, 128, true, true, 0, true>(p, (int)blockIdx.x - first, gx, reinterpret_cast<unsigned*>(gemm_smem));
-  } else if (flag == 1) {
-    gemm_bf16x6_body<64, 64, true, true, 1, true>(p, (int)blockIdx.x - first, gx, reinterpret_cast<unsigned*>(gemm_smem));
-  } else {      // ragged problem: fp32 matrix pipe with bounds handling
+  } else {
     gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, gx, 0);
   }
 }
@@ -2133,12 +2136,17 @@ extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C
 
 // Grouped launch of deferred weight gradients: see gemm_f32_group_kernel.  table: device (n, 16) int64 (layout there),
 // total_wgs = sum of the problems' workgroup counts.
-extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, void* stream) {
+extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, void* stream) {
   if (n < 0 || total_wgs < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_dw_group: negative count");
   if (n == 0 || total_wgs == 0) return RSCOTR_OK;
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
-  static_assert(GROUP_LDS_BYTES >= gemm_lds_bytes<64, 64, 1, 0>(), "group LDS covers both bodies");
-  gemm_f32_group_kernel<<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
+  if (variant == 0) {
+    gemm_f32_group_kernel<false><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
+  } else if (variant == 2) {
+    gemm_f32_group_kernel<true><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
+  } else {
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles) or 2 (bf16x6 128 x 128 tiles)");
+  }
   return check_launch("rscotr_gemm_dw_group");
 }
 

@@ -329,7 +329,7 @@ class _DeferredCombine:
         # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
         # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
         self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
-        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '2'))  # 0: fp32 tiles only, 1: + bf16x6 64x64, 2: + bf16x6 128x128
+        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '0'))  # 0: fp32 tiles only, 1: bf16x6 128 x 128 tiles for interior problems
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.pinned_pool, self.pinned_live = [], []
 
@@ -338,35 +338,42 @@ class _DeferredCombine:
     GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 3072))    # workgroups a grouped launch aims at
 
     def _plan_group(self):
-        """Slices and slab regions of the pending grouped problems -> (device table, total workgroups, combine entries)."""
+        """Slices and slab regions of the pending grouped problems -> ([(device table, problems, workgroups, variant)],
+        combine entries).  Interior problems (M, N multiples of 128, aligned operands) go to the bf16x6 128 x 128 variant of
+        the grouped kernel, the rest to the fp32 64 x 64 variant: one launch each."""
         import numpy as np
         probs = self.group
 
-        def kind(p):  # 2: bf16x6 on 128 x 128 tiles, 1: bf16x6 on 64 x 64 tiles (interior problems), 0: fp32 tiles (ragged)
+        def kind(p):
             a, b, _, _, _, M, N, K, lda, ldb, _ = p
             ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
-            return 0 if not ok or M % 64 or N % 64 else (2 if self.group_x6 >= 2 and M % 128 == 0 and N % 128 == 0 else 1)
+            return 2 if ok and M % 128 == 0 and N % 128 == 0 else 0
         kinds = [kind(p) for p in probs]
         tiles = [(M // 128) * (N // 128) if k == 2 else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
         work = sum(t * p[7] * (4 if k == 2 else 1) for t, k, p in zip(tiles, kinds, probs))
         klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
-        rows, ents, first = [], [], 0
         dev = self.group_keep[0].device
-        for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
-            sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
-            klen = -(-(-(-K // sp)) // 16) * 16
-            sp = -(-K // klen)
-            if sp == 1:
-                klen = K
-            slab = self.reserve(sp * (M * N + M) * 4, dev)
-            rs_slab = slab + sp * M * N * 4 if rs else 0
-            rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), x6, 0))
-            ents.append((slab, rs_slab, out, rs, M, N, N, sp))
-            first += 8 * ((t + 7) // 8) * sp
-        table = self._upload(np.asarray(rows, dtype=np.int64), dev)
-        return table, first, ents
+        launches, ents = [], []
+        for variant in (0, 2):
+            rows, first = [], 0
+            for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
+                if x6 != variant:
+                    continue
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
+                klen = -(-(-(-K // sp)) // 16) * 16
+                sp = -(-K // klen)
+                if sp == 1:
+                    klen = K
+                slab = self.reserve(sp * (M * N + M) * 4, dev)
+                rs_slab = slab + sp * M * N * 4 if rs else 0
+                rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), 0, 0))
+                ents.append((slab, rs_slab, out, rs, M, N, N, sp))
+                first += 8 * ((t + 7) // 8) * sp
+            if rows:
+                launches.append((self._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first, variant))
+        return launches, ents
 
     def prepare_capture(self, n=4):
         """Pinned staging buffers for tables that have to be built WHILE a hipGraph is being captured (the grouped launch's
@@ -453,14 +460,14 @@ class _DeferredCombine:
         sig = (tuple(self.group), self.cur, self.off)  # (the slab regions continue where this pass's reserves stand)
         hit = self.group_cache.get(sig)
         if hit is None:
-            table, total, ents = self._plan_group()
-            hit = (table, total, ents, self.cur, self.off)
+            launches, ents = self._plan_group()
+            hit = (launches, ents, self.cur, self.off)
         else:
-            self.cur, self.off = hit[3], hit[4]
+            self.cur, self.off = hit[2], hit[3]
         self._remember(self.group_cache, sig, hit)
-        table, total, ents = hit[0], hit[1], hit[2]
-        lib.call('rscotr_gemm_dw_group', table.data_ptr(), len(self.group), total, _stream())
-        self.entries.extend(ents)
+        for table, n, total, variant in hit[0]:
+            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, _stream())
+        self.entries.extend(hit[1])
         self.group, self.group_keep = [], []
 
     def flush(self):

@@ -93,7 +93,7 @@ class GraphedTask:
         # weights, moments and step counts are put back afterwards; only the first replay counts
         snap = self.opt.snapshot()
         ops.DEFER.pin = True  # the flush tables looked up from here on are baked into the graph by address
-        ops.DEFER.prepare_capture(8)
+        ops.DEFER.prepare_capture(16)
         try:
             for _ in range(2):
                 self.opt.prepare_step(self.table)

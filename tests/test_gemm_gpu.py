@@ -357,11 +357,13 @@ def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
         assert _rel(acc, ref + C0.double()) < 2e-6, mode
 
 
-def test_grouped_deferred_weight_gradients(cuda):
-    """rscotr_gemm_dw_group through ops.DEFER: a batch of dW = A^T B problems of the step's small-output shapes (ragged
+@pytest.mark.parametrize('x6', [0, 1])
+def test_grouped_deferred_weight_gradients(cuda, x6, monkeypatch):
+    """(x6 = 1: interior problems on the bf16x6 128 x 128 variant, a second launch.)  rscotr_gemm_dw_group through ops.DEFER: a batch of dW = A^T B problems of the step's small-output shapes (ragged
     M / N / K, a destination shared by two problems, bias gradients riding along, per-sample k scaling) computed by ONE
     grouped launch + the deferred combine, against fp64; destinations are ACCUMULATED into."""
     from rscotr_amd import ops
+    monkeypatch.setattr(ops.DEFER, 'group_x6', x6)
     g = torch.Generator().manual_seed(21)
     shapes = [(256, 256, 10880), (256, 256, 1600), (200, 256, 256), (4, 256, 1600), (96, 48, 4096), (384, 384, 2048),
               (128, 256, 10880), (256, 256, 1600), (192, 192, 8192), (100, 20, 40)]
