@@ -924,11 +924,13 @@ __device__ __forceinline__ unsigned pack_bf16(__bf16 a, __bf16 b) {
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-template <int R, bool KM, int NPL>
+template <int R, bool KM, int NPL, int SBK = 16>
 struct SplitOperand {
-  static constexpr int LDR = 16 * NPL + 8;                          // bf16 per LDS row (row-major source)
-  static constexpr int WORDS = KM ? NPL * 8 * R : R * LDR / 2;      // dwords per stage
-  static constexpr int ITEMS = KM ? 8 * R / 4 : R * 4;              // float4 (pairs) per tile
+  static constexpr int LDR = SBK * NPL + 8;                         // bf16 per LDS row (row-major source): 112 / 208 bytes
+  static constexpr int KP = SBK / 2;                                // k pairs per stage
+  static constexpr int Q = SBK / 4;                                 // float4 per row per stage (row-major source)
+  static constexpr int WORDS = KM ? NPL * KP * R : R * LDR / 2;     // dwords per stage
+  static constexpr int ITEMS = KM ? KP * R / 4 : R * Q;             // float4 (pairs) per tile
   static constexpr int NV = (ITEMS + 255) / 256;
   float4 v[NV], w[NV];  // row-major: v; k-major: v = even k row, w = odd k row of a pair
 
@@ -938,7 +940,7 @@ struct SplitOperand {
       const int idx = tid + i * 256;
       if (ITEMS % 256 == 0 || idx < ITEMS) {
         if (!KM) {
-          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + (idx >> 2)) * ld + k0 + (idx & 3) * 4);
+          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + idx / Q) * ld + k0 + (idx % Q) * 4);
         } else {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
           const float* src = P + (long)(k0 + 2 * kp) * ld + row0 + r4;
@@ -961,12 +963,16 @@ struct SplitOperand {
       }
     }
   }
-  // k-major only: running sums over k of the four rows this thread stages (r4 is the same for all its items when NV == 1)
-  __device__ __forceinline__ void accum(float4& a, int tid) const {
-    static_assert(!KM || NV == 1, "row sums assume one item per thread");
-    if (ITEMS % 256 == 0 || tid < ITEMS) {
-      a.x += v[0].x + w[0].x; a.y += v[0].y + w[0].y; a.z += v[0].z + w[0].z; a.w += v[0].w + w[0].w;
-    }
+  // k-major only: running sums over k of the four rows this thread stages (r4 is the same for all its items: 256 is a
+  // multiple of R / 4), times `f` (0 for a tile staged a second time at the end of the pipelined loop)
+  __device__ __forceinline__ void accum(float4& a, int tid, float f = 1.f) const {
+    static_assert(!KM || 256 % (R / 4) == 0, "row sums assume one row group per thread");
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ITEMS % 256 == 0 || tid + i * 256 < ITEMS) {
+        a.x = fmaf(f, v[i].x + w[i].x, a.x); a.y = fmaf(f, v[i].y + w[i].y, a.y);
+        a.z = fmaf(f, v[i].z + w[i].z, a.z); a.w = fmaf(f, v[i].w + w[i].w, a.w);
+      }
   }
   __device__ __forceinline__ void store(unsigned* S, int tid) const {
 #pragma unroll
@@ -974,7 +980,7 @@ struct SplitOperand {
       const int idx = tid + i * 256;
       if (ITEMS % 256 == 0 || idx < ITEMS) {
         if (!KM) {
-          const int row = idx >> 2, kq = (idx & 3) * 4;
+          const int row = idx / Q, kq = (idx % Q) * 4;
           __bf16 a[3], b[3], c[3], d[3];
           split_planes<NPL>(v[i].x, a); split_planes<NPL>(v[i].y, b); split_planes<NPL>(v[i].z, c); split_planes<NPL>(v[i].w, d);
           unsigned* dst = S + (row * LDR + kq) / 2;
@@ -983,7 +989,7 @@ struct SplitOperand {
             uint2 q;
             q.x = pack_bf16(a[pl], b[pl]);
             q.y = pack_bf16(c[pl], d[pl]);
-            *reinterpret_cast<uint2*>(dst + pl * 8) = q;
+            *reinterpret_cast<uint2*>(dst + pl * (SBK / 2)) = q;
           }
         } else {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
@@ -997,21 +1003,22 @@ struct SplitOperand {
             uint4 q;
             q.x = pack_bf16(e0[pl], o0[pl]); q.y = pack_bf16(e1[pl], o1[pl]);
             q.z = pack_bf16(e2[pl], o2[pl]); q.w = pack_bf16(e3[pl], o3[pl]);
-            *reinterpret_cast<uint4*>(S + (pl * 8 + kp) * R + r4) = q;
+            *reinterpret_cast<uint4*>(S + (pl * KP + kp) * R + r4) = q;
           }
         }
       }
     }
   }
-  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, bf16x8 (&f)[3]) {
+  // fragment of k-substep ks (16 k) of the stage
+  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) {
     if (!KM) {
-      const unsigned* q = S + (row * LDR + 8 * g) / 2;
+      const unsigned* q = S + (row * LDR + 16 * ks + 8 * g) / 2;
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
+      for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * (SBK / 2)));
     } else {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        const unsigned* q = S + (pl * 8 + 4 * g) * R + row;
+        const unsigned* q = S + (pl * KP + 8 * ks + 4 * g) * R + row;
         uint4 t;
         t.x = q[0]; t.y = q[R]; t.z = q[2 * R]; t.w = q[3 * R];
         f[pl] = __builtin_bit_cast(bf16x8, t);
@@ -1020,19 +1027,29 @@ struct SplitOperand {
   }
 };
 
+// PIPE: 0 = one LDS stage, two barriers per k-tile of 16; 1 = two LDS stages, one barrier, next tile's loads one step ahead;
+// 2 / 3 = the software-pipelined loop (two LDS stages, one barrier): the loads of tile t + D are issued at the top of step t
+// into the register set step t - 1 freed (D = 2 / 3 sets), and the split / pack / LDS writes of tile t + 1 are interleaved
+// with the MFMAs of tile t inside the wavefront (sched_group_barrier: 1 MFMA : 4 VALU : 1 DS write) — the conversion runs in
+// the shadow of the matrix pipe instead of in a phase of its own.  PIPE 2 stages 32 k per step (64 x 64 tiles: a row-major
+// operand row is one whole 128-byte line per step; half as many barriers), PIPE 3 stages 16 (128 x 128 tiles: LDS).
+__device__ const float bf16x6_one = 1.f;
+template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : 16; }
+template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? 2 : PIPE == 3 ? 3 : 1; }
+
 template <int BM, int BN, bool AKM, bool BKM, int PIPE>
 constexpr int bf16x6_lds_words() {
-  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3>::WORDS + SplitOperand<BN, BKM, 3>::WORDS);
+  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS);
 }
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
 template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
-  constexpr int NPL = 3, SBK = 16;
+  constexpr int NPL = 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
-  using OA = SplitOperand<BM, AKM, NPL>;
-  using OB = SplitOperand<BN, BKM, NPL>;
+  using OA = SplitOperand<BM, AKM, NPL, SBK>;
+  using OB = SplitOperand<BN, BKM, NPL, SBK>;
   constexpr int NBUF = PIPE ? 2 : 1;
   unsigned* sA[2] = {lds, lds + (NBUF - 1) * OA::WORDS};
   unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
@@ -1063,8 +1080,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  OA la;
-  OB lb;
+  OA las[D];
+  OB lbs[D];
+  OA& la = las[0];
+  OB& lb = lbs[0];
   const bool do_rs = AKM && p.rowsum && n0 == 0;  // bias gradient riding the dW contraction (tile column 0)
   float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
   const int fr = lane & 31, g = lane >> 5;
@@ -1079,24 +1098,72 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     lb.store(b_s, tid);
   };
   auto mma = [&](const unsigned* a_s, const unsigned* b_s) {
-    bf16x8 af[MT][3], bf[NT][3];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, af[i]);
+    for (int ks = 0; ks < SBK / 16; ++ks) {
+      bf16x8 af[MT][3], bf[NT][3];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, bf[j]);
+      for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, ks, af[i]);
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, ks, bf[j]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {  // small terms first
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {  // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
   };
-  if (PIPE) {
+  if (PIPE >= 2) {
+    // Steady state without branches inside a step (the scheduler interleaves within one basic block): loads past the end
+    // re-read the last tile, the last step stages it a second time into the idle LDS stage (its row sums times 0).
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;  // steps per unrolled round: register set and LDS stage indices static
+    constexpr int NMFMA = MT * NT * 6 * (SBK / 16);
+    // per-sample k scaling of a k-major A (weight gradients under DropPath / Mixup): always applied, so that a step stays
+    // one basic block — without a scale vector every k reads the constant 1
+    const float* ksp = (AKM && p.kscale) ? p.kscale : &bf16x6_one;
+    const int ksper = (AKM && p.kscale) ? p.krows_per : 0x7fffffff;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int tt = min(d, nk - 1);
+      las[d].load(p.A, p.lda, m0, kbeg + tt * SBK, tid);
+      lbs[d].load(p.B, p.ldb, n0, kbeg + tt * SBK, tid);
+    }
+    if (AKM) las[0].scale_k(ksp, ksper, kbeg, tid);
+    if (AKM) las[0].accum(rs, tid);
+    las[0].store(sA[0], tid);
+    lbs[0].store(sB[0], tid);
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += U) {
+#pragma unroll
+      for (int s = 0; s < U; ++s) {
+        const int t = t0 + s;
+        if (t < nk) {
+          {  // tile t + D into the set tile t left (staged during step t - 1 / the prologue)
+            const int tt = min(t + D, nk - 1);
+            las[s % D].load(p.A, p.lda, m0, kbeg + tt * SBK, tid);
+            lbs[s % D].load(p.B, p.ldb, n0, kbeg + tt * SBK, tid);
+          }
+          mma(sA[s & 1], sB[s & 1]);
+          if (AKM) las[(s + 1) % D].scale_k(ksp, ksper, kbeg + min(t + 1, nk - 1) * SBK, tid);
+          if (AKM) las[(s + 1) % D].accum(rs, tid, t + 1 < nk ? 1.f : 0.f);
+          las[(s + 1) % D].store(sA[(s + 1) & 1], tid);
+          lbs[(s + 1) % D].store(sB[(s + 1) & 1], tid);
+#pragma unroll
+          for (int i = 0; i < NMFMA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+          }
+          __syncthreads();
+        }
+      }
+    }
+  } else if (PIPE) {
     fetch(0);
     stage(sA[0], sB[0]);
     if (nk > 1) fetch(1);
@@ -1123,14 +1190,15 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
 
   if (AKM && do_rs) {  // thread t summed rows (t % (BM/4)) * 4 .. + 3 over the k-pairs it staged: fold the 8 k-lanes
     __syncthreads();
-    float4* red = reinterpret_cast<float4*>(lds);
-    if (tid < 8 * BM / 4) red[tid] = rs;  // [k-lane][BM / 4]
+    constexpr int KL = 256 / (BM / 4) < OA::KP ? 256 / (BM / 4) : OA::KP;  // distinct k-lanes among the threads (item i of a
+    float4* red = reinterpret_cast<float4*>(lds);                            // thread has the same rows: 256 % (BM / 4) == 0)
+    if (tid < KL * BM / 4) red[tid] = rs;  // [k-lane][BM / 4]
     __syncthreads();
     if (tid < BM) {
       const float* rf = reinterpret_cast<const float*>(lds);
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v += rf[k * BM + tid];
+      for (int k = 0; k < KL; ++k) v += rf[k * BM + tid];
       const int m = m0 + tid;
       if (p.splits > 1 || SLAB) p.rs_slabs[(long)split * p.M + m] = v;
       else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
@@ -1287,7 +1355,8 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
     sp = std::min<long>(sp, ws_bytes / per);
     if (sp >= 2) {
       int klen = (int)((p.K + sp - 1) / sp);
-      klen = (klen + 15) / 16 * 16;
+      const int kq = p.K % 32 == 0 ? 32 : 16;  // (k-slices of whole 32-k stages for the pipelined 64 x 64 kernel)
+      klen = (klen + kq - 1) / kq * kq;
       c.bm = 64; c.klen = klen; c.splits = (p.K + klen - 1) / klen;
       if (c.splits == 1) c.klen = p.K;
     }
@@ -2025,8 +2094,14 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
       else snprintf(xname, sizeof(xname), "rscotr::gemm_bf16x6_kernel<%d, %d, %s, %s, *>", sc.bm, sc.bm, a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
       ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", xname);
       const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
-      if (sc.bm == 128) launch_split6<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
-      else launch_split6<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+      static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;  // bit 0: 64 x 64 (measured -0.45 ms / round), bit 1: 128 x 128 (measured slower on every layout of the step: +0.65 ms)
+      if (sc.bm == 128) {
+        if (pipelined & 2) launch_split6<128, 3>(p, a_kmajor, b_kmajor, nwg, s);
+        else launch_split6<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
+      } else {
+        if ((pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0) launch_split6<64, 2>(p, a_kmajor, b_kmajor, nwg, s);
+        else launch_split6<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+      }
       if (int e = check_launch("rscotr_gemm_f32 (bf16x6)")) return e;
       if (sc.splits > 1) {
         if (tl_defer) { tl_last_splits = sc.splits; return RSCOTR_OK; }

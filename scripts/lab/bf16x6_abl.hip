@@ -24,9 +24,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+constexpr int BK = 16;
 
 template <int NPL>
 __device__ __forceinline__ void split(float x, __bf16 (&p)[3]) {
+#ifdef ABL_NOCVT
+  const unsigned short t = (unsigned short)(__builtin_bit_cast(unsigned, x) >> 16);
+  p[0] = p[1] = p[2] = __builtin_bit_cast(__bf16, t);
+  return;
+#endif
   p[0] = (__bf16)x;
   const float r1 = x - (float)p[0];
   p[1] = (__bf16)r1;
@@ -42,14 +48,11 @@ __device__ __forceinline__ unsigned pk(__bf16 a, __bf16 b) {
 //     plane p) is one 16-byte read at row * LDR + 16 p + 8 g.  Row pitch 112 B (NPL 3) / 80 B (NPL 2): conflict-free b128 reads.
 //   k-major source:   [NPL][8 k-pairs][R] dwords (two consecutive k of one row per dword), written as 16-byte rows,
 //     a fragment = four dword reads (pairs 4g .. 4g+3).  Same k order inside a fragment for both layouts.
-template <int R, bool KM, int NPL, int BK>
+template <int R, bool KM, int NPL>
 struct Operand {
-  static constexpr int LDR = BK * NPL + 8;
-  static constexpr int KP = BK / 2;  // k pairs per stage
-  static constexpr int Q = BK / 4;   // float4 per row per stage
-  static constexpr int ITEMS = KM ? KP * R / 4 : R * Q;
-  static constexpr int WORDS = KM ? NPL * KP * R : R * LDR / 2;  // dwords per stage
-  static constexpr int NV = (ITEMS + 255) / 256;
+  static constexpr int LDR = 16 * NPL + 8;
+  static constexpr int WORDS = KM ? NPL * 8 * R : R * LDR / 2;  // dwords per stage
+  static constexpr int NV = KM ? (8 * R / 4 + 255) / 256 : (R * 4 + 255) / 256;
   float4 v[NV], w[NV];  // row-major: v only; k-major: v = even k row, w = odd k row of a pair
 
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid) {
@@ -57,10 +60,10 @@ struct Operand {
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       if (!KM) {
-        if (ITEMS % 256 == 0 || idx < ITEMS)
-          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + idx / Q) * ld + k0 + (idx % Q) * 4);
+        if (R * 4 % 256 == 0 || idx < R * 4)
+          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + (idx >> 2)) * ld + k0 + (idx & 3) * 4);
       } else {
-        if (ITEMS % 256 == 0 || idx < ITEMS) {
+        if (8 * R / 4 % 256 == 0 || idx < 8 * R / 4) {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
           const float* src = P + (long)(k0 + 2 * kp) * ld + row0 + r4;
           v[i] = *reinterpret_cast<const float4*>(src);
@@ -74,8 +77,8 @@ struct Operand {
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       if (!KM) {
-        if (ITEMS % 256 == 0 || idx < ITEMS) {
-          const int row = idx / Q, kq = (idx % Q) * 4;
+        if (R * 4 % 256 == 0 || idx < R * 4) {
+          const int row = idx >> 2, kq = (idx & 3) * 4;
           __bf16 a[3], b[3], c[3], d[3];
           split<NPL>(v[i].x, a); split<NPL>(v[i].y, b); split<NPL>(v[i].z, c); split<NPL>(v[i].w, d);
           unsigned* dst = S + (row * LDR + kq) / 2;
@@ -84,11 +87,11 @@ struct Operand {
             uint2 q;
             q.x = pk(a[p], b[p]);
             q.y = pk(c[p], d[p]);
-            *reinterpret_cast<uint2*>(dst + p * (BK / 2)) = q;
+            *reinterpret_cast<uint2*>(dst + p * 8) = q;
           }
         }
       } else {
-        if (ITEMS % 256 == 0 || idx < ITEMS) {
+        if (8 * R / 4 % 256 == 0 || idx < 8 * R / 4) {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
           __bf16 e0[3], o0[3], e1[3], o1[3], e2[3], o2[3], e3[3], o3[3];
           split<NPL>(v[i].x, e0); split<NPL>(w[i].x, o0);
@@ -99,21 +102,21 @@ struct Operand {
           for (int p = 0; p < NPL; ++p) {
             uint4 q;
             q.x = pk(e0[p], o0[p]); q.y = pk(e1[p], o1[p]); q.z = pk(e2[p], o2[p]); q.w = pk(e3[p], o3[p]);
-            *reinterpret_cast<uint4*>(S + (p * KP + kp) * R + r4) = q;
+            *reinterpret_cast<uint4*>(S + (p * 8 + kp) * R + r4) = q;
           }
         }
       }
     }
   }
-  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) {
+  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, bf16x8 (&f)[3]) {
     if (!KM) {
-      const unsigned* q = S + (row * LDR + 16 * ks + 8 * g) / 2;
+      const unsigned* q = S + (row * LDR + 8 * g) / 2;
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) f[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + p * (BK / 2)));
+      for (int p = 0; p < NPL; ++p) f[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + p * 8));
     } else {
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
-        const unsigned* q = S + (p * KP + 8 * ks + 4 * g) * R + row;
+        const unsigned* q = S + (p * 8 + 4 * g) * R + row;
         uint4 t;
         t.x = q[0]; t.y = q[R]; t.z = q[2 * R]; t.w = q[3 * R];
         f[p] = __builtin_bit_cast(bf16x8, t);
@@ -122,13 +125,13 @@ struct Operand {
   }
 };
 
-template <int BM, int BN, int TERMS, bool AKM, bool BKM, int PIPE, int BK>
+template <int BM, int BN, int TERMS, bool AKM, bool BKM, int PIPE>
 __global__ __launch_bounds__(256) void gemm_split(const float* __restrict__ A, const float* __restrict__ B,
                                                   float* __restrict__ C, int M, int N, int K, int lda, int ldb) {
   constexpr int NPL = TERMS == 6 ? 3 : 2;
   constexpr int MT = BM / 64, NT = BN / 64;
-  using OA = Operand<BM, AKM, NPL, BK>;
-  using OB = Operand<BN, BKM, NPL, BK>;
+  using OA = Operand<BM, AKM, NPL>;
+  using OB = Operand<BN, BKM, NPL>;
   constexpr int NBUF = PIPE ? 2 : 1;
   __shared__ __attribute__((aligned(16))) unsigned sA[NBUF][OA::WORDS], sB[NBUF][OB::WORDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -148,20 +151,18 @@ __global__ __launch_bounds__(256) void gemm_split(const float* __restrict__ A, c
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  constexpr int D = PIPE >= 10 ? PIPE % 10 : PIPE >= 2 ? PIPE : 1;
-  OA las[D];
-  OB lbs[D];
-  OA& la = las[0];
-  OB& lb = lbs[0];
+  OA la;
+  OB lb;
   const int fr = lane & 31, g = lane >> 5;
   auto mma = [&](const unsigned* a_s, const unsigned* b_s) {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+#ifdef ABL_NOMMA
+    return;
+#endif
     bf16x8 af[MT][3], bf[NT][3];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, ks, af[i]);
+    for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, af[i]);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, ks, bf[j]);
+    for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, bf[j]);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -175,91 +176,9 @@ __global__ __launch_bounds__(256) void gemm_split(const float* __restrict__ A, c
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
       }
-    }
   };
   const int nk = K / BK;
-  if (PIPE >= 10) {
-    // branch-free steady state: loads of tile t+D-1 issued at the top of block t into the register set freed by the previous
-    // block, fragment reads + MFMAs of tile t interleaved (sched_group_barrier) with the split / pack / LDS writes of tile t+1
-    constexpr int PAT = PIPE / 10, DD = PIPE % 10;
-    constexpr int U = (DD % 2 == 0) ? DD : 2 * DD;
-    constexpr int NMFMA = MT * NT * (TERMS == 6 ? 6 : 3) * (BK / 16);
-#pragma unroll
-    for (int d = 0; d < DD; ++d) {
-      const int tt = min(d, nk - 1);
-      las[d].load(A, lda, m0, tt * BK, tid);
-      lbs[d].load(B, ldb, n0, tt * BK, tid);
-    }
-    las[0].store(sA[0], tid);
-    lbs[0].store(sB[0], tid);
-    __syncthreads();
-    for (int t0 = 0; t0 < nk; t0 += U) {
-#pragma unroll
-      for (int s = 0; s < U; ++s) {
-        const int t = t0 + s;
-        if (t < nk) {
-          {
-            const int tt = min(t + DD, nk - 1);
-            las[s % DD].load(A, lda, m0, tt * BK, tid);
-            lbs[s % DD].load(B, ldb, n0, tt * BK, tid);
-          }
-          mma(sA[s & 1], sB[s & 1]);
-          las[(s + 1) % DD].store(sA[(s + 1) & 1], tid);
-          lbs[(s + 1) % DD].store(sB[(s + 1) & 1], tid);
-          if (PAT == 1) {
-#pragma unroll
-            for (int i = 0; i < NMFMA; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
-              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-            }
-          } else if (PAT == 2) {
-#pragma unroll
-            for (int i = 0; i < NMFMA; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
-              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-            }
-          }
-          __syncthreads();
-        }
-      }
-    }
-  } else if (PIPE >= 2) {
-    constexpr int U = (D % 2 == 0) ? D : 2 * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < nk) {
-        las[d].load(A, lda, m0, d * BK, tid);
-        lbs[d].load(B, ldb, n0, d * BK, tid);
-      }
-    las[0].store(sA[0], tid);
-    lbs[0].store(sB[0], tid);
-    if (D < nk) {
-      las[0].load(A, lda, m0, D * BK, tid);
-      lbs[0].load(B, ldb, n0, D * BK, tid);
-    }
-    __syncthreads();
-    for (int t0 = 0; t0 < nk; t0 += U) {
-#pragma unroll
-      for (int s = 0; s < U; ++s) {
-        const int t = t0 + s;
-        if (t < nk) {
-          mma(sA[s & 1], sB[s & 1]);
-          if (t + 1 < nk) {
-            las[(s + 1) % D].store(sA[(s + 1) & 1], tid);
-            lbs[(s + 1) % D].store(sB[(s + 1) & 1], tid);
-            if (t + 1 + D < nk) {
-              las[(s + 1) % D].load(A, lda, m0, (t + 1 + D) * BK, tid);
-              lbs[(s + 1) % D].load(B, ldb, n0, (t + 1 + D) * BK, tid);
-            }
-          }
-          __syncthreads();
-        }
-      }
-    }
-  } else if (PIPE) {
+  if (PIPE) {
     la.load(A, lda, m0, 0, tid);
     lb.load(B, ldb, n0, 0, tid);
     la.store(sA[0], tid);
@@ -286,14 +205,24 @@ __global__ __launch_bounds__(256) void gemm_split(const float* __restrict__ A, c
     la.load(A, lda, m0, 0, tid);
     lb.load(B, ldb, n0, 0, tid);
     for (int t = 0; t < nk; ++t) {
+#ifdef ABL_NOSTAGE
+      if (t == 0) {
+        la.store(sA[0], tid);
+        lb.store(sB[0], tid);
+        __syncthreads();
+      }
+#else
       __syncthreads();
       la.store(sA[0], tid);
       lb.store(sB[0], tid);
       __syncthreads();
+#ifndef ABL_NOLOAD
       if (t + 1 < nk) {
         la.load(A, lda, m0, (t + 1) * BK, tid);
         lb.load(B, ldb, n0, (t + 1) * BK, tid);
       }
+#endif
+#endif
       mma(sA[0], sB[0]);
     }
   }
@@ -305,6 +234,9 @@ __global__ __launch_bounds__(256) void gemm_split(const float* __restrict__ A, c
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (BM / 2) + i * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
         const int col = n0 + wn * (BN / 2) + j * 32 + fr;
+#ifdef ABL_NOEPI
+        if (acc[i][j][r] == 123.456f)
+#endif
         C[(long)row * N + col] = acc[i][j][r];
       }
 }
@@ -322,22 +254,15 @@ __global__ void ref_f32(const float* A, const float* B, float* out, int K, int l
 }
 
 typedef void (*Kern)(const float*, const float*, float*, int, int, int, int, int);
-struct Variant { const char* name; Kern k[4]; int bm, bn, bk; };  // k[akm * 2 + bkm]
+struct Variant { const char* name; Kern k[4]; int bm, bn; };  // k[akm * 2 + bkm]
 
-#define VAR(BM, BN, T, P, BK) { #BM "x" #BN "x" #BK " t" #T " p" #P, { gemm_split<BM, BN, T, false, false, P, BK>, gemm_split<BM, BN, T, false, true, P, BK>, \
-                                                         gemm_split<BM, BN, T, true, false, P, BK>, gemm_split<BM, BN, T, true, true, P, BK> }, BM, BN, BK }
+#define VAR(BM, BN, T, P) { #BM "x" #BN " t" #T " p" #P, { gemm_split<BM, BN, T, false, false, P>, gemm_split<BM, BN, T, false, true, P>, \
+                                                         gemm_split<BM, BN, T, true, false, P>, gemm_split<BM, BN, T, true, true, P> }, BM, BN }
 
 int main(int argc, char** argv) {
-  const Variant vars[] = {VAR(128, 128, 6, 0, 16), VAR(128, 128, 6, 2, 16), VAR(128, 128, 6, 2, 16), VAR(128, 128, 6, 12, 16), VAR(128, 128, 6, 13, 16),
-                          VAR(128, 128, 6, 22, 16), VAR(128, 128, 6, 3, 16),
-                          VAR(64, 64, 6, 1, 32), VAR(64, 64, 6, 12, 32), VAR(64, 64, 6, 22, 32), VAR(64, 64, 6, 3, 32), VAR(64, 64, 6, 13, 16)};
+  const Variant vars[] = {VAR(128, 128, 6, 0), VAR(128, 128, 3, 0), VAR(64, 64, 6, 1), VAR(64, 64, 6, 0)};
   // {M, N, K, a_kmajor, b_kmajor, fp32-pipe us (profiles/r1_s7_gemm_census_fp32.txt)}
-  const int shapes[][6] = {
-      {10880, 2048, 256, 0, 0, 117}, {10880, 256, 2048, 0, 0, 125}, {10880, 256, 2048, 0, 1, 128}, {10880, 2048, 256, 0, 1, 125},
-      {256, 2048, 10880, 1, 1, 124},  {10880, 256, 256, 0, 0, 23},   {10880, 256, 256, 0, 1, 24},
-      {2048, 1536, 384, 0, 0, 34},   {2048, 384, 1536, 0, 0, 42},   {2048, 384, 1536, 0, 1, 41},
-      {384, 1536, 2048, 1, 1, 43},  {8192, 768, 192, 0, 0, 35},    {8192, 192, 768, 0, 0, 41},    {512, 3072, 768, 0, 0, 40},
-      {4096, 4096, 4096, 0, 0, 0}};
+  const int shapes[][6] = {{10880, 2048, 256, 0, 0, 117}, {10880, 256, 256, 0, 0, 23}, {10880, 256, 2048, 0, 0, 125}, {4096, 4096, 4096, 0, 0, 0}};
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
   for (auto& sh : shapes) {
@@ -374,8 +299,7 @@ int main(int argc, char** argv) {
     const double flop = 2.0 * M * N * K;
     printf("M=%5d N=%5d K=%5d %d%d  fp32 pipe (r1 census): %3d us   fp32 FMA chain err %.1e\n", M, N, K, akm, bkm, sh[5], e32 / refmax);
     for (const Variant& v : vars) {
-      if (M % v.bm || N % v.bn || K % v.bk) continue;
-      const int BK = v.bk; (void)BK;
+      if (M % v.bm || N % v.bn || K % BK) continue;
       const dim3 grid((M / v.bm) * (N / v.bn));
       Kern kern = v.k[akm * 2 + bkm];
       const int iters = flop > 5e10 ? 10 : 40;
