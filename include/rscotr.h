@@ -100,6 +100,11 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * (the row sums see the scaled operand).  Together they fold the per-sample DropPath factor of the Swin blocks
  * (mmdet SwinBlock: x + drop_path(attn/ffn(...)), cfg ...potsdam.py:20) into the proj / fc2 Linear: forward
  * y = x + s_b (h W^T + b); backward dH = s_b (g W), dW = (s g)^T h, db = sum s g.
+ * out2 (may be NULL; same ldc as C): a second output C2 = C + resid, while C itself is then stored WITHOUT the residual
+ * (C = epilogue value [+ old C]; C2 = C + resid).  Backward of an attention block wants one product both alone (the
+ * gradient of the positional embedding) and merged with the gradient of the residual path (the gradient of the block
+ * input): this replaces the element-wise add autograd would launch (mmcv MultiheadAttention / MultiScaleDeformableAttention
+ * `query + query_pos`, `identity + dropout(out)`).
  * `workspace` (may be NULL) holds split-K slabs (long reductions on short grids are cut along K and combined
  * in fixed order by a second kernel); rscotr_gemm_f32_workspace() returns the bytes the split path wants
  * for a problem (0 = it never splits).
@@ -120,7 +125,7 @@ int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
                     int ldc, int a_kmajor, int b_kmajor, const float* bias, int act, const float* aux,
                     float* pre, const float* resid, int accumulate, float* rowsum, int rowsum_accumulate,
                     const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
-                    float* workspace, int64_t workspace_bytes, void* stream);
+                    float* out2, float* workspace, int64_t workspace_bytes, void* stream);
 /* Deferred split-K combine for weight gradients.  rscotr_gemm_f32_dw_slabs = rscotr_gemm_f32(a_kmajor = b_kmajor = 1,
  * accumulate = 1, rowsum_accumulate = 1) WITHOUT its combine launch: the slabs stay in `slab_region` (caller-owned until
  * the flush; rscotr_gemm_f32_workspace() bytes), *splits_out (HOST int) = number of slabs written ([splits][M][N] floats,

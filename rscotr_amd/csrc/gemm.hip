@@ -59,6 +59,8 @@ struct GemmParams {
   const float* aux;
   float* pre;
   const float* resid;
+  float* C2;          // optional second output (same ldc): C2 = C + resid while C itself is stored WITHOUT the residual
+                      // (a gradient that is wanted both alone and merged with another one: no element-wise add launch)
   int M, N, K;
   int lda, ldb, ldc;
   int act, accumulate;
@@ -103,6 +105,11 @@ __device__ __forceinline__ float epilogue_one(const GemmParams& p, float v, int 
     default: break;
   }
   if (p.rowscale) v *= p.rowscale[m / p.rows_per];
+  if (p.C2) {
+    if (p.accumulate) v += p.C[o];
+    p.C2[o] = p.resid ? v + p.resid[o] : v;
+    return v;
+  }
   if (p.resid) v += p.resid[o];
   if (p.accumulate) v += p.C[o];
   return v;
@@ -136,6 +143,12 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, i
   if (p.rowscale) {
     const float f = p.rowscale[m / p.rows_per];
     v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+  }
+  if (p.C2) {
+    if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+    *reinterpret_cast<float4*>(p.C + o) = v;
+    *reinterpret_cast<float4*>(p.C2 + o) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+    return;
   }
   if (p.resid) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
   if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
@@ -194,6 +207,25 @@ __device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4
     for (int u = 0; u < 4; ++u) x[u] = ok[u] ? p.rowscale[(m + u) / p.rows_per] : 1.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] *= x[u];
+  }
+  if (p.C2) {  // C = value (+ old C), C2 = C + resid
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.resid) {
+      const float* rp = p.resid + base;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = ok[u] ? rp[o[u]] : 0.f;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = ok[u] ? crow[o[u]] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] += x[u];
+    }
+    float* c2 = p.C2 + base;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) { crow[o[u]] = v[u]; c2[o[u]] = v[u] + r[u]; }
+    return;
   }
   if (p.resid) {
     const float* rp = p.resid + base;
@@ -592,7 +624,7 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
       }
     return;
   }
-  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale;
+  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -822,7 +854,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_big_kernel(GemmParams p) {
       }
     return;
   }
-  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale;
+  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1220,7 +1252,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       }
     return;
   }
-  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale;
+  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1286,7 +1318,7 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   p.M = (int)t[5]; p.N = (int)t[6]; p.K = (int)t[7]; p.lda = (int)t[8]; p.ldb = (int)t[9];
   p.ksplit_len = (int)t[10]; p.splits = (int)t[11];
   p.krows_per = (int)t[13];
-  p.C = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr; p.rowscale = nullptr;
+  p.C = nullptr; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr; p.rowscale = nullptr;
   p.ldc = p.N; p.act = ACT_NONE; p.accumulate = 0; p.rows_per = 1; p.rowsum_acc = 0;
   p.rowsum = p.rs_slabs;  // non-null = the row sums are wanted (they go to rs_slabs)
   p.vecA = ((t[0] & 15) == 0) && (p.lda % 4 == 0);
@@ -2023,7 +2055,7 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
                                int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
                                const float* aux, float* pre, const float* resid, int accumulate,
                                float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
-                               const float* kscale, int krows_per_scale, float* workspace,
+                               const float* kscale, int krows_per_scale, float* out2, float* workspace,
                                int64_t workspace_bytes, void* stream) {
   if (M < 0 || N < 0 || K < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: negative dimension");
   if ((rowscale && rows_per_scale <= 0) || (kscale && (krows_per_scale <= 0 || !a_kmajor)))
@@ -2037,12 +2069,12 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
     return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: leading dimension too small");
   if (rowsum && !a_kmajor) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: rowsum needs a k-major A");
   GemmParams p;
-  p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux = aux; p.pre = pre; p.resid = resid;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux = aux; p.pre = pre; p.resid = resid; p.C2 = out2;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.act = act; p.accumulate = accumulate;
   p.vecA = aligned16(A) && (lda % 4 == 0);
   p.vecB = aligned16(B) && (ldb % 4 == 0);
-  p.vecC = (ldc % 4 == 0) && aligned16(C) && aligned16(bias) && aligned16(aux) && aligned16(pre) && aligned16(resid);
+  p.vecC = (ldc % 4 == 0) && aligned16(C) && aligned16(bias) && aligned16(aux) && aligned16(pre) && aligned16(resid) && aligned16(out2);
   p.rowsum = rowsum; p.rowsum_acc = rowsum_accumulate;
   p.nb1 = 0; p.nb2 = 1;
   p.rowscale = rowscale; p.rows_per = rows_per_scale; p.kscale = kscale; p.krows_per = krows_per_scale;
@@ -2203,7 +2235,7 @@ extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C
   tl_defer = 1;
   tl_last_splits = 1;
   const int e = rscotr_gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, 1, 1, nullptr, ACT_NONE, nullptr, nullptr, nullptr, 1, rowsum,
-                                1, nullptr, 0, kscale, krows_per_scale, slab_region, slab_bytes, stream);
+                                1, nullptr, 0, kscale, krows_per_scale, nullptr, slab_region, slab_bytes, stream);
   tl_defer = 0;
   *splits_out = tl_last_splits;
   return e;
@@ -2307,7 +2339,7 @@ extern "C" int rscotr_gemm_f32_batched(const float* A, const float* B, float* C,
                       !aligned16(workspace)))
     return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_batched: ksplits needs row-major A, k-major B, K %% ksplits == 0, a workspace");
   GemmParams p;
-  p.A = A; p.B = B; p.C = ksplits > 1 ? workspace : C; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr;
+  p.A = A; p.B = B; p.C = ksplits > 1 ? workspace : C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr; p.pre = nullptr; p.resid = nullptr;
   p.M = M; p.N = N; p.K = K / ksplits; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.act = ACT_NONE; p.accumulate = accumulate;
   const long kl = K / ksplits;

@@ -339,7 +339,9 @@ class DinoTransformerDecoder(TransformerLayerSequence):
         return torch.cat(outs, dim=2)
 
     def forward(self, query, value, reference_points, valid_ratios, reg_branches, attn_mask, key_padding_mask, geom):
-        """Batch-first. Returns (stack of normed outputs (nl,B,Q,C), stack of refs (nl+1,B,Q,4))."""
+        """Batch-first. Returns (normed outputs of the nl layers, each (B,Q,C); the nl+1 reference sets, each (B,Q,4)) as
+        LISTS: the head applies a different branch to every layer's output, and indexing a stacked tensor would cost a
+        full-size zero-fill + copy per use and an add per layer in backward (35 launches on 10 MB tensors per step)."""
         output = query
         inter, inter_ref = [], [reference_points]
         vr4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
@@ -354,7 +356,7 @@ class DinoTransformerDecoder(TransformerLayerSequence):
             reference_points = new_ref.detach()
             inter.append(ops.layer_norm(output, self.norm.weight, self.norm.bias))
             inter_ref.append(new_ref)  # look-forward-twice: un-detached
-        return torch.stack(inter), torch.stack(inter_ref)
+        return inter, inter_ref
 
 
 @MODELS.register_module()
@@ -661,10 +663,9 @@ class DINOHead(nn.Module):
             mlvl_feats, mlvl_masks, None, mlvl_pos, dn_label_query, dn_bbox_query, attn_mask, encoder,
             reg_branches=self.reg_branches, cls_branches=self.cls_branches, record=record, unpadded=not padded)
         if dn_label_query is not None and dn_label_query.size(1) == 0:
-            hs = hs.clone()
-            hs[0] += self.label_embedding.weight[0, 0] * 0.0  # dino_head.py:124-128
+            hs = [hs[0] + self.label_embedding.weight[0, 0] * 0.0] + list(hs[1:])  # dino_head.py:124-128
         outputs_classes, outputs_coords = [], []
-        for lvl in range(hs.shape[0]):
+        for lvl in range(len(hs)):
             outputs_classes.append(ops.linear(hs[lvl], self.cls_branches[lvl].weight, self.cls_branches[lvl].bias))
             outputs_coords.append(ops.refine_box(_mlp(hs[lvl], self.reg_branches[lvl]), inter_references[lvl], eps=1e-3))
         return torch.stack(outputs_classes), torch.stack(outputs_coords), topk_score, topk_anchor

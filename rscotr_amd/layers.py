@@ -159,27 +159,16 @@ class MultiScaleDeformableAttention(nn.Module):
                 reference_points=None, spatial_shapes=None, level_start_index=None, offset_norm=None, **kwargs):
         """Batch-first: query (B,Nq,C), value (B,Nk,C); reference_points (B,Nq,L,2|4);
         spatial_shapes (L,2) int64 device tensor; offset_norm (L,2) float (W_l,H_l)."""
-        if value is None:
-            value = query
         if identity is None:
             identity = query
-        if query_pos is not None:
-            query = query + query_pos
-        B, Nq, C = query.shape
-        Nk = value.shape[1]
-        H, L, P = self.num_heads, self.num_levels, self.num_points
-        v = ops.linear(value, self.value_proj.weight, self.value_proj.bias)
-        if key_padding_mask is not None:
-            v = v.masked_fill(key_padding_mask[..., None], 0.0)
-        v = v.view(B, Nk, H, C // H)
-        off = ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias)
-        aw = ops.linear(query, self.attention_weights.weight, self.attention_weights.bias).view(B, Nq, H, L * P)
-        if reference_points.shape[-1] not in (2, 4):
-            raise ValueError(f'Last dim of reference_points must be 2 or 4, got {reference_points.shape[-1]}')
-        # softmax over the L*P weights and loc = ref + off / (W_l, H_l)  [2-d]  |  ref_xy + off / P * ref_wh * 0.5  [4-d]
-        loc, aw = ops.msda_prep(off, aw, reference_points, offset_norm, L, P)
-        out = ops.msda(v, spatial_shapes, level_start_index, loc, aw)
-        return ops.linear(out, self.output_proj.weight, self.output_proj.bias, resid=identity)  # + identity in the epilogue
+        # projections, softmax / location arithmetic, sampling kernel, output projection + identity: one autograd node
+        # (ops._MSDAAttn); `value is None` / `value is query` = self-attention over the token map
+        return ops.msda_attention(
+            query, query_pos, value, identity, key_padding_mask, reference_points, spatial_shapes, level_start_index,
+            offset_norm, self.num_heads, self.num_levels, self.num_points,
+            self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
+            self.attention_weights.bias, self.value_proj.weight, self.value_proj.bias, self.output_proj.weight,
+            self.output_proj.bias)
 
 
 @MODELS.register_module()
@@ -206,17 +195,12 @@ class MultiheadAttention(nn.Module):
             identity = query
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
-        same_qk = key is query and key_pos is query_pos
-        if query_pos is not None:
-            query = query + query_pos
-        if same_qk:
-            key = query  # self-attention: one positional add serves both
-        elif key_pos is not None:
-            key = key + key_pos
         a = self.attn
         mode = kwargs.get('attn_mask_mode')
+        # the positional adds, the projections, the attention core, the output projection and the identity are one autograd
+        # node (ops._MHA): what meets at `query` in backward is merged in GEMM epilogues
         return ops.mha(query, key, value, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                       self.num_heads, attn_mask, identity=identity, mask_mode=mode)
+                       self.num_heads, attn_mask, identity=identity, mask_mode=mode, q_pos=query_pos, k_pos=key_pos)
 
 
 @MODELS.register_module()

@@ -179,6 +179,43 @@ def _msda_host_shapes(spatial_shapes):
     return a
 
 
+def _msda_fwd_raw(value, spatial_shapes, level_start_index, loc, attn):
+    B, Nk, H, D = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
+    # algorithmic bytes: read value + loc + attn, write out
+    nbytes = 4 * B * (Nk * H * D + Nq * H * L * P * 3 + Nq * H * D)
+    with _Prof('msda_fwd', nbytes):
+        lib.call('rscotr_msda_fwd', value.data_ptr(), spatial_shapes.data_ptr(),
+                 level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+                 B, Nk, Nq, H, D, L, P, _stream())
+    return out
+
+
+def _msda_bwd_raw(value, spatial_shapes, level_start_index, loc, attn, grad_out):
+    B, Nk, H, D = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    hs, hs_ptr, nws = None, 0, 0
+    if MSDA_BWD_STRATEGY != 'scatter':
+        nws = lib.rscotr_msda_bwd_workspace(B, Nk, Nq, H, L, P)
+        if MSDA_BWD_STRATEGY == 'tiled':
+            hs = _msda_host_shapes(spatial_shapes)
+            hs_ptr = hs.ctypes.data
+            nws = max(nws, lib.rscotr_msda_bwd_tiled_workspace(hs_ptr, B, Nk, Nq, H, D, L, P))
+    ws = _WS.get(nws, value.device) if nws else None
+    grad_value = torch.zeros_like(value) if ws is None else torch.empty_like(value)
+    grad_loc = torch.empty_like(loc)
+    grad_attn = torch.empty_like(attn)
+    # algorithmic bytes: read value, RMW grad_value, read loc/attn/grad_out, write grad_loc/attn
+    nbytes = 4 * B * (3 * Nk * H * D + Nq * H * L * P * 3 + Nq * H * D + Nq * H * L * P * 3)
+    with _Prof('msda_bwd', nbytes):
+        lib.call('rscotr_msda_bwd', value.data_ptr(), spatial_shapes.data_ptr(),
+                 level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
+                 grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                 B, Nk, Nq, H, D, L, P, hs_ptr, 0 if ws is None else ws.data_ptr(), nws, _stream())
+    return grad_value, grad_loc, grad_attn
+
+
 class _MSDA(Function):
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, loc, attn):
@@ -187,42 +224,14 @@ class _MSDA(Function):
         level_start_index = level_start_index.contiguous()
         _chk(value, spatial_shapes, level_start_index, loc, attn)
         assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
-        B, Nk, H, D = value.shape
-        _, Nq, _, L, P, _ = loc.shape
-        out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
-        # algorithmic bytes: read value + loc + attn, write out
-        nbytes = 4 * B * (Nk * H * D + Nq * H * L * P * 3 + Nq * H * D)
-        with _Prof('msda_fwd', nbytes):
-            lib.call('rscotr_msda_fwd', value.data_ptr(), spatial_shapes.data_ptr(),
-                     level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
-                     B, Nk, Nq, H, D, L, P, _stream())
+        out = _msda_fwd_raw(value, spatial_shapes, level_start_index, loc, attn)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attn)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         value, spatial_shapes, level_start_index, loc, attn = ctx.saved_tensors
-        grad_out = _f32c(grad_out)
-        B, Nk, H, D = value.shape
-        _, Nq, _, L, P, _ = loc.shape
-        hs, hs_ptr, nws = None, 0, 0
-        if MSDA_BWD_STRATEGY != 'scatter':
-            nws = lib.rscotr_msda_bwd_workspace(B, Nk, Nq, H, L, P)
-            if MSDA_BWD_STRATEGY == 'tiled':
-                hs = _msda_host_shapes(spatial_shapes)
-                hs_ptr = hs.ctypes.data
-                nws = max(nws, lib.rscotr_msda_bwd_tiled_workspace(hs_ptr, B, Nk, Nq, H, D, L, P))
-        ws = _WS.get(nws, value.device) if nws else None
-        grad_value = torch.zeros_like(value) if ws is None else torch.empty_like(value)
-        grad_loc = torch.empty_like(loc)
-        grad_attn = torch.empty_like(attn)
-        # algorithmic bytes: read value, RMW grad_value, read loc/attn/grad_out, write grad_loc/attn
-        nbytes = 4 * B * (3 * Nk * H * D + Nq * H * L * P * 3 + Nq * H * D + Nq * H * L * P * 3)
-        with _Prof('msda_bwd', nbytes):
-            lib.call('rscotr_msda_bwd', value.data_ptr(), spatial_shapes.data_ptr(),
-                     level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
-                     grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                     B, Nk, Nq, H, D, L, P, hs_ptr, 0 if ws is None else ws.data_ptr(), nws, _stream())
+        grad_value, grad_loc, grad_attn = _msda_bwd_raw(value, spatial_shapes, level_start_index, loc, attn, _f32c(grad_out))
         return grad_value, None, None, grad_loc, grad_attn
 
 
@@ -233,30 +242,38 @@ def msda(value, spatial_shapes, level_start_index, loc, attn):
     return _MSDA.apply(value, spatial_shapes, level_start_index, loc, attn)
 
 
+def _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P):
+    refdim = ref.shape[-1]
+    loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=off.device)
+    attn = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=off.device)
+    lib.call('rscotr_msda_prep_fwd', off.data_ptr(), logit.data_ptr(), ref.data_ptr(), _ptr(norm), loc.data_ptr(),
+             attn.data_ptr(), B, Nq, H, L, P, refdim, _stream())
+    return loc, attn
+
+
+def _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P):
+    goff = torch.empty((B, Nq, H, L * P * 2), dtype=torch.float32, device=attn.device)
+    glogit = torch.empty((B, Nq, H, L * P), dtype=torch.float32, device=attn.device)
+    lib.call('rscotr_msda_prep_bwd', gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), ref.data_ptr(), _ptr(norm),
+             goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, ref.shape[-1], _stream())
+    return goff, glogit
+
+
 class _MSDAPrep(Function):
     @staticmethod
     def forward(ctx, off, logit, ref, norm, L, P):
         off, logit, ref = _f32c(off), _f32c(logit), _f32c(ref.detach())
         _chk(off, logit, ref, norm)
         B, Nq, H = logit.shape[:3]
-        refdim = ref.shape[-1]
-        loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=off.device)
-        attn = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=off.device)
-        lib.call('rscotr_msda_prep_fwd', off.data_ptr(), logit.data_ptr(), ref.data_ptr(), _ptr(norm), loc.data_ptr(),
-                 attn.data_ptr(), B, Nq, H, L, P, refdim, _stream())
+        loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
         ctx.save_for_backward(attn, ref, norm)
-        ctx.geom = (B, Nq, H, L, P, refdim)
+        ctx.geom = (B, Nq, H, L, P)
         return loc, attn
 
     @staticmethod
     def backward(ctx, gloc, gattn):
         attn, ref, norm = ctx.saved_tensors
-        B, Nq, H, L, P, refdim = ctx.geom
-        gloc, gattn = _f32c(gloc), _f32c(gattn)
-        goff = torch.empty((B, Nq, H, L * P * 2), dtype=torch.float32, device=attn.device)
-        glogit = torch.empty((B, Nq, H, L * P), dtype=torch.float32, device=attn.device)
-        lib.call('rscotr_msda_prep_bwd', gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), ref.data_ptr(), _ptr(norm),
-                 goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, refdim, _stream())
+        goff, glogit = _msda_prep_bwd_raw(_f32c(gloc), _f32c(gattn), attn, ref, norm, *ctx.geom)
         return goff, glogit, None, None, None, None
 
 
@@ -552,12 +569,13 @@ def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
 
 def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=ACT_NONE, aux=None, pre=None,
          resid=None, accumulate=False, rowsum=None, rowsum_accumulate=False, rowscale=None, rows_per=0, kscale=None,
-         krows_per=0):
+         krows_per=0, out2=None):
     """C[m,n] = epilogue(sum_k Aop[m,k] Bop[n,k]) on the fp32 matrix cores (include/rscotr.h,
     rscotr_gemm_f32).  A, B, out are contiguous fp32 device tensors; out (M,N) is allocated here
     unless given.  `rowsum` (M,) (+)= sum_k Aop[m,k] (k-major A only: the bias gradient riding the dW
-    contraction).  Returns out."""
-    _chk(A, B, out, bias, aux, pre, resid, rowsum)
+    contraction).  `out2` (M,N): second output out + resid, `out` itself then stays without the residual.
+    Returns out."""
+    _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     key = (M, N, K, lib.rscotr_gemm_get_precision())  # the workspace a shape wants depends on the precision mode
@@ -571,7 +589,8 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     ws = _WS.get(nws, A.device).data_ptr() if nws else 0
     args = (A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, int(a_kmajor), int(b_kmajor),
             _ptr(bias), int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowsum),
-            int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), ws, nws, _stream())
+            int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), _ptr(out2), ws, nws,
+            _stream())
     if PROFILE is None:
         lib.call('rscotr_gemm_f32', *args)
     else:
@@ -1009,25 +1028,190 @@ def gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, nb0, nb1, 
 MASK_NONE, MASK_SHARED, MASK_PER_IMAGE, MASK_PER_HEAD = 0, 1, 2, 3
 
 
-class _MHA(Function):
-    """torch.nn.MultiheadAttention (batch-first) + the identity add of mmcv's wrapper, forward and backward,
-    entirely on the C ABI: in-proj GEMMs (bias fused), per-head q k^T and P v on the batched GEMM with the
-    (B, L, heads*hd) tensors addressed in place (no head transposes), masked softmax / its backward in
-    place, out-proj GEMM with bias + identity fused; backward = the transposed contractions, parameter
-    gradients accumulated straight into the arena (packed in_proj rows addressed as sub-blocks)."""
+def _linear_param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b):
+    """Parameter gradients of y = x W^T + b from A = dy (K rows, M columns as the k-major operand) and Bm = x:
+    dW[row0:row0+M] (+)= A^T Bm, db[row0:row0+M] (+)= column sums of A (riding the dW contraction); straight into the
+    gradient arena when the parameter is sunk (then nothing is returned for it).  Returns (gw, gb, sink_w, sink_b)."""
+    dev = A.device
+    skw = _sink(w_handle) if want_w else None
+    skb = _sink(b_handle) if want_b else None
+    gw = gb = None
+    rs, rs_acc = None, False
+    if want_b:
+        if skb is not None:
+            rs, rs_acc = skb[1][row0:row0 + M], True
+        else:
+            rs = gb = torch.empty(M, dtype=torch.float32, device=dev)
+    if want_w:
+        if skw is not None and (skb is not None or not want_b):
+            _off_path(lambda: gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True,
+                                   rowsum=rs, rowsum_accumulate=rs_acc), A, Bm)
+        elif skw is not None:
+            gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True, rowsum=rs,
+                 rowsum_accumulate=rs_acc)
+        else:
+            gw = gemm(A, Bm, M, N, K, M, N, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc)
+    elif want_b:
+        colsum(A, K, M, out=rs, accumulate=rs_acc)
+    return gw, gb, skw, skb
+
+
+class _MSDAAttn(Function):
+    """mmcv MultiScaleDeformableAttention.forward as ONE autograd node: q = x + query_pos, value / offset /
+    weight projections, softmax + location arithmetic, the sampling kernel, output projection + identity — and a backward
+    that MERGES the gradients meeting at the block input inside GEMM epilogues instead of leaving them to autograd's
+    element-wise adds: d(x) = d(offsets) W_off + d(weights) W_aw [+ dy when x is the identity] [+ d(value) W_v when x is
+    the value]; d(query_pos) is the same product without the merged terms (second output of the epilogue).
+    args: x (B,Nq,C), q_pos (B,Nq,C)|None, value_in (B,Nk,C)|None (= x), identity Tensor|None (may be x), key_padding_mask
+    (B,Nk) bool|None, reference_points (no gradient), spatial_shapes, level_start_index, offset_norm, heads, L, P, then
+    W/b of sampling_offsets, attention_weights, value_proj, output_proj."""
 
     @staticmethod
-    def forward(ctx, q_in, k_in, v_in, in_w, in_b, out_w, out_b, identity, heads, mask, mask_mode):
-        B, Lq, C = q_in.shape
-        Lk = k_in.shape[1]
+    def forward(ctx, x, q_pos, value_in, identity, kpm, ref, spatial_shapes, lsi, norm, heads, L, P,
+                w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+        B, Nq, C = x.shape
+        H, D = heads, C // heads
+        M = B * Nq
+        x2 = _f32c(x).reshape(M, C)
+        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos)).reshape(M, C)
+        v_is_x = value_in is None or value_in is x
+        id_is_x = identity is x
+        val2 = x2 if v_is_x else _f32c(value_in).reshape(-1, C)
+        Mk = val2.shape[0]
+        Nk = Mk // B
+        ws = [w if w.is_contiguous() else w.contiguous() for w in (w_off, w_aw, w_v, w_o)]
+        ref = _f32c(ref.detach())
+        spatial_shapes, lsi = spatial_shapes.contiguous(), lsi.contiguous()
+        _chk(x2, q2, val2, ref, spatial_shapes, lsi, norm)
+        v = gemm(val2, ws[2], Mk, C, C, C, C, 0, 0, bias=b_v)
+        if kpm is not None:
+            v.view(B, Nk, C).masked_fill_(kpm[..., None], 0.0)
+        n_off, n_aw = H * L * P * 2, H * L * P
+        off = gemm(q2, ws[0], M, n_off, C, C, C, 0, 0, bias=b_off)
+        logit = gemm(q2, ws[1], M, n_aw, C, C, C, 0, 0, bias=b_aw)
+        loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
+        out = _msda_fwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn)
+        id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(M, C))
+        y = gemm(out.view(M, C), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2)
+        ctx.save_for_backward(q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, *ws)
+        ctx.kpm = kpm
+        ctx.params = (w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)  # handles for the gradient sink
+        ctx.geom = (B, Nq, Nk, C, H, D, L, P)
+        ctx.flags = (v_is_x, id_is_x, q_pos is not None, identity is not None)
+        ctx.shapes = (x.shape, None if q_pos is None else q_pos.shape, None if value_in is None else value_in.shape,
+                      None if identity is None else identity.shape)
+        return y.view(B, Nq, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, w_off, w_aw, w_v, w_o = ctx.saved_tensors
+        p_off, pb_off, p_aw, pb_aw, p_v, pb_v, p_o, pb_o = ctx.params
+        B, Nq, Nk, C, H, D, L, P = ctx.geom
+        v_is_x, id_is_x, has_pos, has_id = ctx.flags
+        need = ctx.needs_input_grad
+        M, Mk = B * Nq, B * Nk
+        n_off, n_aw = H * L * P * 2, H * L * P
+        g = _f32c(dy).reshape(M, C)
+        sinks = []
+        # output projection
+        gw_o, gb_o, s1, s2 = _linear_param_grad(g, out.view(M, C), C, C, M, p_o, pb_o, 0, need[18], pb_o is not None and need[19])
+        sinks += [s1, s2]
+        d_out = gemm(g, w_o, M, C, C, C, C, 0, 1)
+        # sampling kernel and the location / softmax arithmetic
+        gv, gloc, gattn = _msda_bwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn, d_out.view(B, Nq, C))
+        goff, glogit = _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P)
+        goff, glogit, gv = goff.view(M, n_off), glogit.view(M, n_aw), gv.view(Mk, C)
+        if ctx.kpm is not None:
+            gv.view(B, Nk, C).masked_fill_(ctx.kpm[..., None], 0.0)
+        gw_off, gb_off, s1, s2 = _linear_param_grad(goff, q2, n_off, C, M, p_off, pb_off, 0, need[12], pb_off is not None and need[13])
+        sinks += [s1, s2]
+        gw_aw, gb_aw, s1, s2 = _linear_param_grad(glogit, q2, n_aw, C, M, p_aw, pb_aw, 0, need[14], pb_aw is not None and need[15])
+        sinks += [s1, s2]
+        gw_v, gb_v, s1, s2 = _linear_param_grad(gv, val2, C, C, Mk, p_v, pb_v, 0, need[16], pb_v is not None and need[17])
+        sinks += [s1, s2]
+        for sk_ in sinks:
+            if sk_ is not None:
+                GRAD_SINK.grad_written(sk_[0])
+        # input gradients, merged in the epilogues
+        want_pos = has_pos and need[1]
+        want_x = need[0]
+        want_val = (not v_is_x) and need[2]
+        d_x = d_pos = d_val = None
+        merge_id = id_is_x and want_x
+        if want_x or want_pos:
+            pure = gemm(goff, w_off, M, C, n_off, n_off, C, 0, 1)
+            if want_pos and want_x and (merge_id or v_is_x):
+                d_x = torch.empty_like(pure)  # pure = d(query_pos); d_x = pure (+ dy) (+ d(value) below)
+                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True, out2=d_x,
+                     resid=g if merge_id else None)
+                d_pos = pure
+            else:
+                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True,
+                     resid=g if (merge_id and not want_pos) else None)
+                d_x = pure if want_x else None
+                d_pos = pure if want_pos else None
+            if v_is_x and want_x:
+                gemm(gv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
+        elif v_is_x and want_x:
+            d_x = gemm(gv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
+        if want_val:
+            d_val = gemm(gv, w_v, Mk, C, C, C, C, 0, 1).view(ctx.shapes[2])
+        d_id = g.view(ctx.shapes[3]) if (has_id and not merge_id and need[3]) else None
+        if id_is_x and not merge_id:
+            d_id = None
+        return (None if d_x is None else d_x.view(ctx.shapes[0]), None if d_pos is None else d_pos.view(ctx.shapes[1]),
+                d_val, d_id, None, None, None, None, None, None, None, None,
+                gw_off, gb_off, gw_aw, gb_aw, gw_v, gb_v, gw_o, gb_o)
+
+
+def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes, level_start_index,
+                   offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+    """The whole of mmcv MultiScaleDeformableAttention.forward on batch-first tensors (see _MSDAAttn); `value` None or x
+    itself = self-attention over the token map (encoder), `identity` None = no residual, x = the usual one."""
+    assert not reference_points.requires_grad, 'reference points are detached on this path'
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError(f'Last dim of reference_points must be 2 or 4, got {reference_points.shape[-1]}')
+    if q_pos is not None and q_pos.shape != x.shape:
+        q_pos = q_pos.expand_as(x)
+    return _MSDAAttn.apply(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes,
+                           level_start_index, offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)
+
+
+class _MHA(Function):
+    """torch.nn.MultiheadAttention (batch-first) + the positional adds and the identity add of mmcv's wrapper, forward and
+    backward, entirely on the C ABI: in-proj GEMMs (bias fused), per-head q k^T and P v on the batched GEMM with the
+    (B, L, heads*hd) tensors addressed in place (no head transposes), masked softmax / its backward in
+    place, out-proj GEMM with bias + identity fused; backward = the transposed contractions, parameter
+    gradients accumulated straight into the arena (packed in_proj rows addressed as sub-blocks), and the gradients that
+    meet at the block inputs merged inside GEMM epilogues (second epilogue output / accumulate) instead of by autograd's
+    element-wise adds.
+    args: x (B,Lq,C) query content, q_pos | None, kx (B,Lk,C) key content | None (= x: self-attention), k_pos | None (the
+    SAME object as q_pos in self-attention = one q|k projection), vx value content | None (= the key content), then the
+    packed parameters, identity (Tensor | None, may be x), heads, mask, mask_mode."""
+
+    @staticmethod
+    def forward(ctx, x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, mask, mask_mode):
+        B, Lq, C = x.shape
         hd = C // heads
-        dev = q_in.device
-        q2, k2, v2 = _f32c(q_in).reshape(B * Lq, C), _f32c(k_in).reshape(B * Lk, C), _f32c(v_in).reshape(B * Lk, C)
+        dev = x.device
+        self_attn = kx is None
+        x2 = _f32c(x).reshape(B * Lq, C)
+        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos)).reshape(B * Lq, C)
+        # self-attention with one positional embedding for both sides (query + pos feeds q and k): the q and k projections
+        # are one GEMM over the first 2C rows of the packed in_proj weight; q / k are then the column halves of one
+        # (B*L, 2C) tensor, addressed in place by the batched products (row stride 2C, element offset C for k)
+        fused = self_attn and (k_pos is q_pos)
+        if self_attn:
+            kx2 = x2
+            k2 = q2 if fused else (x2 if k_pos is None else _f32c(torch.add(x, k_pos)).reshape(B * Lq, C))
+        else:
+            kx2 = _f32c(kx).reshape(-1, C)
+            k2 = kx2 if k_pos is None else _f32c(torch.add(kx, k_pos)).reshape(-1, C)
+        Lk = k2.shape[0] // B
+        v_is_kx = vx is None or vx is (x if self_attn else kx)
+        v2 = kx2 if v_is_kx else _f32c(vx).reshape(B * Lk, C)
+        id_is_x = identity is x
         in_w, in_b = in_w.contiguous(), in_b.contiguous()
-        # self-attention (q_in IS k_in: query + pos feeds both): the q and k projections are one GEMM over the first
-        # 2C rows of the packed in_proj weight; q / k are then the column halves of one (B*L, 2C) tensor, addressed
-        # in place by the batched products (row stride 2C, element offset C for k)
-        fused = k_in is q_in
         ldq = 2 * C if fused else C
         if fused:
             q = k = gemm(q2, in_w[:2 * C], B * Lq, 2 * C, C, C, C, 0, 0, bias=in_b[:2 * C])
@@ -1046,13 +1230,15 @@ class _MHA(Function):
                  Lq, Lk, float(hd ** -0.5), _stream())
         o = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
         gemm_batched(P, v, o, Lq, hd, Lk, Lk, C, C, 0, 1, B, heads, sp, sk, sq, ksplit=True)
-        id2 = None if identity is None else _f32c(identity).reshape(B * Lq, C)
+        id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(B * Lq, C))
         y = gemm(o, out_w, B * Lq, C, C, C, C, 0, 0, bias=out_b, resid=id2)
         ctx.save_for_backward(q2, k2, v2, q, k, v, P, o, in_w, out_w)
         ctx.params = (in_w, in_b, out_w, out_b)  # handles for the gradient sink
         ctx.geom = (B, Lq, Lk, C, heads, hd)
-        ctx.fused = fused
-        ctx.shapes = (q_in.shape, k_in.shape, v_in.shape, None if identity is None else identity.shape)
+        ctx.flags = (fused, self_attn, v_is_kx, id_is_x, q_pos is not None, k_pos is not None, identity is not None)
+        ctx.shapes = (x.shape, None if q_pos is None else q_pos.shape, None if kx is None else kx.shape,
+                      None if k_pos is None else k_pos.shape, None if vx is None else vx.shape,
+                      None if identity is None else identity.shape)
         return y.view(B, Lq, C)
 
     @staticmethod
@@ -1060,37 +1246,14 @@ class _MHA(Function):
         q2, k2, v2, q, k, v, P, o, in_w, out_w = ctx.saved_tensors
         p_in_w, p_in_b, p_out_w, p_out_b = ctx.params
         B, Lq, Lk, C, heads, hd = ctx.geom
+        fused, self_attn, v_is_kx, id_is_x, has_qpos, has_kpos, has_id = ctx.flags
         dev = dy.device
         g = _f32c(dy).reshape(B * Lq, C)
-        need = ctx.needs_input_grad
+        need = ctx.needs_input_grad  # x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity
         sq, sk, sp = (Lq * C, hd), (Lk * C, hd), (heads * Lq * Lk, Lq * Lk)
 
-        def param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b):
-            """dW[row0:row0+M] (+)= A^T Bm, db[row0:row0+M] (+)= column sums of A; arena-direct when sunk."""
-            skw = _sink(w_handle) if want_w else None
-            skb = _sink(b_handle) if want_b else None
-            gw = gb = None
-            rs, rs_acc = None, False
-            if want_b:
-                if skb is not None:
-                    rs, rs_acc = skb[1][row0:row0 + M], True
-                else:
-                    rs = gb = torch.empty(M, dtype=torch.float32, device=dev)
-            if want_w:
-                if skw is not None and (skb is not None or not want_b):
-                    _off_path(lambda: gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True,
-                                           rowsum=rs, rowsum_accumulate=rs_acc), A, Bm)
-                elif skw is not None:
-                    gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True, rowsum=rs,
-                         rowsum_accumulate=rs_acc)
-                else:
-                    gw = gemm(A, Bm, M, N, K, M, N, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc)
-            elif want_b:
-                colsum(A, K, M, out=rs, accumulate=rs_acc)
-            return gw, gb, skw, skb
-
         # out projection
-        gw_o, gb_o, skw_o, skb_o = param_grad(g, o, C, C, B * Lq, p_out_w, p_out_b, 0, need[5], need[6])
+        gw_o, gb_o, skw_o, skb_o = _linear_param_grad(g, o, C, C, B * Lq, p_out_w, p_out_b, 0, need[7], need[8])
         do = gemm(g, out_w, B * Lq, C, C, C, C, 0, 1)
         # attention core
         dv = torch.empty((B * Lk, C), dtype=torch.float32, device=dev)
@@ -1098,7 +1261,6 @@ class _MHA(Function):
         dP = torch.empty_like(P)
         gemm_batched(do, v, dP, Lq, Lk, hd, C, C, Lk, 0, 0, B, heads, sq, sk, sp)                  # dP = dO V^T
         lib.call('rscotr_softmax_bwd', P.data_ptr(), dP.data_ptr(), B * heads * Lq, Lk, float(hd ** -0.5), _stream())
-        fused = ctx.fused
         ldq = 2 * C if fused else C
         sqp, skp = (Lq * ldq, hd), (Lk * ldq, hd)
         if fused:  # dq | dk as the column halves of one (B*L, 2C) tensor, like q | k
@@ -1112,7 +1274,7 @@ class _MHA(Function):
         gemm_batched(dP, k, dq, Lq, hd, Lk, Lk, ldq, ldq, 0, 1, B, heads, sp, skp, sqp, offB=koff, ksplit=True)  # dQ = dS K
         gemm_batched(dP, q, dk, Lk, hd, Lq, Lk, ldq, ldq, 1, 1, B, heads, sp, sqp, skp, offC=koff)  # dK = dS^T Q
         # in projections (packed (3C, C) weight / (3C) bias: three row blocks; q and k as one block when fused)
-        want_w, want_b = need[3], need[4]
+        want_w, want_b = need[5], need[6]
         sink_w = _sink(p_in_w) if want_w else None
         sink_b = _sink(p_in_b) if want_b else None
         gw_in = None if (not want_w or sink_w is not None) else torch.empty((3 * C, C), dtype=torch.float32, device=dev)
@@ -1132,31 +1294,107 @@ class _MHA(Function):
                     call()
             elif want_b:
                 colsum(dproj, M_, R, out=rs, accumulate=sink_b is not None)
-        if fused:  # d(q_in) + d(k_in) in one product over K = 2C (q_in is k_in: autograd would add the two)
-            dq_in = gemm(dq, in_w[:2 * C], B * Lq, C, 2 * C, 2 * C, C, 0, 1).view(ctx.shapes[0]) \
-                if (need[0] or need[1]) else None
-            dk_in = None
-        else:
-            dq_in = gemm(dq, in_w[:C], B * Lq, C, C, C, C, 0, 1).view(ctx.shapes[0]) if need[0] else None
-            dk_in = gemm(dk, in_w[C:2 * C], B * Lk, C, C, C, C, 0, 1).view(ctx.shapes[1]) if need[1] else None
-        dv_in = gemm(dv, in_w[2 * C:], B * Lk, C, C, C, C, 0, 1).view(ctx.shapes[2]) if need[2] else None
         for sk_ in (skw_o, skb_o, sink_w, sink_b):
             if sk_ is not None:
                 GRAD_SINK.grad_written(sk_[0])
-        d_id = g.view(ctx.shapes[3]) if (ctx.shapes[3] is not None and need[7]) else None
-        return dq_in, dk_in, dv_in, gw_in, gb_in, gw_o, gb_o, d_id, None, None, None
+
+        # ---- input gradients: what meets at x (and at the key content) is merged in the epilogues -----------------
+        Mq, Mk = B * Lq, B * Lk
+        w_q, w_k, w_v, w_qk = in_w[:C], in_w[C:2 * C], in_w[2 * C:], in_w[:2 * C]
+        want_x, want_qpos = need[0], has_qpos and need[1]
+        merge_id = id_is_x and want_x
+        d_x = d_qpos = d_kx = d_kpos = d_vx = None
+        if self_attn:
+            want_kpos = has_kpos and need[3] and not fused   # (fused: k_pos is q_pos, one gradient)
+            v_to_x = v_is_kx and want_x
+            if fused:
+                # d(q side) + d(k side) in one product over K = 2C (both reach x and the shared positional embedding)
+                if want_qpos and want_x and (merge_id or v_to_x):
+                    d_x = torch.empty((Mq, C), dtype=torch.float32, device=dev)
+                    d_qpos = gemm(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, out2=d_x, resid=g if merge_id else None)
+                elif want_x or want_qpos:
+                    pure = gemm(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, resid=g if (merge_id and not want_qpos) else None)
+                    d_x = pure if want_x else None
+                    d_qpos = pure if want_qpos else None
+            else:
+                dq_in = gemm(dq, w_q, Mq, C, C, C, C, 0, 1) if (want_x or want_qpos) else None
+                dk_in = gemm(dk, w_k, Mk, C, C, C, C, 0, 1) if (want_x or want_kpos) else None
+                d_qpos = dq_in if want_qpos else None
+                d_kpos = dk_in if want_kpos else None
+                if want_x:  # (rare on this path: distinct positional embeddings for the two sides)
+                    d_x = dq_in + dk_in
+                    if merge_id:
+                        d_x = d_x + g
+            if v_to_x:
+                if d_x is None:
+                    d_x = gemm(dv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
+                elif d_x is d_qpos or d_x is d_kpos:  # shared with a positional gradient: must not be modified
+                    d_x = gemm(dv, w_v, Mk, C, C, C, C, 0, 1, resid=d_x)
+                else:
+                    gemm(dv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
+            elif not v_is_kx and need[4]:
+                d_vx = gemm(dv, w_v, Mk, C, C, C, C, 0, 1)
+        else:
+            want_kx, want_kpos = need[2], has_kpos and need[3]
+            if want_x or want_qpos:
+                if want_qpos and merge_id:
+                    d_x = torch.empty((Mq, C), dtype=torch.float32, device=dev)
+                    d_qpos = gemm(dq, w_q, Mq, C, C, C, C, 0, 1, out2=d_x, resid=g)
+                else:
+                    pure = gemm(dq, w_q, Mq, C, C, C, C, 0, 1, resid=g if merge_id else None)
+                    d_x = pure if want_x else None
+                    d_qpos = pure if want_qpos else None
+            v_to_kx = v_is_kx and want_kx
+            dv_in = gemm(dv, w_v, Mk, C, C, C, C, 0, 1) if (v_to_kx or (not v_is_kx and need[4])) else None
+            if want_kx or want_kpos:
+                if want_kpos and v_to_kx:
+                    d_kx = torch.empty((Mk, C), dtype=torch.float32, device=dev)
+                    d_kpos = gemm(dk, w_k, Mk, C, C, C, C, 0, 1, out2=d_kx, resid=dv_in)
+                elif v_to_kx:
+                    d_kx = gemm(dk, w_k, Mk, C, C, C, C, 0, 1, out=dv_in, accumulate=True)
+                else:
+                    pure = gemm(dk, w_k, Mk, C, C, C, C, 0, 1)
+                    d_kx = pure if want_kx else None
+                    d_kpos = pure if want_kpos else None
+            elif v_to_kx:
+                d_kx = dv_in
+            if not v_is_kx and need[4]:
+                d_vx = dv_in
+        d_id = g if (has_id and not id_is_x and need[9]) else None
+        sh = ctx.shapes
+
+        def shaped(t, i):
+            return None if t is None else t.view(sh[i])
+        return (shaped(d_x, 0), shaped(d_qpos, 1), shaped(d_kx, 2), shaped(d_kpos, 3), shaped(d_vx, 4),
+                gw_in, gb_in, gw_o, gb_o, shaped(d_id, 5), None, None, None)
 
 
-def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None):
-    """torch.nn.MultiheadAttention semantics on batch-first tensors (+ `identity`, the residual mmcv's wrapper
-    adds): q_in (B,Lq,C), k_in/v_in (B,Lk,C); attn_mask bool, True = blocked: (Lq,Lk) shared, (B,Lq,Lk) per
-    image (mask_mode=MASK_PER_IMAGE) or (B*heads,Lq,Lk)."""
+def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None):
+    """torch.nn.MultiheadAttention semantics on batch-first tensors (+ the positional adds and the `identity` residual of
+    mmcv's wrapper): query = x + q_pos (B,Lq,C), key = kx + k_pos, value = vx (B,Lk,C); kx None or x itself =
+    self-attention (k_pos None then means q_pos), vx None = the key content; attn_mask bool, True = blocked: (Lq,Lk)
+    shared, (B,Lq,Lk) per image (mask_mode=MASK_PER_IMAGE) or (B*heads,Lq,Lk)."""
     if attn_mask is not None and mask_mode is None:
         if attn_mask.dim() == 2:
             mask_mode = MASK_SHARED
         else:
-            mask_mode = MASK_PER_IMAGE if attn_mask.shape[0] == q_in.shape[0] and heads > 1 else MASK_PER_HEAD
-    return _MHA.apply(q_in, k_in, v_in, in_w, in_b, out_w, out_b, identity, heads, attn_mask, mask_mode or 0)
+            mask_mode = MASK_PER_IMAGE if attn_mask.shape[0] == x.shape[0] and heads > 1 else MASK_PER_HEAD
+    same_pos = k_pos is q_pos
+    if q_pos is not None and q_pos.shape != x.shape:
+        q_pos = q_pos.expand_as(x)
+    if kx is x:
+        if vx is kx:
+            vx = None
+        kx = None
+        if k_pos is None:
+            same_pos = True
+    elif vx is kx:
+        vx = None
+    if same_pos and kx is None:
+        k_pos = q_pos
+    elif k_pos is not None and k_pos.shape != (x if kx is None else kx).shape:
+        k_pos = k_pos.expand_as(x if kx is None else kx)
+    return _MHA.apply(x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, attn_mask, mask_mode or 0)
 
 
 # ------------------------------------------------------------------------------------------

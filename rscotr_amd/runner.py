@@ -208,13 +208,15 @@ class GraphedTask:
 
 class IterBasedRunner:
     def __init__(self, model, optimizer, data_loader, lr_config=None, log_interval=0, logger=print,
-                 bucket_mb=32.0, rnd_fn=None, graph_tasks=None):
+                 bucket_mb=None, rnd_fn=None, graph_tasks=None):
         self.model, self.optimizer, self.data_loader = model, optimizer, data_loader
         self.iter = 0
         self.lr_updater = None
         if lr_config and lr_config.get('policy') == 'step':
             self.lr_updater = StepLrUpdater(**{k: v for k, v in lr_config.items() if k != 'policy'})
         self.log_interval, self.logger = log_interval, logger
+        if bucket_mb is None:  # gradient exchange granularity (MB of fp32 gradients per all-reduce)
+            bucket_mb = float(os.environ.get('RSCOTR_BUCKET_MB', 32.0))
         self.sync = GradSync(optimizer, bucket_mb) if is_dist() else None
         self.rnd_fn = rnd_fn
         # tasks whose iteration is replayed from a hipGraph (RSCOTR_GRAPHS=0 disables)

@@ -67,15 +67,14 @@ class MlvlSegPixelDecoder(nn.Module):
         # the reference passes an all-False padding mask: value.masked_fill is the identity
         memory = encoder(x, None, None, query_pos=pos, query_key_padding_mask=None, reference_points=ref,
                          **geom.kwargs())
-        outs = []
-        for i, (h, w) in enumerate(shapes):
-            s = geom.starts[i]
-            outs.append(ops.tokens_to_map(memory[:, s:s + h * w], (h, w)))  # channels-last views
+        # one split (its backward is ONE concatenation; slicing level by level costs a full-size zero-fill + copy per level
+        # and an add per level in backward)
+        levels = torch.split(memory, [h * w for h, w in shapes], dim=1)
+        outs = [ops.tokens_to_map(lv, hw) for lv, hw in zip(levels, shapes)]  # channels-last views
         multi_scale_features = outs[:self.num_outs]
         # 1x1 conv = MFMA GEMM on the tokens of the finest level
         h, w = shapes[-1]
-        mf = ops.linear(memory[:, geom.starts[-1]:geom.starts[-1] + h * w],
-                        self.mask_feature.weight.view(self.mask_feature.weight.shape[0], -1), self.mask_feature.bias)
+        mf = ops.linear(levels[-1], self.mask_feature.weight.view(self.mask_feature.weight.shape[0], -1), self.mask_feature.bias)
         mask_feature = ops.tokens_to_map(mf, (h, w))
         return mask_feature, multi_scale_features
 

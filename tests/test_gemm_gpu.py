@@ -58,6 +58,26 @@ def test_gemm_epilogues(cuda, act, M, N, K):
     assert _rel(out, ref) < 1e-5
     assert _rel(pre, pre_ref) < 1e-5
 
+@pytest.mark.parametrize('M,N,K,bk', [(200, 256, 256, 1), (1600, 256, 512, 1), (10880, 256, 384, 1), (10880, 256, 256, 0),
+                                      (400, 256, 2048, 1), (130, 77, 100, 1), (2048, 384, 1536, 1)])
+@pytest.mark.parametrize('acc', [False, True])
+@pytest.mark.parametrize('with_resid', [True, False])
+def test_gemm_second_output(cuda, M, N, K, bk, acc, with_resid):
+    """out2 of rscotr_gemm_f32: C = A B (+ old C) stays WITHOUT the residual, C2 = C + resid — on the small-product,
+    tiled, split-K and bf16x6 kernels (the merged input gradients of the attention blocks)."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn((K, N) if bk else (N, K), generator=g) * 0.1
+    resid, c0 = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ (B.double() if bk else B.double().t()) + (c0.double() if acc else 0.0)
+    out = c0.clone().to(cuda) if acc else None
+    out2 = torch.full((M, N), float('nan'), device=cuda)
+    out = ops.gemm(A.to(cuda), B.to(cuda), M, N, K, K, B.shape[1], 0, bk, out=out, accumulate=acc,
+                   resid=resid.to(cuda) if with_resid else None, out2=out2)
+    assert _rel(out, ref) < 1e-5
+    assert _rel(out2, ref + (resid.double() if with_resid else 0.0)) < 1e-5
+
 
 def test_gemm_splitk_matches_unsplit(cuda):
     """dW-shaped problem (small output, long reduction) takes the split-K path."""

@@ -64,6 +64,54 @@ def test_mha_matches_torch(cuda, B, Lq, Lk, mask_kind):
     for n, p in ref.named_parameters():
         assert _rel(P[n].grad, p.grad) < 1e-4, n
 
+@pytest.mark.parametrize('kind', ['self', 'self_const_pos', 'cross', 'cross_const_kpos', 'self_no_identity'])
+def test_mha_positional_inputs_and_merged_gradients(cuda, kind):
+    """The mmcv wrapper's positional adds and identity inside the node (ops.mha(x, kx, vx, ..., q_pos, k_pos, identity=x)):
+    output and the gradients of x, q_pos, the key content and k_pos — merged in GEMM epilogues, no element-wise adds —
+    against torch.nn.MultiheadAttention in fp64 with the adds written out."""
+    from rscotr_amd import ops
+    C, H, B, Lq, Lk = 256, 8, 2, 100, 320
+    g = torch.Generator().manual_seed(11)
+    ref = torch.nn.MultiheadAttention(C, H, 0.0).double()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).double() * 0.1)
+    self_attn = kind.startswith('self')
+    x, qp = torch.randn(B, Lq, C, generator=g), torch.randn(B, Lq, C, generator=g)
+    kx, kp = torch.randn(B, Lk, C, generator=g), torch.randn(B, Lk, C, generator=g)
+    gy = torch.randn(B, Lq, C, generator=g)
+    qp_grad = kind != 'self_const_pos'
+    kp_grad = kind == 'cross'
+    with_id = kind != 'self_no_identity'
+    xr, qpr, kxr, kpr = (t.double().clone().requires_grad_(True) for t in (x, qp, kx, kp))
+    qq = xr + qpr
+    kk, vv = (qq, xr) if self_attn else (kxr + kpr, kxr)
+    out_ref = ref(qq.transpose(0, 1), kk.transpose(0, 1), vv.transpose(0, 1))[0].transpose(0, 1)
+    if with_id:
+        out_ref = out_ref + xr
+    out_ref.backward(gy.double())
+    xd = x.to(cuda).requires_grad_(True)
+    qpd = qp.to(cuda).requires_grad_(qp_grad)
+    kxd = kx.to(cuda).requires_grad_(True)
+    kpd = kp.to(cuda).requires_grad_(kp_grad)
+    P = {n: p.detach().float().to(cuda).requires_grad_(True) for n, p in ref.named_parameters()}
+    w = (P['in_proj_weight'], P['in_proj_bias'], P['out_proj.weight'], P['out_proj.bias'])
+    if self_attn:
+        out = ops.mha(xd, xd, xd, *w, H, None, identity=xd if with_id else None, q_pos=qpd, k_pos=qpd)
+    else:
+        out = ops.mha(xd, kxd, kxd, *w, H, None, identity=xd, q_pos=qpd, k_pos=kpd)
+    out.backward(gy.to(cuda))
+    assert _rel(out, out_ref) < 1e-4
+    assert _rel(xd.grad, xr.grad) < 1e-4
+    if qp_grad:
+        assert _rel(qpd.grad, qpr.grad) < 1e-4
+    if not self_attn:
+        assert _rel(kxd.grad, kxr.grad) < 1e-4
+        if kp_grad:
+            assert _rel(kpd.grad, kpr.grad) < 1e-4
+    for n, p in ref.named_parameters():
+        assert _rel(P[n].grad, p.grad) < 1e-4, n
+
 
 def test_mask_logits_matches_einsum(cuda):
     """einsum('bqd,bdhw->bqhw') of the seg head on the batched MFMA GEMM (token layout), with both gradients."""

@@ -218,3 +218,49 @@ def test_msda_large_pyramids(cuda, bwd_strategy, shapes, expect):
     for s_, c_ in zip(res[bwd_strategy], res['scatter']):
         assert torch.isfinite(s_).all()
         _close(c_.cpu(), s_.cpu(), rtol=1e-4, atol=1e-4 * float(c_.abs().max()) + 1e-7)
+
+
+@pytest.mark.parametrize('kind', ['encoder', 'decoder', 'decoder_const_pos', 'plain'])
+def test_msda_attention_block_matches_composition(cuda, kind):
+    """ops.msda_attention (the whole mmcv MultiScaleDeformableAttention.forward as one node, gradients merged in GEMM
+    epilogues) against the composition of the single ops (linear / msda_prep / msda with autograd's own adds): output,
+    input and parameter gradients; then the composition itself is what tests/test_model_gpu.py holds to the oracle."""
+    from rscotr_amd import ops
+    torch.manual_seed(3)
+    B, H, L, P, C = 2, 8, 4, 4, 256
+    shapes = [(16, 16), (8, 8), (4, 4), (2, 2)]
+    Nk = sum(h * w for h, w in shapes)
+    Nq = Nk if kind == 'encoder' else 90
+    ss = torch.tensor(shapes, dtype=torch.int64, device=cuda)
+    lsi = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    norm = torch.stack([ss[:, 1], ss[:, 0]], -1).float()
+    refdim = 2 if kind == 'encoder' else 4
+    ref = torch.rand(B, Nq, L, refdim, device=cuda) * 0.8 + 0.1
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device=cuda) * sc)
+    W = dict(w_off=mk(H * L * P * 2, C, sc=0.02), b_off=mk(H * L * P * 2), w_aw=mk(H * L * P, C, sc=0.05), b_aw=mk(H * L * P, sc=0.1),
+             w_v=mk(C, C, sc=0.06), b_v=mk(C, sc=0.1), w_o=mk(C, C, sc=0.06), b_o=mk(C, sc=0.1))
+    x0, pos0, mem0, gy = mk(B, Nq, C), mk(B, Nq, C), mk(B, Nk, C), mk(B, Nq, C)
+    pos_grad = kind in ('encoder', 'decoder')
+    res = []
+    for fused in (False, True):
+        x, pos, mem = x0.clone().requires_grad_(True), pos0.clone().requires_grad_(pos_grad), mem0.clone().requires_grad_(True)
+        Wp = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+        value = x if kind == 'encoder' else mem
+        ident = None if kind == 'plain' else x
+        if fused:
+            y = ops.msda_attention(x, pos, value, ident, None, ref, ss, lsi, norm, H, L, P, Wp['w_off'], Wp['b_off'],
+                                   Wp['w_aw'], Wp['b_aw'], Wp['w_v'], Wp['b_v'], Wp['w_o'], Wp['b_o'])
+        else:
+            q = x + pos
+            v = ops.linear(value, Wp['w_v'], Wp['b_v']).view(B, Nk, H, C // H)
+            off = ops.linear(q, Wp['w_off'], Wp['b_off'])
+            aw = ops.linear(q, Wp['w_aw'], Wp['b_aw']).view(B, Nq, H, L * P)
+            loc, a = ops.msda_prep(off, aw, ref, norm, L, P)
+            y = ops.linear(ops.msda(v, ss, lsi, loc, a), Wp['w_o'], Wp['b_o'], resid=ident)
+        y.backward(gy)
+        res.append((y, x.grad, pos.grad if pos_grad else None, None if kind == 'encoder' else mem.grad,
+                    *[Wp[k].grad for k in sorted(Wp)]))
+    for a, b in zip(*res):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, (kind, float((a - b).abs().max()), float(a.abs().max()))
