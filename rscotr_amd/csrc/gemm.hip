@@ -1352,7 +1352,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;
   static const int gelu_ok = getenv("RSCOTR_BF16X6_GELU") ? atoi(getenv("RSCOTR_BF16X6_GELU")) : 1;
   static const int dw_ok = getenv("RSCOTR_BF16X6_DW") ? atoi(getenv("RSCOTR_BF16X6_DW")) : 1;
-  // Measured on the step (gpurun_out/r2t3_gemm_census_bf16x6.txt against profiles/r1_s7_gemm_census_fp32.txt): the split
+  // Measured on the step (profiles/r2_gemm_census.txt against profiles/history/r1_s7_gemm_census_fp32.txt): the split
   // product wins where the MFMA work dominates — the encoder FFN products (117 -> 85 us, 125 -> 100 us), their weight
   // gradients (124 -> 75 us), the 10880- / 2048-row products with K >= 256 (5-15 %) — and loses on small outputs (256 x 256
   // weight gradients: 22.6 -> 32.5 us: too few tiles to hide the staging), on K < 192 (conversion not amortised) and where
@@ -1997,7 +1997,7 @@ static GemmCfg choose_cfg(int M, int N, int K) {
     }
   }
   // Measured on MI355X over the step's shapes (scripts/tune_gemm.py, scripts/lab/gemm_lab.hip,
-  // profiles/r1_gemm_tuning.md): 64x64 tiles (8 resident workgroups per CU) win on nearly every shape;
+  // profiles/history/r1_gemm_tuning.md): 64x64 tiles (8 resident workgroups per CU) win on nearly every shape;
   // 128x64 wins on the wide, tall products of the encoder FFN (N >= 1024, >= 1360 tiles of 128x64).
   c.BM = 64; c.BN = 64;
   if (N <= 32) { c.BM = 128; c.BN = 32; }

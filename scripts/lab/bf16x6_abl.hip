@@ -261,7 +261,7 @@ struct Variant { const char* name; Kern k[4]; int bm, bn; };  // k[akm * 2 + bkm
 
 int main(int argc, char** argv) {
   const Variant vars[] = {VAR(128, 128, 6, 0), VAR(128, 128, 3, 0), VAR(64, 64, 6, 1), VAR(64, 64, 6, 0)};
-  // {M, N, K, a_kmajor, b_kmajor, fp32-pipe us (profiles/r1_s7_gemm_census_fp32.txt)}
+  // {M, N, K, a_kmajor, b_kmajor, fp32-pipe us (profiles/history/r1_s7_gemm_census_fp32.txt)}
   const int shapes[][6] = {{10880, 2048, 256, 0, 0, 117}, {10880, 256, 256, 0, 0, 23}, {10880, 256, 2048, 0, 0, 125}, {4096, 4096, 4096, 0, 0, 0}};
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);

@@ -331,7 +331,7 @@ int main(int argc, char** argv) {
   const Variant vars[] = {VAR(128, 128, 6, 0, 16), VAR(128, 128, 6, 2, 16), VAR(128, 128, 6, 2, 16), VAR(128, 128, 6, 12, 16), VAR(128, 128, 6, 13, 16),
                           VAR(128, 128, 6, 22, 16), VAR(128, 128, 6, 3, 16),
                           VAR(64, 64, 6, 1, 32), VAR(64, 64, 6, 12, 32), VAR(64, 64, 6, 22, 32), VAR(64, 64, 6, 3, 32), VAR(64, 64, 6, 13, 16)};
-  // {M, N, K, a_kmajor, b_kmajor, fp32-pipe us (profiles/r1_s7_gemm_census_fp32.txt)}
+  // {M, N, K, a_kmajor, b_kmajor, fp32-pipe us (profiles/history/r1_s7_gemm_census_fp32.txt)}
   const int shapes[][6] = {
       {10880, 2048, 256, 0, 0, 117}, {10880, 256, 2048, 0, 0, 125}, {10880, 256, 2048, 0, 1, 128}, {10880, 2048, 256, 0, 1, 125},
       {256, 2048, 10880, 1, 1, 124},  {10880, 256, 256, 0, 0, 23},   {10880, 256, 256, 0, 1, 24},
