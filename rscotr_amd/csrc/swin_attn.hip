@@ -774,6 +774,287 @@ __global__ __launch_bounds__(64) void swin_wattn_bwd_mfma_kernel(const float* __
   for (int t = lane; t < 3 * HD; t += 64) prow[WATTN_PBIAS + t] = sdB[t];
 }
 
+// =====================================================================================================
+// Four wavefronts per (window, head) item.  One wavefront per item (above) is a chain of ~280 dependent-latency MFMAs,
+// five LDS phases and a 49-step row softmax: ~50 us per item however few items there are (stages 3-4 have 600 items for
+// 1024 SIMDs).  Here the 256 threads of a workgroup share one item: each wavefront stages one of the four operand tiles,
+// owns one 32 x 32 tile of S, the softmax runs four lanes per row, and the backward products are spread as
+//   waves 0,1: dP rows 0-31 / 32-63 (kept in registers) -> dS for those rows -> dQ rows 0-31 / 32-63
+//   waves 2,3: dV rows 0-31 / 32-63                                          -> dK rows 0-31 / 32-63
+// so the MFMA chain of an item is 16 + 32 + 25 instead of 278 issues.  The relative-position-bias gradient is a GATHER
+// (thread t < 169 sums dS over the <= 49 (i, j) pairs of its table entry in fixed order, in a register across the items
+// of the workgroup) instead of ~64 LDS float atomics per lane and item, and the pad-token (qkv-bias) sums are per-lane
+// registers folded wave by wave at the end: no atomics at all, bit-reproducible.
+__device__ __forceinline__ void mma_rr1(f32x16& acc, const float* A, const float* B, int mi, int ni, int lane) {
+  const int fr = lane & 31, fk = lane >> 5;
+  const float* a = A + min(mi * 32 + fr, WN - 1) * LDT + fk;
+  const float* b = B + min(ni * 32 + fr, WN - 1) * LDT + fk;
+#pragma unroll
+  for (int kk = 0; kk < HD; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma_pt1(f32x16& acc, const float* SP, const float* T, int mi, int lane) {
+  const int fr = lane & 31, fk = lane >> 5;
+  const float* a = SP + min(mi * 32 + fr, WN) * LDP + fk;
+#pragma unroll 5
+  for (int kk = 0; kk < NPD; kk += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], T[min(kk + fk, WN - 1) * LDT + fr], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma_ptT1(f32x16& acc, const float* SP, const float* T, int mi, int lane) {
+  const int fr = lane & 31, fk = lane >> 5;
+  const int j = min(mi * 32 + fr, WN);
+#pragma unroll 5
+  for (int kk = 0; kk < NPD; kk += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SP[(kk + fk) * LDP + j], T[min(kk + fk, WN - 1) * LDT + fr], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store_scores1(const f32x16& acc, float* sP, const float* sT, const int* sLab, int shift,
+                                              int mi, int ni, int lane) {
+  const int fr = lane & 31;
+  const int j = ni * 32 + fr, jc = min(j, WN - 1);
+  const int jb = (6 - jc / WS) * 13 + (6 - jc % WS), jl = sLab[jc];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = mi * 32 + crow(r, lane);
+    if (i >= WN || j >= WN) continue;
+    const int ti = (i / WS) * 13 + i % WS;
+    sP[i * LDP + j] = acc[r] + sT[ti + jb] + ((shift > 0 && jl != sLab[i]) ? -100.0f : 0.f);
+  }
+}
+
+// softmax of the 49 rows of sP in place, four lanes per row (all 256 threads call it)
+__device__ __forceinline__ void softmax_rows4(float* sP, int tid) {
+  const int row = tid >> 2, q = tid & 3;
+  float* rowp = sP + min(row, WN - 1) * LDP;
+  float v[13];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < 13; ++u) {
+    const int j = q + 4 * u;
+    v[u] = j < WN ? rowp[j] : -3.0e38f;
+    m = fmaxf(m, v[u]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 13; ++u) {
+    v[u] = (q + 4 * u < WN) ? __expf(v[u] - m) : 0.f;
+    sum += v[u];
+  }
+  sum += __shfl_xor(sum, 1, 64);
+  sum += __shfl_xor(sum, 2, 64);
+  const float inv = 1.f / sum;
+  if (row < WN) {
+#pragma unroll
+    for (int u = 0; u < 13; ++u)
+      if (q + 4 * u < WN) rowp[q + 4 * u] = v[u] * inv;
+  }
+}
+
+// wave w stages operand tile w of the item (0: q * scale, 1: k, 2: v, 3: dO when `dout` is given)
+__device__ __forceinline__ void stage_item_tiles(float* sQ, float* sK, float* sV, float* sG, const float* base,
+                                                 const float* __restrict__ qkv_b, const float* dout_b, const WinGeom& g,
+                                                 int head, const int* sTok, float scale, int w, int lane) {
+  if (w == 3 && !dout_b) return;
+  const float* src = w == 3 ? dout_b : base + w * g.C;
+  const long tstride = w == 3 ? g.C : 3 * g.C;
+  const float* padv = (w == 3 || !qkv_b) ? nullptr : qkv_b + w * g.C + head * HD;
+  float* dst = w == 0 ? sQ : (w == 1 ? sK : (w == 2 ? sV : sG));
+  TileRegs r;
+  tile_load(r, src, tstride, padv, sTok, lane);
+  tile_store(r, dst, w == 0 ? scale : 1.f, lane);
+}
+
+__global__ __launch_bounds__(256) void swin_wattn_fwd_mfma4_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ qkv_b,
+                                                                   const float* __restrict__ table,
+                                                                   float* __restrict__ out, WinGeom g, int B) {
+  __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT];
+  __shared__ float sP[NPD * LDP];
+  __shared__ float sT[TBL];
+  __shared__ int sLab[WN], sTok[WN];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int head = blockIdx.x % g.heads;
+  const int stride = gridDim.x / g.heads;
+  const float scale = 0.17677669529663687f;
+  const long L = (long)g.H * g.W;
+  for (int t = tid; t < TBL; t += 256) sT[t] = table[t * g.heads + head];
+  for (int t = tid; t < NPD * LDP; t += 256) sP[t] = 0.f;  // the padding row / column stay zero
+  for (int bw = blockIdx.x / g.heads; bw < B * g.nW; bw += stride) {
+    const int b = bw / g.nW, win = bw % g.nW, wy = win / g.nWw, wx = win % g.nWw;
+    __syncthreads();
+    if (tid < WN) {
+      const TokPos me = win_token(g, wy, wx, tid);
+      sLab[tid] = me.label;
+      sTok[tid] = me.pad ? -1 : (int)me.tok;
+    }
+    __syncthreads();
+    stage_item_tiles(sQ, sK, sV, nullptr, qkv + (long)b * L * 3 * g.C + head * HD, qkv_b, nullptr, g, head, sTok, scale, w, lane);
+    __syncthreads();
+    {
+      f32x16 a;
+      zero16(a);
+      mma_rr1(a, sQ, sK, w >> 1, w & 1, lane);
+      store_scores1(a, sP, sT, sLab, g.shift, w >> 1, w & 1, lane);
+    }
+    __syncthreads();
+    softmax_rows4(sP, tid);
+    __syncthreads();
+    if (w < 2) {  // O rows 32 w .. 32 w + 31
+      f32x16 o;
+      zero16(o);
+      mma_pt1(o, sP, sV, w, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = w * 32 + crow(r, lane);
+        if (i < WN) {
+          const int tok = sTok[i];
+          if (tok >= 0) out[((long)b * L + tok) * g.C + head * HD + (lane & 31)] = o[r];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ qkv_b,
+                                                                   const float* __restrict__ table,
+                                                                   const float* __restrict__ dout,
+                                                                   float* __restrict__ dqkv, float* __restrict__ part,
+                                                                   WinGeom g, int B) {
+  __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT], sG[WN * LDT];
+  __shared__ float sP[NPD * LDP];
+  __shared__ float sT[TBL];
+  __shared__ float sBw[4][3 * HD];
+  __shared__ int sLab[WN], sTok[WN];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 31;
+  const int head = blockIdx.x % g.heads;
+  const int stride = gridDim.x / g.heads;
+  const float scale = 0.17677669529663687f;
+  const long L = (long)g.H * g.W;
+  for (int t = tid; t < TBL; t += 256) sT[t] = table[t * g.heads + head];
+  for (int t = tid; t < NPD * LDP; t += 256) sP[t] = 0.f;
+  float dT = 0.f;                        // thread t < 169: gradient of table entry t over this workgroup's items
+  float accB[3] = {0.f, 0.f, 0.f};       // pad-token sums of this lane's rows: dq (waves 0,1), dk, dv (waves 2,3), column fr
+  const int tdy = tid / 13 - 6, tdx = tid % 13 - 6;
+  const int iy0 = max(0, tdy), iy1 = min(6, 6 + tdy), ix0 = max(0, tdx), ix1 = min(6, 6 + tdx);
+  for (int bw = blockIdx.x / g.heads; bw < B * g.nW; bw += stride) {
+    const int b = bw / g.nW, win = bw % g.nW, wy = win / g.nWw, wx = win % g.nWw;
+    __syncthreads();
+    if (tid < WN) {
+      const TokPos me = win_token(g, wy, wx, tid);
+      sLab[tid] = me.label;
+      sTok[tid] = me.pad ? -1 : (int)me.tok;
+    }
+    __syncthreads();
+    stage_item_tiles(sQ, sK, sV, sG, qkv + (long)b * L * 3 * g.C + head * HD, qkv_b, dout + (long)b * L * g.C + head * HD, g,
+                     head, sTok, scale, w, lane);
+    __syncthreads();
+    float* dq_base = dqkv + (long)b * L * 3 * g.C + head * HD;
+    {  // ---- 1. S tile (w >> 1, w & 1) -> sP
+      f32x16 a;
+      zero16(a);
+      mma_rr1(a, sQ, sK, w >> 1, w & 1, lane);
+      store_scores1(a, sP, sT, sLab, g.shift, w >> 1, w & 1, lane);
+    }
+    __syncthreads();
+    softmax_rows4(sP, tid);
+    __syncthreads();
+    // ---- 2. waves 0,1: dP rows of tile w (both column tiles, registers); waves 2,3: dV rows of tile w - 2
+    f32x16 dp[2];
+    if (w < 2) {
+      zero16(dp[0]); zero16(dp[1]);
+      mma_rr1(dp[0], sG, sV, w, 0, lane);
+      mma_rr1(dp[1], sG, sV, w, 1, lane);
+    } else {
+      f32x16 dv;
+      zero16(dv);
+      mma_ptT1(dv, sP, sG, w - 2, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (w - 2) * 32 + crow(r, lane);
+        if (j < WN) {
+          const int tok = sTok[j];
+          if (tok >= 0) dq_base[(long)tok * 3 * g.C + 2 * g.C + fr] = dv[r];
+          else accB[2] += dv[r];
+        }
+      }
+    }
+    __syncthreads();  // P has been consumed as an MFMA operand before the rows overwrite it with dS
+    if (w < 2) {      // ---- 3. delta_i = sum_j P_ij dP_ij, dS = P (dP - delta) -> sP
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = w * 32 + crow(r, lane);  // same row for the 32 lanes of a half-wave
+        const bool iv = i < WN;
+        const int j0 = fr, j1 = 32 + fr;
+        const float p0 = iv ? sP[i * LDP + j0] : 0.f;
+        const float p1 = (iv && j1 < WN) ? sP[i * LDP + j1] : 0.f;
+        const float delta = half_sum(p0 * dp[0][r] + p1 * dp[1][r]);
+        if (iv) {
+          sP[i * LDP + j0] = p0 * (dp[0][r] - delta);
+          if (j1 < WN) sP[i * LDP + j1] = p1 * (dp[1][r] - delta);
+        }
+      }
+    }
+    __syncthreads();
+    if (w < 2) {  // ---- 4. dQ = scale * dS K   (rows = query i)
+      f32x16 dq;
+      zero16(dq);
+      mma_pt1(dq, sP, sK, w, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = w * 32 + crow(r, lane);
+        if (i < WN) {
+          const int tok = sTok[i];
+          if (tok >= 0) dq_base[(long)tok * 3 * g.C + fr] = dq[r] * scale;
+          else accB[0] += dq[r] * scale;
+        }
+      }
+    } else {      // ---- 5. dK = dS^T (q * scale)   (rows = key j; sQ already holds q * scale)
+      f32x16 dk;
+      zero16(dk);
+      mma_ptT1(dk, sP, sQ, w - 2, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (w - 2) * 32 + crow(r, lane);
+        if (j < WN) {
+          const int tok = sTok[j];
+          if (tok >= 0) dq_base[(long)tok * 3 * g.C + g.C + fr] = dk[r];
+          else accB[1] += dk[r];
+        }
+      }
+    }
+    if (tid < TBL) {  // bias-table gradient: entry (dy, dx) = sum of dS over the pairs i - j = (dy, dx), fixed order
+      // (constant trip counts + predicates: the 49 LDS reads are issued together instead of one dependent read per add)
+      float part7[WS];
+#pragma unroll
+      for (int iy = 0; iy < WS; ++iy) {
+        float v[WS];
+#pragma unroll
+        for (int ix = 0; ix < WS; ++ix) {
+          const bool ok = iy >= iy0 && iy <= iy1 && ix >= ix0 && ix <= ix1;
+          v[ix] = ok ? sP[(iy * WS + ix) * LDP + (iy - tdy) * WS + (ix - tdx)] : 0.f;
+        }
+        part7[iy] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
+      }
+      dT += ((part7[0] + part7[1]) + (part7[2] + part7[3])) + ((part7[4] + part7[5]) + part7[6]);
+    }
+  }
+  // this workgroup's share of the bias-table / pad-token (qkv-bias) gradients: one partial row, folded over the
+  // workgroups of the head in fixed order by wattn_param_fold_kernel
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float other = __shfl_xor(accB[k], 32, 64);
+    if (lane < 32) sBw[w][k * HD + fr] = accB[k] + other;
+  }
+  __syncthreads();
+  float* prow = part + (long)blockIdx.x * WATTN_PROW;
+  if (tid < TBL) prow[tid] = dT;
+  if (tid < 3 * HD) prow[WATTN_PBIAS + tid] = ((sBw[0][tid] + sBw[1][tid]) + sBw[2][tid]) + sBw[3][tid];
+}
+
 static int wattn_geom(const char* fn, WinGeom* g, int B, int H, int W, int C, int heads, int ws, int shift) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0)
     return fail(RSCOTR_E_SHAPE, "%s: bad shape B=%d H=%d W=%d C=%d heads=%d", fn, B, H, W, C, heads);
@@ -811,11 +1092,13 @@ extern "C" int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, co
   // resident workgroups per CU) and wins when there are more items than resident wavefronts (stages 1-2: 45 vs 47 us,
   // 25 vs 31 us); the matrix-core kernel has the shorter per-item chain (stages 3-4: 16.5 vs 21 us).
   static const int force = getenv("RSCOTR_WATTN_IMPL") ? atoi(getenv("RSCOTR_WATTN_IMPL")) : -1;  // 0 VALU, 1 MFMA
-  const int impl = force >= 0 ? force : ((long)B * g.nW * heads <= 1024 ? 1 : 0);
+  const int impl = force >= 0 ? force : 2;  // 2: four wavefronts per item
   if (impl == 0)
     swin_wattn_fwd_kernel<<<wattn_grid(g, B, 8), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
-  else
+  else if (impl == 1)
     swin_wattn_fwd_mfma_kernel<<<wattn_grid(g, B, 4), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
+  else
+    swin_wattn_fwd_mfma4_kernel<<<wattn_grid(g, B, 4), 256, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
   return check_launch("rscotr_swin_wattn_fwd");
 }
 
@@ -870,12 +1153,14 @@ extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, co
   if (!workspace || workspace_bytes < (int64_t)nwg * WATTN_PROW * 4)
     return fail(RSCOTR_E_ARG, "rscotr_swin_wattn_bwd: workspace of rscotr_swin_wattn_bwd_workspace() bytes required");
   static const int phases = getenv("RSCOTR_WATTN_PHASES") ? atoi(getenv("RSCOTR_WATTN_PHASES")) : 4;
-  static const int impl = getenv("RSCOTR_WATTN_BWD_IMPL") ? atoi(getenv("RSCOTR_WATTN_BWD_IMPL")) : 1;  // 0 VALU, 1 MFMA
+  static const int impl = getenv("RSCOTR_WATTN_BWD_IMPL") ? atoi(getenv("RSCOTR_WATTN_BWD_IMPL")) : 2;  // 0 VALU, 1 MFMA, 2 MFMA x 4 waves
   hipStream_t s = (hipStream_t)stream;
   if (impl == 0)
     swin_wattn_bwd_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B, phases);
-  else
+  else if (impl == 1)
     swin_wattn_bwd_mfma_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B);
+  else
+    swin_wattn_bwd_mfma4_kernel<<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B);
   if (dbias_table || dqkv_bias)
     wattn_param_fold_kernel<<<dim3((WATTN_PROW + 63) / 64, heads), 256, 0, s>>>(workspace, dbias_table, dqkv_bias, heads, C,
                                                                               nwg / heads);
