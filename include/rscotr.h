@@ -213,13 +213,21 @@ int rscotr_layernorm_flush(const int64_t* table, const int32_t* wgmap, int nwg, 
  * Backward recomputes the probabilities; dqkv (B, H*W, 3C) is fully overwritten; dqkv_bias (3C, pad-token
  * contributions only) and dbias_table (169, heads) are ACCUMULATED (caller zeroes); either may be NULL.  workspace:
  * rscotr_swin_wattn_bwd_workspace() bytes of per-workgroup partial rows of those two gradients, folded in fixed order
- * by a second launch (no global atomics: bit-reproducible). */
+ * by a second launch (no global atomics: bit-reproducible).  With BOTH gradient pointers NULL the partial rows simply
+ * stay in `workspace` (then caller-owned) and rscotr_swin_wattn_flush folds the rows of many backward passes in one
+ * launch.  `out` (may be NULL): the forward output of the same inputs; with it the softmax backward's
+ * delta_i = sum_j P_ij dP_ij is taken as dO_i . O_i (a 32-channel dot product) instead of a cross-lane reduction.
+ * Default kernels: four wavefronts per (window, head) item, matrix cores for the five 49x49x32 products. */
 int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
                           int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
 int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, int heads);
 int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* dout,
                           float* dqkv, float* dqkv_bias, float* dbias_table, int B, int H, int W, int C,
-                          int heads, int ws, int shift, float* workspace, int64_t workspace_bytes, void* stream);
+                          int heads, int ws, int shift, const float* out, float* workspace,
+                          int64_t workspace_bytes, void* stream);
+/* table: device (n, 16) int64 rows {partial rows, dbias_table | 0, dqkv_bias | 0, heads, C, rows per head (= workspace bytes
+ * / (heads * 268 * 4)), running sum of `heads` over the previous rows, 0 ...}; total_heads = sum of heads. */
+int rscotr_swin_wattn_flush(const int64_t* table, int n, int total_heads, void* stream);
 
 /* ---- ChannelMapper neck in token layout -----------------------------------------------------------
  * mmdet ChannelMapper (configs/multi/MTL_slvlcls_...potsdam.py:26-33; models/multi/multitask_learner.py:84):

@@ -918,16 +918,18 @@ __global__ __launch_bounds__(256) void swin_wattn_fwd_mfma4_kernel(const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* __restrict__ qkv,
+__device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restrict__ qkv,
                                                                    const float* __restrict__ qkv_b,
                                                                    const float* __restrict__ table,
                                                                    const float* __restrict__ dout,
+                                                                   const float* __restrict__ outp,
                                                                    float* __restrict__ dqkv, float* __restrict__ part,
-                                                                   WinGeom g, int B) {
+                                                                   const WinGeom& g, int B) {
   __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT], sG[WN * LDT];
   __shared__ float sP[NPD * LDP];
   __shared__ float sT[TBL];
   __shared__ float sBw[4][3 * HD];
+  __shared__ float sDelta[64];
   __shared__ int sLab[WN], sTok[WN];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 31;
   const int head = blockIdx.x % g.heads;
@@ -949,10 +951,29 @@ __global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* 
       sTok[tid] = me.pad ? -1 : (int)me.tok;
     }
     __syncthreads();
+    // delta_i = sum_j P_ij dP_ij = dO_i . O_i (O = the forward output of this head): with the forward output at hand
+    // it is a 32-channel dot product per row (four lanes per row) instead of a cross-lane reduction per dS row
+    float4 o_a = make_float4(0.f, 0.f, 0.f, 0.f), o_b = o_a;
+    if (outp && (tid >> 2) < WN) {
+      const int tok = sTok[tid >> 2];
+      if (tok >= 0) {
+        const float4* o4 = reinterpret_cast<const float4*>(outp + ((long)b * L + tok) * g.C + head * HD + (tid & 3) * 8);
+        o_a = o4[0];
+        o_b = o4[1];
+      }
+    }
     stage_item_tiles(sQ, sK, sV, sG, qkv + (long)b * L * 3 * g.C + head * HD, qkv_b, dout + (long)b * L * g.C + head * HD, g,
                      head, sTok, scale, w, lane);
     __syncthreads();
     float* dq_base = dqkv + (long)b * L * 3 * g.C + head * HD;
+    if (outp) {
+      const float* gq = sG + min(tid >> 2, WN - 1) * LDT + (tid & 3) * 8;
+      float d = ((o_a.x * gq[0] + o_a.y * gq[1]) + (o_a.z * gq[2] + o_a.w * gq[3])) +
+                ((o_b.x * gq[4] + o_b.y * gq[5]) + (o_b.z * gq[6] + o_b.w * gq[7]));
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if ((tid & 3) == 0) sDelta[tid >> 2] = d;  // (read after the barriers below)
+    }
     {  // ---- 1. S tile (w >> 1, w & 1) -> sP
       f32x16 a;
       zero16(a);
@@ -991,7 +1012,7 @@ __global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* 
         const int j0 = fr, j1 = 32 + fr;
         const float p0 = iv ? sP[i * LDP + j0] : 0.f;
         const float p1 = (iv && j1 < WN) ? sP[i * LDP + j1] : 0.f;
-        const float delta = half_sum(p0 * dp[0][r] + p1 * dp[1][r]);
+        const float delta = outp ? sDelta[min(i, 63)] : half_sum(p0 * dp[0][r] + p1 * dp[1][r]);
         if (iv) {
           sP[i * LDP + j0] = p0 * (dp[0][r] - delta);
           if (j1 < WN) sP[i * LDP + j1] = p1 * (dp[1][r] - delta);
@@ -1028,18 +1049,18 @@ __global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* 
     }
     if (tid < TBL) {  // bias-table gradient: entry (dy, dx) = sum of dS over the pairs i - j = (dy, dx), fixed order
       // (constant trip counts + predicates: the 49 LDS reads are issued together instead of one dependent read per add)
-      float part7[WS];
-#pragma unroll
-      for (int iy = 0; iy < WS; ++iy) {
+      float acc7 = 0.f;
+#pragma unroll 1
+      for (int iy = iy0; iy <= iy1; ++iy) {  // (seven reads in flight per row of the window: registers)
         float v[WS];
 #pragma unroll
         for (int ix = 0; ix < WS; ++ix) {
-          const bool ok = iy >= iy0 && iy <= iy1 && ix >= ix0 && ix <= ix1;
+          const bool ok = ix >= ix0 && ix <= ix1;
           v[ix] = ok ? sP[(iy * WS + ix) * LDP + (iy - tdy) * WS + (ix - tdx)] : 0.f;
         }
-        part7[iy] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
+        acc7 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
       }
-      dT += ((part7[0] + part7[1]) + (part7[2] + part7[3])) + ((part7[4] + part7[5]) + part7[6]);
+      dT += acc7;
     }
   }
   // this workgroup's share of the bias-table / pad-token (qkv-bias) gradients: one partial row, folded over the
@@ -1053,6 +1074,16 @@ __global__ __launch_bounds__(256) void swin_wattn_bwd_mfma4_kernel(const float* 
   float* prow = part + (long)blockIdx.x * WATTN_PROW;
   if (tid < TBL) prow[tid] = dT;
   if (tid < 3 * HD) prow[WATTN_PBIAS + tid] = ((sBw[0][tid] + sBw[1][tid]) + sBw[2][tid]) + sBw[3][tid];
+}
+
+// Resident workgroups per CU = wavefronts per SIMD: LDS allows four (39 KB each); the registers decide — 2: 202 VGPRs, no
+// scratch; 3: 168 + 92 B of scratch per lane; 4: 128 + 252 B.  OCC picks the budget (rscotr_swin_wattn_bwd measures which wins).
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void swin_wattn_bwd_mfma4_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_b, const float* __restrict__ table,
+    const float* __restrict__ dout, const float* __restrict__ outp, float* __restrict__ dqkv, float* __restrict__ part,
+    WinGeom g, int B) {
+  swin_wattn_bwd_mfma4_body(qkv, qkv_b, table, dout, outp, dqkv, part, g, B);
 }
 
 static int wattn_geom(const char* fn, WinGeom* g, int B, int H, int W, int C, int heads, int ws, int shift) {
@@ -1131,7 +1162,51 @@ __global__ __launch_bounds__(256) void wattn_param_fold_kernel(const float* __re
     dqkv_b[(t / HD) * C + head * HD + (t % HD)] += a;
   }
 }
+
+// The same fold for ALL pending window-attention backward passes of a backward pass in one launch
+// (rscotr_swin_wattn_flush): grid (ceil(WATTN_PROW / 64), total heads); table rows {partial rows, dtable | 0,
+// dqkv_bias | 0, heads, C, rows per head, first head of this entry in the grid}.
+__global__ __launch_bounds__(256) void wattn_param_flush_kernel(const int64_t* __restrict__ table, int n) {
+  __shared__ float red[3][64];
+  int e = 0;
+  while (e + 1 < n && (int)table[(long)(e + 1) * 16 + 6] <= (int)blockIdx.y) ++e;
+  const int64_t* t = table + (long)e * 16;
+  const float* part = reinterpret_cast<const float*>(t[0]);
+  float* dtable = reinterpret_cast<float*>(t[1]);
+  float* dqkv_b = reinterpret_cast<float*>(t[2]);
+  const int heads = (int)t[3], C = (int)t[4], rows = (int)t[5], head = (int)blockIdx.y - (int)t[6];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (col < WATTN_PROW) {
+#pragma unroll 8
+    for (int r = w; r < rows; r += 4) a += part[((long)r * heads + head) * WATTN_PROW + col];
+  }
+  if (w > 0) red[w - 1][lane] = a;
+  __syncthreads();
+  if (w != 0 || col >= WATTN_PROW) return;
+  a += red[0][lane];
+  a += red[1][lane];
+  a += red[2][lane];
+  if (col < TBL) {
+    if (dtable) dtable[col * heads + head] += a;
+  } else if (col >= WATTN_PBIAS && dqkv_b) {
+    const int c = col - WATTN_PBIAS;
+    dqkv_b[(c / HD) * C + head * HD + (c % HD)] += a;
+  }
+}
 }  // namespace rscotr
+
+// table: device (n, 16) int64 rows {partial rows left by rscotr_swin_wattn_bwd(dqkv_bias = dbias_table = NULL), dbias_table | 0,
+// dqkv_bias | 0, heads, C, rows per head (= workspace bytes / (heads * WATTN_PROW * 4)), first grid row of the entry (running
+// sum of heads), 0 ...}; total_heads = sum of heads.  The destinations are ADDED to.
+extern "C" int rscotr_swin_wattn_flush(const int64_t* table, int n, int total_heads, void* stream) {
+  if (n < 0 || total_heads < 0) return fail(RSCOTR_E_SHAPE, "rscotr_swin_wattn_flush: negative count");
+  if (n == 0 || total_heads == 0) return RSCOTR_OK;
+  if (!table) return fail(RSCOTR_E_ARG, "rscotr_swin_wattn_flush: null table");
+  wattn_param_flush_kernel<<<dim3((WATTN_PROW + 63) / 64, (unsigned)total_heads), 256, 0, (hipStream_t)stream>>>(table, n);
+  return check_launch("rscotr_swin_wattn_flush");
+}
 
 extern "C" int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, int heads) {
   WinGeom g;
@@ -1141,8 +1216,8 @@ extern "C" int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, i
 
 extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table,
                                      const float* dout, float* dqkv, float* dqkv_bias, float* dbias_table,
-                                     int B, int H, int W, int C, int heads, int ws, int shift, float* workspace,
-                                     int64_t workspace_bytes, void* stream) {
+                                     int B, int H, int W, int C, int heads, int ws, int shift, const float* out,
+                                     float* workspace, int64_t workspace_bytes, void* stream) {
   WinGeom g;
   if (int e = wattn_geom("rscotr_swin_wattn_bwd", &g, B, H, W, C, heads, ws, shift)) return e;
   if (B == 0) return RSCOTR_OK;
@@ -1160,7 +1235,17 @@ extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, co
   else if (impl == 1)
     swin_wattn_bwd_mfma_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B);
   else
-    swin_wattn_bwd_mfma4_kernel<<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B);
+  {
+    // measured (scripts/bench_wattn.py, B = 2 at 512^2): 2 resident workgroups per CU win except where the items fit the
+    // chip at 3 per CU but not at 2 (stage 3: 600 items, 35.7 -> 28.9 us); 4 (with scratch) always loses
+    static const int occ_env = getenv("RSCOTR_WATTN_OCC") ? atoi(getenv("RSCOTR_WATTN_OCC")) : 0;
+    const int occ = occ_env ? occ_env : ((nwg > 512 && nwg <= 768) ? 3 : 2);
+    static const int use_out = getenv("RSCOTR_WATTN_DELTA_OUT") ? atoi(getenv("RSCOTR_WATTN_DELTA_OUT")) : 1;
+    const float* o = (use_out && out && aligned16(out)) ? out : nullptr;
+    if (occ >= 4) swin_wattn_bwd_mfma4_kernel<4><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
+    else if (occ == 3) swin_wattn_bwd_mfma4_kernel<3><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
+    else swin_wattn_bwd_mfma4_kernel<2><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
+  }
   if (dbias_table || dqkv_bias)
     wattn_param_fold_kernel<<<dim3((WATTN_PROW + 63) / 64, heads), 256, 0, s>>>(workspace, dbias_table, dqkv_bias, heads, C,
                                                                               nwg / heads);

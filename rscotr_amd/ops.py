@@ -349,6 +349,7 @@ class _DeferredCombine:
         self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '0'))  # 0: fp32 tiles only, 1: bf16x6 128 x 128 tiles for interior problems
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.pinned_pool, self.pinned_live = [], []
+        self.wattn_entries, self.wattn_cache = [], {}
 
     MAX_TABLES = 64
     GROUP_MAX_OUT = int(os.environ.get('RSCOTR_DW_GROUP_MAX', 160000))     # M * N of a grouped problem
@@ -436,11 +437,12 @@ class _DeferredCombine:
             self.cur, self.off = self.cur + 1, 0
 
     def pending(self):
-        return bool(self.entries or self.ln_entries or self.group)
+        return bool(self.entries or self.ln_entries or self.group or self.wattn_entries)
 
     def drop(self):
         self.entries, self.notify, self.ln_entries = [], [], []
         self.group, self.group_keep = [], []
+        self.wattn_entries = []
         self.cur = self.off = 0
 
     @staticmethod
@@ -487,11 +489,28 @@ class _DeferredCombine:
         self.entries.extend(hit[1])
         self.group, self.group_keep = [], []
 
+    def _flush_wattn(self):
+        """Partial rows of the window-attention backward passes (bias-table / pad-token gradients): one fold launch."""
+        sig = tuple(self.wattn_entries)
+        hit = self.wattn_cache.get(sig)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for part, dt, db, heads, C, nrows in self.wattn_entries:
+                rows.append((part, dt, db, heads, C, nrows, first) + (0,) * 9)
+                first += heads
+            hit = (self._upload(np.asarray(rows, dtype=np.int64), self.blocks[0].device), len(rows), first)
+        self._remember(self.wattn_cache, sig, hit)
+        lib.call('rscotr_swin_wattn_flush', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        self.wattn_entries = []
+
     def flush(self):
         if self.group:
             self._flush_group()
         if self.ln_entries:
             self._flush_ln()
+        if self.wattn_entries:
+            self._flush_wattn()
         if self.entries:
             sig = tuple(self.entries)
             hit = self.cache.get(sig)
@@ -955,13 +974,13 @@ class _SwinWindowAttn(Function):
         with _Prof('swin_wattn_fwd', 4 * B * L * 4 * C):
             lib.call('rscotr_swin_wattn_fwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), out.data_ptr(),
                      B, H, W, C, heads, ws, shift, _stream())
-        ctx.save_for_backward(qkv, qkv_b, table)
+        ctx.save_for_backward(qkv, qkv_b, table, out)  # (out: the proj Linear keeps it alive anyway)
         ctx.geom = (B, H, W, C, heads, ws, shift)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, qkv_b, table = ctx.saved_tensors
+        qkv, qkv_b, table, out = ctx.saved_tensors
         B, H, W, C, heads, ws, shift = ctx.geom
         dout = _f32c(dout)
         dqkv = torch.empty_like(qkv)
@@ -973,11 +992,19 @@ class _SwinWindowAttn(Function):
         dqkv_b = None if (skb is not None or qkv_b is None) else torch.zeros_like(qkv_b)
         dt_ptr = skt[1].data_ptr() if skt is not None else dtable.data_ptr()
         db_ptr = skb[1].data_ptr() if skb is not None else _ptr(dqkv_b)
-        with _Prof('swin_wattn_bwd', 4 * B * H * W * 8 * C):
-            nws = lib.rscotr_swin_wattn_bwd_workspace(B, H, W, C, heads)
+        nws = lib.rscotr_swin_wattn_bwd_workspace(B, H, W, C, heads)
+        if (skt is not None and (skb is not None or qkv_b is None) and DEFER.enabled and SIDE is None
+                and PROFILE is None):
+            # arena-direct: the fold of the partial rows joins the end-of-pass flush (one launch for all 12 blocks)
+            part = DEFER.reserve(nws, qkv.device)
             lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), dout.data_ptr(),
-                     dqkv.data_ptr(), db_ptr, dt_ptr, B, H, W, C, heads, ws, shift,
-                     _WS.get(nws, qkv.device).data_ptr(), nws, _stream())
+                     dqkv.data_ptr(), 0, 0, B, H, W, C, heads, ws, shift, out.data_ptr(), part, nws, _stream())
+            DEFER.wattn_entries.append((part, dt_ptr, db_ptr, heads, C, nws // (heads * 268 * 4)))
+        else:
+            with _Prof('swin_wattn_bwd', 4 * B * H * W * 8 * C):
+                lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), dout.data_ptr(),
+                         dqkv.data_ptr(), db_ptr, dt_ptr, B, H, W, C, heads, ws, shift, out.data_ptr(),
+                         _WS.get(nws, qkv.device).data_ptr(), nws, _stream())
         for sk in (skt, skb):
             if sk is not None:
                 GRAD_SINK.grad_written(sk[0])
