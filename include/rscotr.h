@@ -118,6 +118,21 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * against ~1e-6 for fp32 FMA, inside the 1e-3 gate of the path; 2 = bf16x3 only on the large row-major x row-major products
  * (128x128x32 tiles, gemm_bf16x3_big_kernel), fp32 pipe elsewhere.  Process-wide; start value 0, or from
  * RSCOTR_GEMM_PREC=fp32|bf16x3|bf16x3-big. */
+/* The same product with PRE-SPLIT WEIGHTS.  In y = x W^T and dx = dy W of a Linear layer (torch F.linear behind mmcv's FFN,
+ * MultiheadAttention, MultiScaleDeformableAttention, mmdet's WindowMSA / FFN) the B operand is a parameter that changes once
+ * per optimizer step; rscotr_gemm_split_weights writes its three bf16 planes once (layout [K/16][npad][3][16], npad = rows
+ * rounded up to 256 with zero rows behind; `transposed` entries hold the planes of W^T for dx = dy W, N % 16 == 0), and
+ * rscotr_gemm_f32_wplanes multiplies an fp32 row-major A (split on the fly, once per 128 / 256 output columns) with them:
+ * same six-term product and error class as precision mode 3, same epilogue arguments as rscotr_gemm_f32 (no row sums, no
+ * k scaling: those belong to weight gradients).  table of rscotr_gemm_split_weights: device (n, 8) int64 rows {W, planes, N, K,
+ * ldw, npad, first block, transposed}; an entry takes ceil(npad * (reduction / 16) / 256) blocks, reduction = K (or N when
+ * transposed, the plane set then has K rows).  Plane buffers hold npad * reduction * 6 bytes. */
+int rscotr_gemm_split_weights(const int64_t* table, int n, int total_blocks, void* stream);
+int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K);
+int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int npad, float* C, int M, int N, int K, int lda, int ldc,
+                            const float* bias, int act, const float* aux, float* pre, const float* resid, int accumulate,
+                            const float* rowscale, int rows_per_scale, float* out2, float* workspace,
+                            int64_t workspace_bytes, void* stream);
 int rscotr_gemm_set_precision(int prec);
 int rscotr_gemm_get_precision(void);
 int64_t rscotr_gemm_f32_workspace(int M, int N, int K);

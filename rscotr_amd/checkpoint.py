@@ -108,6 +108,8 @@ def load_checkpoint(model, path, strict=False, map_location='cpu', weights_only=
     ckpt = torch.load(path, map_location=map_location, weights_only=weights_only) if isinstance(path, str) else path
     sd = ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt
     report = model.load_state_dict(_strip_module_prefix(sd), strict=strict)
+    from . import ops
+    ops.WPLANES.bump()  # parameters changed in place: pre-split planes are stale
     if isinstance(ckpt, dict) and 'CLASSES' in ckpt.get('meta', {}):
         model.CLASSES = ckpt['meta']['CLASSES']
     return ckpt, report

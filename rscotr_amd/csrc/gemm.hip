@@ -1284,6 +1284,223 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf16x6 with PRE-SPLIT WEIGHTS (rscotr_gemm_f32_wplanes; scripts/lab/planes_lab.hip is the stand-alone version).
+// In y = x W^T and dx = dy W the B operand is a parameter: it changes once per optimizer step, yet the kernels above split it
+// into bf16 planes again in every workgroup of every launch (a 10880 x 2048 x 256 product converts W 85 times).  Here the
+// planes are written ONCE per step by rscotr_gemm_split_weights, in a k-step-major layout [K / 16][Npad][3 planes][16 k]
+// bf16 (Npad = N rounded up to 128, zero rows behind N), so that the B stage of a workgroup is one contiguous run of
+// 96-byte rows that goes global -> VGPR -> LDS with no VALU work at all; the transposed set (planes of W^T) serves
+// dx = dy W.  Only A (the activation, fp32, row-major) is split while it is staged — once per 256 (128) output columns.
+// Workgroup = 512 threads = 8 wavefronts; tile 128 x 256 (wave tile 64 x 64) or 128 x 128 (wave tile 32 x 64); two LDS
+// stages, one barrier per 16-k step, three register sets of prefetch (tile t + 3 is requested at the top of step t), the
+// split / pack / LDS writes of tile t + 1 interleaved with the MFMAs of tile t (sched_group_barrier).  Rows past M are
+// clamped loads / guarded stores, columns past N are zero planes / guarded stores: any M, N; K % 16 == 0.
+// Lab (MI355X, no epilogue): 10880 x 256 x 2048 in 3 k-slices 70 us against 105 for the in-kernel split, 32768 x 384 x 96
+// 26 against 47, 8192 x 768 x 192 21 against 35, 2048 x 1536 x 384 22 against 30, 4096^3 207 TFLOP/s-equivalent against 174.
+constexpr int WPL_LDR = 56;  // bf16 per LDS row: 3 planes x 16 k + 8 pad (112 bytes: conflict-free 16-byte fragment reads)
+
+struct WplRegs {
+  float4 a;
+  uint4 b[3];
+  __device__ __forceinline__ void load(const float* a_src, const unsigned short* b_src, long a_off, long b_off, bool b_active) {
+    a = *reinterpret_cast<const float4*>(a_src + a_off);
+    if (b_active) {
+      const uint4* s = reinterpret_cast<const uint4*>(b_src + b_off);
+      b[0] = s[0]; b[1] = s[1]; b[2] = s[2];
+    }
+  }
+  __device__ __forceinline__ void store(unsigned* a_s, unsigned* b_s, int tid, bool b_active) const {
+    __bf16 x[3], y[3], z[3], w[3];
+    split_planes<3>(a.x, x); split_planes<3>(a.y, y); split_planes<3>(a.z, z); split_planes<3>(a.w, w);
+    unsigned* dst = a_s + ((tid >> 2) * WPL_LDR + (tid & 3) * 4) / 2;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * 8) = make_uint2(pack_bf16(x[p], y[p]), pack_bf16(z[p], w[p]));
+    if (b_active) {
+      uint4* d4 = reinterpret_cast<uint4*>(b_s + ((tid >> 1) * WPL_LDR + (tid & 1) * 24) / 2);
+      d4[0] = b[0]; d4[1] = b[1]; d4[2] = b[2];
+    }
+  }
+};
+
+template <int BN> constexpr size_t wplanes_lds_bytes() { return 2 * (size_t)(128 + BN) * WPL_LDR * 2; }
+
+// p.B is unused; `planes` = the pre-split B, npad = its row count per k-step.  p.tiles = tiles_m * tiles_n, p.splits k-slices
+// (k-steps divided evenly), slabs as in the kernels above.
+template <int BN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wplanes_kernel(
+    GemmParams p, const unsigned short* __restrict__ planes, int npad) {
+  constexpr int BM = 128, DEPTH = 3;
+  constexpr int WNW = BN / 64, WMW = 8 / WNW, MT = BM / WMW / 32, NT = 2;
+  constexpr int A_WORDS = BM * WPL_LDR / 2, B_WORDS = BN * WPL_LDR / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned wpl_lds[];
+  unsigned* sA[2] = {wpl_lds, wpl_lds + A_WORDS};
+  unsigned* sB[2] = {wpl_lds + 2 * A_WORDS, wpl_lds + 2 * A_WORDS + B_WORDS};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  // grid = tiles x k-slices EXACTLY: one (128 x 256) workgroup is resident per CU, so a grid padded past 256 workgroups
+  // (the XCD-run mapping of the kernels above) would leave a handful of them to a second round of the whole chip
+  const int idx = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = idx / p.tiles, tile = idx - split * p.tiles;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk_all = p.K / 16;
+  const int kt0 = (int)((long)split * nk_all / p.splits), kt1 = (int)((long)(split + 1) * nk_all / p.splits);
+  const int nk = kt1 - kt0;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  WplRegs sets[DEPTH];
+  const float* a_src = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;  // rows past M: clamped reads
+  const bool b_active = BN == 256 || tid < 256;
+  const unsigned short* b_src = planes + ((long)n0 + (tid >> 1)) * 48 + (tid & 1) * 24;      // (n0 + BN <= npad)
+  const long b_step = (long)npad * 48;
+  const int fr = lane & 31, g = lane >> 5;
+  auto mma = [&](const unsigned* a_s, const unsigned* b_s) {
+    bf16x8 af[MT][3], bf[NT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned* q = a_s + ((wm * (BM / WMW) + i * 32 + fr) * WPL_LDR + 8 * g) / 2;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const unsigned* q = b_s + ((wn * 64 + j * 32 + fr) * WPL_LDR + 8 * g) / 2;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {  // small terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+  constexpr int U = 2 * DEPTH;
+  constexpr int NMFMA = MT * NT * 6;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int kt = kt0 + min(d, nk - 1);
+    sets[d].load(a_src, b_src, (long)kt * 16, kt * b_step, b_active);
+  }
+  sets[0].store(sA[0], sB[0], tid, b_active);
+  __syncthreads();
+  for (int t0 = 0; t0 < nk; t0 += U) {
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      const int t = t0 + s;
+      if (t < nk) {
+        {
+          const int kt = kt0 + min(t + DEPTH, nk - 1);
+          sets[s % DEPTH].load(a_src, b_src, (long)kt * 16, kt * b_step, b_active);
+        }
+        mma(sA[s & 1], sB[s & 1]);
+        sets[(s + 1) % DEPTH].store(sA[(s + 1) & 1], sB[(s + 1) & 1], tid, b_active);
+#pragma unroll
+        for (int i = 0; i < NMFMA; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  if (p.splits > 1) {
+    float* slab = p.slabs + (long)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / WMW) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (m < p.M) slab[(long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + fr;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const int mb = m0 + wm * (BM / WMW) + i * 32 + 4 * g;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
+        epilogue_rows4<true>(p, v, mb + 8 * g4, n);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+}
+
+// Split weights into the plane layout above: table rows {W, planes, N, K, ldw, npad, first block, transposed} (int64 x 8);
+// transposed = 0: planes of W (N rows, reduction over K: y = x W^T); 1: planes of W^T (rows = the K columns of W, reduction
+// over N: dx = dy W), N % 16 == 0 then.  One thread per (row, k-step): 16 values, one 96-byte output row.
+__global__ __launch_bounds__(256) void split_weights_kernel(const int64_t* __restrict__ table, int n_entries) {
+  int e = 0;
+  while (e + 1 < n_entries && (long)table[(long)(e + 1) * 8 + 6] <= (long)blockIdx.x) ++e;
+  const int64_t* t = table + (long)e * 8;
+  const float* W = reinterpret_cast<const float*>(t[0]);
+  unsigned short* planes = reinterpret_cast<unsigned short*>(t[1]);
+  const int N = (int)t[2], K = (int)t[3], ldw = (int)t[4], npad = (int)t[5], tr = (int)t[7];
+  const int rows = tr ? K : N, red = tr ? N : K;  // output rows, reduction length
+  const long idx = ((long)blockIdx.x - t[6]) * 256 + threadIdx.x;
+  const int nkt = red / 16;
+  // consecutive threads take consecutive k-steps of one row (tr = 0: contiguous 64-byte reads) or consecutive rows of one
+  // k-step (tr = 1: W is read along its rows)
+  const int row = tr ? (int)(idx % npad) : (int)(idx / nkt);
+  const int kt = tr ? (int)(idx / npad) : (int)(idx % nkt);
+  if (kt >= nkt || row >= npad) return;
+  float v[16];
+  if (row >= rows) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+  } else if (!tr) {
+    const float4* src = reinterpret_cast<const float4*>(W + (long)row * ldw + kt * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = W[(long)(kt * 16 + i) * ldw + row];
+  }
+  unsigned out[3][8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    __bf16 a[3], b[3];
+    split_planes<3>(v[2 * q], a);
+    split_planes<3>(v[2 * q + 1], b);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl][q] = pack_bf16(a[pl], b[pl]);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(planes + ((long)kt * npad + row) * 48);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    dst[pl * 2] = make_uint4(out[pl][0], out[pl][1], out[pl][2], out[pl][3]);
+    dst[pl * 2 + 1] = make_uint4(out[pl][4], out[pl][5], out[pl][6], out[pl][7]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Grouped launch of deferred weight gradients (rscotr_gemm_dw_group): MANY dW = A^T B problems with small outputs (the
 // 256 x 256 projections of the encoder / decoders, the Swin stage 1-2 Linears: ~110 launches of 8-40 us per co-training
 // round, each a short grid that ramps up and drains alone) run as ONE launch.  Operands are the k-major activations /
@@ -2239,6 +2456,114 @@ extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C
   tl_defer = 0;
   *splits_out = tl_last_splits;
   return e;
+}
+
+// Planes of weights for rscotr_gemm_f32_wplanes (layout: gemm_wplanes_kernel).  table: device (n, 8) int64 rows {W, planes, N,
+// K, ldw, npad, first block, transposed}; an entry takes ceil(npad * (reduction / 16) / 256) blocks (npad = rows of the plane
+// set rounded up to 256; reduction = K, or N when transposed); total_blocks = their sum.
+extern "C" int rscotr_gemm_split_weights(const int64_t* table, int n, int total_blocks, void* stream) {
+  if (n < 0 || total_blocks < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_split_weights: negative count");
+  if (n == 0 || total_blocks == 0) return RSCOTR_OK;
+  if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_split_weights: null table");
+  split_weights_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(table, n);
+  return check_launch("rscotr_gemm_split_weights");
+}
+
+// Tile width and k-slices of the pre-split product: one 128 x 256 workgroup is resident per CU (86 KB of LDS), two 128 x 128
+// ones; the grid should be a whole number of such rounds over the 256 CUs (340 workgroups take as long as 512).
+static void wplanes_cfg(int M, int N, int K, int* bn_out, int* splits_out) {
+  static const char* force = getenv("RSCOTR_WPLANES_FORCE");  // "bn,splits" — tuning only
+  if (force) {
+    int b = 0, sp = 0;
+    if (sscanf(force, "%d,%d", &b, &sp) == 2 && (b == 128 || b == 256) && sp >= 1) {
+      *bn_out = b; *splits_out = (int)std::min<long>(sp, std::max(1, K / 128));
+      return;
+    }
+  }
+  const long tm = (M + 127) / 128;
+  const long smax = std::max<long>(1, std::min<long>(8, K / 256));
+  double best = -1.0;
+  int bbn = 128, bsp = 1;
+  for (int bn = 256; bn >= 128; bn -= 128) {
+    if (bn == 256 && N <= 128) continue;
+    const long t = tm * ((N + bn - 1) / bn), cap = bn == 256 ? 256 : 512;
+    for (long sp = 1; sp <= smax; ++sp) {
+      const long wgs = t * sp, rounds = (wgs + cap - 1) / cap;
+      // time model: rounds x (k-steps per slice + prologue / epilogue worth ~4 steps) x tile area, plus the slab pass
+      const double steps = (double)K / 16 / sp + 4.0;
+      // (a round of 512 half-width workgroups covers the area of a round of 256 full-width ones, ~1.2x slower: lab)
+      double cost = rounds * steps * (bn == 256 ? 1.0 : 1.22);
+      if (sp > 1) cost += 2.0 * sp * M * N * 4.0 * 1.9e-7;  // slabs written and read at ~4 TB/s, in k-steps of 1.3 us
+      const double score = 1.0 / cost;
+      if (score > best) { best = score; bbn = bn; bsp = (int)sp; }
+    }
+  }
+  *bn_out = bbn; *splits_out = bsp;
+}
+
+extern "C" int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K) {
+  int bn, splits;
+  wplanes_cfg(M, N, K, &bn, &splits);
+  return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+}
+
+// C = epilogue(A x Bplanes): A (M, K) fp32 row-major (lda), planes = the pre-split B of rscotr_gemm_split_weights (N rows,
+// npad >= N rounded up to 256, reduction K, K % 16 == 0); epilogue arguments as rscotr_gemm_f32.
+extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int npad, float* C, int M, int N, int K, int lda,
+                                       int ldc, const float* bias, int act, const float* aux, float* pre, const float* resid,
+                                       int accumulate, const float* rowscale, int rows_per_scale, float* out2,
+                                       float* workspace, int64_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32_wplanes: negative dimension");
+  if (M == 0 || N == 0) return RSCOTR_OK;
+  if (!A || !planes || !C) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: null pointer");
+  if (K % 16 || K < 16 || npad % 256 || npad < N || lda < K || ldc < N || lda % 4 || !aligned16(A) || !aligned16(planes))
+    return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32_wplanes: K %% 16, npad %% 256, 16-byte aligned A rows required (M=%d N=%d K=%d npad=%d lda=%d)",
+                M, N, K, npad, lda);
+  if (act < ACT_NONE || act > ACT_GELU_GRAD) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: unknown act %d", act);
+  if ((act == ACT_RELU_GRAD || act == ACT_GELU_GRAD) && !aux) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: act %d needs aux", act);
+  if (rowscale && rows_per_scale <= 0) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: rowscale needs rows_per_scale > 0");
+  GemmParams p;
+  p.A = A; p.B = nullptr; p.C = C; p.bias = bias; p.aux = aux; p.pre = pre; p.resid = resid; p.C2 = out2;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = K; p.ldc = ldc;
+  p.act = act; p.accumulate = accumulate;
+  p.vecA = 1; p.vecB = 1;
+  p.vecC = (ldc % 4 == 0) && aligned16(C) && aligned16(bias) && aligned16(aux) && aligned16(pre) && aligned16(resid) && aligned16(out2);
+  p.rowsum = nullptr; p.rowsum_acc = 0; p.rs_slabs = nullptr;
+  p.nb1 = 0; p.nb2 = 1;
+  p.rowscale = rowscale; p.rows_per = rows_per_scale; p.kscale = nullptr; p.krows_per = 0;
+  hipStream_t s = (hipStream_t)stream;
+  int bn, splits;
+  wplanes_cfg(M, N, K, &bn, &splits);
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4))
+    splits = (int)std::max<int64_t>(1, workspace ? workspace_bytes / ((int64_t)M * N * 4) : 1);
+  const long tm = (M + 127) / 128;
+  const long t128 = tm * ((N + 127) / 128), t256 = tm * ((N + 255) / 256);
+  p.tiles = (int)(bn == 256 ? t256 : t128);
+  p.splits = splits; p.ksplit_len = K;
+  p.slabs = splits > 1 ? workspace : nullptr;
+  static const bool prof_shapes_w = getenv("RSCOTR_PROF_SHAPES") != nullptr;
+  char wname[112];
+  if (prof_shapes_w) snprintf(wname, sizeof(wname), "M=%d N=%d K=%d 0p wplanes-%d splits=%d", M, N, K, bn, splits);
+  else snprintf(wname, sizeof(wname), "rscotr::gemm_wplanes_kernel<%d>", bn);
+  ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", wname);
+  const unsigned nwg = (unsigned)p.tiles * (unsigned)splits;
+  static const bool attr_set = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wplanes_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)wplanes_lds_bytes<256>());
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wplanes_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)wplanes_lds_bytes<128>());
+    return true;
+  }();
+  (void)attr_set;
+  const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
+  if (bn == 256) gemm_wplanes_kernel<256><<<dim3(nwg), 512, wplanes_lds_bytes<256>(), s>>>(p, pl, npad);
+  else gemm_wplanes_kernel<128><<<dim3(nwg), 512, wplanes_lds_bytes<128>(), s>>>(p, pl, npad);
+  if (int e = check_launch("rscotr_gemm_f32_wplanes")) return e;
+  if (splits > 1) {
+    launch_splitk_reduce(p, workspace, s);
+    return check_launch("rscotr_gemm_f32_wplanes (split-K reduce)");
+  }
+  return RSCOTR_OK;
 }
 
 // Grouped launch of deferred weight gradients: see gemm_f32_group_kernel.  table: device (n, 16) int64 (layout there),

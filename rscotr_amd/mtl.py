@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import ops
 from .cls_head import Augments
 from .layers import MultiScaleDeformableAttention
 from .registry import MODELS, build_backbone, build_head, build_neck, build_transformer_layer_sequence
@@ -267,7 +268,12 @@ class MTL(nn.Module):
         return list(seg_pred.cpu().numpy())
 
     # -------------------------------------------------------------------------------------
+    def load_state_dict(self, *args, **kwargs):
+        ops.WPLANES.bump()  # parameters change in place: the pre-split weight planes are stale
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, task, img, img_metas, return_loss=True, dataset_name=None, **kwargs):
+        ops.WPLANES.begin(task)  # (the weight-plane sets this task uses are refreshed together)
         if return_loss:
             return self.forward_train(task=task, img=img, img_metas=img_metas, **kwargs)
         with torch.no_grad():

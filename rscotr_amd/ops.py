@@ -51,6 +51,78 @@ _WS = _Workspace()
 _gemm_ws_bytes = {}
 
 
+class _WeightPlanes:
+    """bf16 plane sets of the parameters that serve as the B operand of y = x W^T (and dx = dy W): rscotr_gemm_split_weights
+    writes them ONCE per optimizer step and rscotr_gemm_f32_wplanes multiplies fp32 activations with them (include/rscotr.h).
+    A parameter is recognised by its address inside the optimizer's flat arena (`GRAD_SINK.is_param_ptr`); the sets a task
+    uses are remembered under the task's name (`begin`), and the first product of an iteration that finds them stale
+    re-splits ALL of them in one grouped launch (inside the per-task hipGraph when the iteration is replayed).  `bump()` =
+    "the parameters have changed" (optimizer step, checkpoint load, snapshot restore)."""
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_WPLANES', '1') != '0'
+        self.min_m = int(os.environ.get('RSCOTR_WPLANES_MIN_M', 4096))
+        self.min_k = int(os.environ.get('RSCOTR_WPLANES_MIN_K', 1024))
+        self.version = 1
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.current = None
+
+    def begin(self, group):
+        self.current = group
+
+    def reset(self):
+        """Forget every plane set (a new optimizer arena: addresses may be reused by other parameters)."""
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.version += 1
+
+    def bump(self):
+        self.version += 1
+
+    def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
+        if not self.enabled or a_kmajor or GRAD_SINK is None or K % 16 or K < self.min_k or M < self.min_m or N < 64:
+            return False
+        if lda % 4 or A.data_ptr() % 16 or (b_kmajor and ldb % 4):
+            return False
+        if lib.rscotr_gemm_get_precision() != 3:
+            return False
+        return GRAD_SINK.is_param_ptr(B.data_ptr())
+
+    def get(self, B, N, K, ldb, b_kmajor):
+        """-> (planes pointer, npad) of the weight behind operand B (N output rows, reduction K), fresh."""
+        key = (B.data_ptr(), N, K, ldb, int(b_kmajor))
+        e = self.entries.get(key)
+        if e is None:
+            npad = (N + 255) // 256 * 256
+            e = self.entries[key] = dict(planes=torch.empty(npad * K * 3, dtype=torch.int16, device=B.device), npad=npad,
+                                         version=0, blocks=(npad * (K // 16) + 255) // 256)
+        keys = self.groups.setdefault(self.current, [])
+        if key not in keys:
+            keys.append(key)
+        if e['version'] != self.version:
+            self._refresh(keys, B.device)
+        return e['planes'].data_ptr(), e['npad']
+
+    def _refresh(self, keys, dev):
+        stale = tuple(k for k in keys if self.entries[k]['version'] != self.version)
+        hit = self.tables.get(stale)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for (ptr, N, K, ldb, tr) in stale:
+                e = self.entries[(ptr, N, K, ldb, tr)]
+                # table row {W, planes, rows of W, cols of W, ldw, npad, first block, transposed}: operand B (N, K) row-major is
+                # W itself; operand B k-major is the (K, N) matrix W whose TRANSPOSE is multiplied (planes of W^T)
+                rows.append((ptr, e['planes'].data_ptr(), K if tr else N, N if tr else K, ldb, e['npad'], first, tr))
+                first += e['blocks']
+            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+        lib.call('rscotr_gemm_split_weights', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        for k in stale:
+            self.entries[k]['version'] = self.version
+
+
+WPLANES = _WeightPlanes()
+
+
 class _Side:
     """Second stream for the weight-gradient (dW / db) contractions of backward.  They only feed the gradient
     arena, which nobody reads before the optimizer step, so they need not sit on the critical path: each one
@@ -597,6 +669,16 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if (rowsum is None and kscale is None and PROFILE is None
+            and WPLANES.eligible(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor)):
+        # B is a parameter: multiply with its pre-split bf16 planes (written once per optimizer step)
+        planes, npad = WPLANES.get(B, N, K, ldb, b_kmajor)
+        nws = lib.rscotr_gemm_f32_wplanes_workspace(M, N, K)
+        ws = _WS.get(nws, A.device).data_ptr() if nws else 0
+        lib.call('rscotr_gemm_f32_wplanes', A.data_ptr(), planes, npad, out.data_ptr(), M, N, K, lda, N, _ptr(bias), int(act),
+                 _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowscale), int(rows_per), _ptr(out2), ws, nws,
+                 _stream())
+        return out
     key = (M, N, K, lib.rscotr_gemm_get_precision())  # the workspace a shape wants depends on the precision mode
     nws = _gemm_ws_bytes.get(key)
     if nws is None:

@@ -106,6 +106,7 @@ class FlatAdamW:
             off += (params[gi].numel() + 3) // 4 * 4  # 16-byte aligned segments
         self.total = off
         self.offsets = [offs[i] for i in range(len(groups))]
+        ops.WPLANES.reset()  # (plane sets are keyed by arena addresses)
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_m = torch.zeros(off, dtype=torch.float32, device=device)
@@ -160,6 +161,11 @@ class FlatAdamW:
     # ---- GRAD_SINK protocol (rscotr_amd.ops): backward kernels add a parameter's gradient straight
     # into its slice of the (zero-filled) gradient arena instead of returning a tensor that autograd
     # would add with one more element-wise kernel per parameter.
+    def is_param_ptr(self, ptr):
+        """Does `ptr` point into the flat parameter arena (a parameter, or a slice of one)?"""
+        base = self.flat_p.data_ptr()
+        return base <= ptr < base + self.flat_p.numel() * 4
+
     def grad_view(self, tensor):
         """-> (index, view of the gradient arena shaped like `tensor`) if `tensor` IS a registered
         parameter (same storage start and size), else None."""
@@ -239,6 +245,7 @@ class FlatAdamW:
         if self.max_norm > 0:
             lib.call('rscotr_grad_sumsq', self.flat_g.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
                      self.chunk_len.data_ptr(), self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), s)
+        ops.WPLANES.bump()  # the parameters change: their pre-split planes are stale from here on
         lib.call('rscotr_adamw_clip_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                  self.flat_v.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(), self.chunk_len.data_ptr(),
                  self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), self.max_norm, float(b1), float(b2),
@@ -270,6 +277,7 @@ class FlatAdamW:
                     live=self.live.copy())
 
     def restore(self, snap):
+        ops.WPLANES.bump()
         self.flat_p.copy_(snap['p'])
         self.flat_m.copy_(snap['m'])
         self.flat_v.copy_(snap['v'])

@@ -78,6 +78,51 @@ def test_gemm_second_output(cuda, M, N, K, bk, acc, with_resid):
     assert _rel(out, ref) < 1e-5
     assert _rel(out2, ref + (resid.double() if with_resid else 0.0)) < 1e-5
 
+def _split_planes(lib, W, rows, red, ldw, tr, cuda):
+    """planes of rscotr_gemm_split_weights for one weight: rows = output rows of the plane set, red = reduction length."""
+    import numpy as np
+    npad = (rows + 255) // 256 * 256
+    planes = torch.full((npad * red * 3,), 0x7fc0, dtype=torch.int16, device=cuda)  # bf16 NaN pattern: every word must be written
+    blocks = (npad * (red // 16) + 255) // 256
+    n_w, k_w = (red, rows) if tr else (rows, red)
+    table = torch.from_numpy(np.asarray([[W.data_ptr(), planes.data_ptr(), n_w, k_w, ldw, npad, 0, tr]], dtype=np.int64)).to(cuda)
+    lib.call('rscotr_gemm_split_weights', table.data_ptr(), 1, blocks, torch.cuda.current_stream().cuda_stream)
+    return planes, npad
+
+
+@pytest.mark.parametrize('M,N,K', [(10880, 2048, 256), (10880, 256, 2048), (2048, 384, 1536), (32768, 384, 96), (8192, 288, 192),
+                                   (2048, 1152, 384), (1600, 256, 256), (1000, 200, 112), (300, 45, 64)])
+@pytest.mark.parametrize('tr', [0, 1])
+def test_gemm_with_presplit_weight_planes(cuda, M, N, K, tr):
+    """rscotr_gemm_split_weights + rscotr_gemm_f32_wplanes against fp64: both plane orientations (y = x W^T with W (N, K);
+    dx = dy W with W (K, N)), ragged M / N, k-slices, bias + activation / residual / second output epilogues; error of the
+    class of an fp32 FMA chain (same bound as the in-kernel split)."""
+    from rscotr_amd import ops
+    from rscotr_amd._lib import lib
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + tr)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn((K, N) if tr else (N, K), generator=g) * 0.1
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Wd = A.to(cuda), W.to(cuda)
+    planes, npad = _split_planes(lib, Wd, N, K, W.shape[1], tr, cuda)
+    ref = A.double() @ (W.double() if tr else W.double().t())
+    s = torch.cuda.current_stream().cuda_stream
+    nws = lib.rscotr_gemm_f32_wplanes_workspace(M, N, K)
+    ws = torch.empty(max(nws, 4) // 4, device=cuda)
+    out = torch.full((M, N), float('nan'), device=cuda)
+    lib.call('rscotr_gemm_f32_wplanes', Ad.data_ptr(), planes.data_ptr(), npad, out.data_ptr(), M, N, K, K, N, 0, 0, 0, 0, 0, 0,
+             0, 0, 0, ws.data_ptr(), nws, s)
+    err = _rel(out, ref)
+    fp32 = _rel(ops.gemm(Ad, Wd, M, N, K, K, W.shape[1], 0, tr), ref)
+    assert err <= max(1e-6, 1.5 * fp32), (err, fp32)
+    # epilogue: bias + ReLU, then + resid as the second output
+    out2 = torch.full((M, N), float('nan'), device=cuda)
+    bias_d, resid_d = bias.to(cuda), resid.to(cuda)  # (kept alive across the launch)
+    lib.call('rscotr_gemm_f32_wplanes', Ad.data_ptr(), planes.data_ptr(), npad, out.data_ptr(), M, N, K, K, N,
+             bias_d.data_ptr(), 1, 0, 0, resid_d.data_ptr(), 0, 0, 0, out2.data_ptr(), ws.data_ptr(), nws, s)
+    want = torch.relu(ref + bias.double())
+    assert _rel(out, want) < 2e-6 and _rel(out2, want + resid.double()) < 2e-6
+
 
 def test_gemm_splitk_matches_unsplit(cuda):
     """dW-shaped problem (small output, long reduction) takes the split-K path."""
