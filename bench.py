@@ -313,14 +313,15 @@ def main():
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12
-            split = 'bf16x3' in name or 'bf16x6' in name
-            peak = BF16X6_PEAK_TF if 'bf16x6' in name else (BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF)
+            x6 = 'bf16x6' in name or 'wplanes' in name  # (pre-split weight planes: the same six-term product)
+            split = 'bf16x3' in name or x6
+            peak = BF16X6_PEAK_TF if x6 else (BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF)
             r_gemm = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
                           traffic=None, kernel=name, launches_sampled=d[2], avg_us=d[1] / d[2] * 1e6,
                           flops_per_launch=d[0] / d[2],
                           note=(('fp32 operands split into three bf16 planes in the kernel (all 24 significand bits), six '
                                  'v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate — fp32-FMA-class error: achieved = '
-                                 'fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 6; ' if 'bf16x6' in name else
+                                 'fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 6; ' if x6 else
                                  'fp32 operands split into hi + lo bf16 halves in the kernel, three v_mfma_f32_32x32x16_bf16 per '
                                  'k-step, fp32 accumulate: achieved = fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 3; ')
                                 if split else 'fp32 in / fp32 accumulate MFMA (v_mfma_f32_32x32x2_f32); ') + '1 launch in '
@@ -343,21 +344,21 @@ def main():
                 pass
             tf, tt = sum(v[0] for v in gg.values()), sum(v[1] for v in gg.values())
             sf3 = sum(v[0] for k, v in gg.items() if 'bf16x3' in k)
-            sf6 = sum(v[0] for k, v in gg.items() if 'bf16x6' in k)
+            sf6 = sum(v[0] for k, v in gg.items() if 'bf16x6' in k or 'wplanes' in k)
             sf = sf3 + sf6
-            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or 'bf16x6' in k)
+            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or 'bf16x6' in k or 'wplanes' in k)
             # the family mixes the matrix pipes: its peak is the time the same flops would take at each kernel's own peak
             fam_peak = tf / (sf3 / BF16X3_PEAK_TF + sf6 / BF16X6_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
-                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_bf16x3_big_kernel<*>, '
+                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_bf16x3_big_kernel<*>, '
                               'gemm_small_kernel<*>, gemm_dw_direct_kernel<*>',
                        launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
                             '2500/3 (bf16x3)')
         r_f = hbm('msda_fwd', 'rscotr::msda_fwd_kernel<32, 4>')
-        r_b = hbm('msda_bwd', 'rscotr_msda_bwd (hist + sample + plan + fill + pull kernels)')
+        r_b = hbm('msda_bwd', 'rscotr_msda_bwd (sample + tile + combine kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
             with open(os.path.join(ROOT, 'profiles', 'pmc_gemm_traffic.json')) as fh:
                 pk = json.load(fh)['kernels']
@@ -366,7 +367,7 @@ def main():
             if r_f and fw:
                 r_f['traffic'] = sum(tb(v) * v['dispatches'] for v in fw) / sum(v['dispatches'] for v in fw)
             bw = [v for k, v in pk.items() if 'msda_' in k and 'msda_fwd_kernel' not in k and 'msda_prep' not in k]
-            calls = max([v['dispatches'] for k, v in pk.items() if 'msda_pull_kernel' in k] or [0])
+            calls = max([v['dispatches'] for k, v in pk.items() if 'msda_bwd_kernel' in k] or [0])
             if r_b and bw and calls:
                 r_b['traffic'] = sum(tb(v) * v['dispatches'] for v in bw) / calls
         except (OSError, KeyError, ValueError):

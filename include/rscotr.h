@@ -49,13 +49,16 @@ int rscotr_prof_disable(void);
  *   level_start_index (L) int64, DEVICE memory | loc (B,Nq,H,L,P,2) as (x,y) in [0,1] |
  *   attn (B,Nq,H,L,P) | out (B,Nq,H*D).  D in {16,32,64}, P in {1,2,4,8}.
  * Backward: grad_loc / grad_attn are fully overwritten.  grad_value (B,Nk,H,D), by what the caller provides:
+ *   shapes_host = HOST copy of spatial_shapes (L <= 8) + rscotr_msda_bwd_tiled_workspace() bytes: TILE ACCUMULATION (the
+ *     default of rscotr_amd.ops) — the sample kernel leaves one record per sample; one workgroup per (b, h, level, tile of
+ *     16 x 8 bins, sample chunk) scans the level's records, keeps those of its tile in sample order, sorts them by bin in
+ *     LDS and sums every bin's four tap rows in registers; a combine kernel folds the tiles' cells per token in fixed
+ *     order: fully overwritten, no atomics, BIT-REPRODUCIBLE, 3 launches;
  *   shapes_host NULL + a `workspace` of rscotr_msda_bwd_workspace() bytes (16-byte aligned, contents irrelevant): the
  *     samples are counting-sorted by destination token (one wavefront per chunk: the ranks, hence the summation order,
  *     depend on the data only) and every token pulls its taps; long tap lists are cut into work items whose partial
- *     rows are folded in order: fully overwritten, no fp32 atomics, BIT-REPRODUCIBLE (the default of rscotr_amd.ops);
- *   shapes_host = HOST copy of spatial_shapes (L <= 8) + rscotr_msda_bwd_tiled_workspace() bytes: tile accumulation —
- *     samples partitioned by destination tile in sample order, per-tile LDS accumulators, fixed-order combine: also
- *     bit-reproducible, about twice slower at the encoder shapes (kept as an independent formulation);
+ *     rows are folded in order: fully overwritten, no fp32 atomics, bit-reproducible, 8 launches (kept as an independent
+ *     formulation);
  *   workspace NULL / too small: scatter with fp32 atomics into a grad_value the caller has ZEROED (order-dependent). */
 int rscotr_msda_fwd(const float* value, const int64_t* spatial_shapes,
                     const int64_t* level_start_index, const float* loc, const float* attn,

@@ -36,6 +36,7 @@ struct Bilinear {
   bool ok1, ok2, ok3, ok4;  // tap inside the map
   bool in;                  // sample inside (-1, size) on both axes
   float hh, hw, lh, lw;
+  int h_low, w_low;         // top-left tap (-1 .. size - 1 when `in`)
 };
 
 __device__ __forceinline__ Bilinear bilinear_setup(float lx, float ly, int Hl, int Wl) {
@@ -46,6 +47,8 @@ __device__ __forceinline__ Bilinear bilinear_setup(float lx, float ly, int Hl, i
   const float hf = floorf(h_im), wf = floorf(w_im);
   const int h_low = t.in ? (int)hf : 0, w_low = t.in ? (int)wf : 0;
   const int h_high = h_low + 1, w_high = w_low + 1;
+  t.h_low = h_low;
+  t.w_low = w_low;
   t.lh = h_im - hf;
   t.lw = w_im - wf;
   t.hh = 1.f - t.lh;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attn, const float* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int Nk, int Nq, int H, int L, int ntiles, int bins_cap) {
+    int4* __restrict__ rec, int* __restrict__ binw, int Nk, int Nq, int H, int L, int ntiles, int bins_cap) {
   constexpr int G = D / 4;
   constexpr int QW = kWave / G;
   constexpr int QB = 4 * QW;
@@ -192,6 +195,10 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
   float* s_attn = smem + QB * LP * 2;        // [QB][LP]    in: weights
   float* s_gattn = smem + QB * LP * 3;       // [QB][LP]    out: grad_attn
   float* s_gloc = smem + QB * LP * 4;        // [QB][LP*2]  out: grad_loc
+  // rec != nullptr (tile-accumulation backward): one record {bin of the top-left tap on the extended grid | -1, attention
+  // weight, lw, lh} per sample, laid out (b h, level, q, p); staged [L][QB][P] for a coalesced store (the launch then
+  // brings QB * LP * 16 more bytes of LDS)
+  int4* s_rec = reinterpret_cast<int4*>(smem + QB * LP * 6);
 
   const int bid = blockIdx.x;
   const int h = bid % H;
@@ -274,6 +281,9 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       ga = group_sum<G>(ga);
       if (sub == 0) {
         const bool in = g[p].in;
+        if (rec)
+          s_rec[(l * QB + r) * P + p] = make_int4(in ? ((g[p].h_low + 1) << 16) | (g[p].w_low + 1) : -1, __float_as_int(aw[p]),
+                                                  __float_as_int(lw), __float_as_int(lh));
         s_gloc[(r * LP + l * P + p) * 2 + 0] = in ? (float)Wl * gw : 0.f;
         s_gloc[(r * LP + l * P + p) * 2 + 1] = in ? (float)Hl * gh : 0.f;
         s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
@@ -290,6 +300,16 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const int rr = i / LP, c = i - rr * LP;
     const int qq = q0 + rr;
     if (qq < Nq) grad_attn[(((long)b * Nq + qq) * H + h) * LP + c] = s_gattn[i];
+  }
+  if (rec) {
+    const long SP = (long)Nq * P;
+    for (int i = tid; i < L * QB * P; i += 256) {
+      const int l = i / (QB * P), rem = i - l * (QB * P);
+      if (q0 + rem / P < Nq) {
+        rec[((long)(b * H + h) * L + l) * SP + (long)q0 * P + rem] = s_rec[i];
+        binw[((long)(b * H + h) * L + l) * ((SP + 3) & ~3L) + (long)q0 * P + rem] = s_rec[i].x;  // (the scan reads these only)
+      }
+    }
   }
 }
 
@@ -724,355 +744,330 @@ __global__ __launch_bounds__(256) void msda_chunk_combine_kernel(const int64_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, grad_value by TILE ACCUMULATION — deterministic (round 2; replaces the sort pipeline above as the default)
+// backward, grad_value by TILE ACCUMULATION — deterministic, no global sort (round 2, second design; the default)
 // ---------------------------------------------------------------------------------------------
-// Every level's value map is cut into square tiles of ts x ts tokens (ts = 16 on the largest level, halved per octave so
-// that every level has about the same number of tiles: the levels receive the same number of samples).  A sample belongs
-// to the tile of its TOP-LEFT tap; its four taps then lie inside the tile's (ts+1) x (ts+1) block (one-token halo to the
-// right / bottom).
-//   1. msda_tile_part_kernel: one WAVEFRONT per chunk of 1024 consecutive samples of one (b, h): tile id per sample, STABLE
-//      rank inside (chunk, tile) — lanes of equal tile found with ballots, running per-tile counters in LDS updated by one
-//      wavefront in program order — then the chunk's samples are written, partitioned by tile, as 16-byte records
-//      {query | local top-left cell, attention weight, lw, lh} plus a (chunk, tile) -> (offset, count) table.  No atomics
-//      whose order matters: the record order inside a tile is the sample order, always.
-//   2. msda_tile_acc_kernel: one workgroup per (b, h, tile) with the block's accumulators in LDS.  Its four wavefronts own
-//      the four tap parities (x & 1, y & 1) — the 2x2 footprint of a sample has exactly one tap of each parity — so no two
-//      wavefronts ever touch the same accumulator; inside a wavefront the records are processed in list order, 64 / (D/4)
-//      samples per step, D/4 lanes x float4 per sample: grad_out row gather (L2-resident: one head per XCD) and a plain
-//      LDS read-add-write of the cell's row; the samples of one step that hit the same cell are applied in sample order
-//      (rank among equal cells from wave shuffles, one round per rank).  The block is then written to a partial buffer.
-//   3. msda_tile_combine_kernel: grad_value[token] = its own tile's cell + the halo cells of the left / upper / upper-left
-//      neighbour tiles, fixed order.
-// The result is bit-reproducible; traffic: 16-byte records written + read once, partial blocks ~1.2x grad_value.
-constexpr int MSDA_T_MAXL = 8;      // levels the tile path handles
-constexpr int MSDA_T_CH = 1024;     // samples per partition chunk = 16 rounds of one wavefront
-constexpr int MSDA_T_MAXNT = 1024;  // tiles per (b, h)
-constexpr int MSDA_T_MAXCH = 2048;  // chunks per (b, h)
+// A sample belongs to the BIN of its top-left tap, (h_low + 1, w_low + 1) on the (H_l + 1) x (W_l + 1) "extended" grid of its
+// level; its four taps land on the cells (bin, bin + 1 right, bin + 1 down, both).  The bins of a level are cut into tiles of
+// at most 16 x 16 bins (17 x 17 cells with the one-cell halo to the right / bottom), and the samples of a level — in sample
+// order — into `nch` chunks; one 256-thread workgroup per (b, h, level, tile, chunk):
+//   0. the sample kernel (msda_bwd_kernel, which has every bilinear set-up in registers anyway) leaves one 16-byte record
+//      {bin | -1, attention weight, lw, lh} per sample, laid out (b h, level, q, p);
+//   1. SCAN: the workgroup reads the records of its chunk (coalesced, L2-resident: all workgroups of a (b, h) run on one
+//      XCD) and keeps those whose bin lies in its tile — ballot compaction, so the kept list is in sample order.  No sort of
+//      the whole sample set: filtering 16 x redundantly costs less than the counting sort did (5 launches, ~110 us);
+//   2. every MSDA_T_CAP kept records (and at the end): stable counting sort of the list by bin inside LDS (one wavefront
+//      per quarter of the list, LDS atomics return the rank), then lane groups of D/4 lanes walk the runs of equal bin, bins
+//      of one parity class (x & 1, y & 1) at a time: ONE 128-byte gather of the sample's grad_out row serves all four taps
+//      (the pull formulation gathers it once per tap), four register accumulators per run, added to the tile's LDS cells
+//      at the end of the run — bins of one parity class never share a cell, so plain read-add-write;
+//   3. the tile's 17 x 17 cell block goes to a partial buffer; msda_tile_combine_kernel sums, per token, the <= 4 tiles that
+//      hold its cell x nch chunks in fixed order and stores grad_value (fully overwritten).
+// Every float sum runs in an order fixed by the data layout alone: bit-reproducible.
+constexpr int MSDA_T_MAXL = 8;     // levels the tile path handles
+constexpr int MSDA_T_TS = 16;      // bins per tile edge (at most)
+constexpr int MSDA_T_CW = 17;      // cells per tile edge
+constexpr int MSDA_T_CAP = 3072;   // kept records per sort + accumulate round (list entries: 8 bytes)
+constexpr int MSDA_T_TARGET = 16;  // workgroups per (b, h, level) aimed at
 
 struct MsdaTiles {
-  int L, NT, prows;  // levels, tiles per (b, h), partial rows (tokens incl. halos) per (b, h)
+  int L, NW;                                       // levels, workgroups (= partial tiles) per (b, h)
   int Hl[MSDA_T_MAXL], Wl[MSDA_T_MAXL], lsi[MSDA_T_MAXL];
-  int tsh[MSDA_T_MAXL], ntx[MSDA_T_MAXL];      // log2 of the tile edge, tiles per row
-  int tbase[MSDA_T_MAXL], pbase[MSDA_T_MAXL];  // first tile / first partial row of the level
+  int tsx[MSDA_T_MAXL], tsy[MSDA_T_MAXL];          // bins per tile along x / y (<= 16)
+  int ntx[MSDA_T_MAXL], nty[MSDA_T_MAXL];          // tiles along x / y
+  int nch[MSDA_T_MAXL];                            // sample chunks
+  int wbase[MSDA_T_MAXL];                          // first workgroup of the level
 };
 
-static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, int Nk) {
+static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, int Nk, long SP, int D) {
+  const int tsy_max = D >= 32 ? 8 : 16;  // MsdaTileGeom<D>::TSY
   if (!shapes_host || L < 1 || L > MSDA_T_MAXL) return false;
-  static const int ts0 = [] { const char* e = getenv("RSCOTR_MSDA_TS"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 16) ? v : 16; }();
-  int maxdim0 = 1;
-  for (int l = 0; l < L; ++l) maxdim0 = std::max<int>(maxdim0, (int)std::max(shapes_host[2 * l], shapes_host[2 * l + 1]));
+  static const int target = [] { const char* e = getenv("RSCOTR_MSDA_TILE_WGS"); const int v = e ? atoi(e) : MSDA_T_TARGET; return v > 0 ? v : MSDA_T_TARGET; }();
   T->L = L;
-  int tiles = 0, prows = 0, tok = 0;
+  int nw = 0, tok = 0;
   for (int l = 0; l < L; ++l) {
     const int Hh = (int)shapes_host[2 * l], Ww = (int)shapes_host[2 * l + 1];
-    if (Hh < 1 || Ww < 1) return false;
-    int ts = ts0;
-    for (int d = std::max(Hh, Ww); 2 * d <= maxdim0 + d / 2 && ts > 2; d *= 2) ts >>= 1;  // one halving per octave below the largest level
-    int tsh = 0;
-    while ((1 << tsh) < ts) ++tsh;
-    T->Hl[l] = Hh; T->Wl[l] = Ww; T->lsi[l] = tok; T->tsh[l] = tsh;
-    T->ntx[l] = (Ww + ts - 1) >> tsh;
-    const int nty = (Hh + ts - 1) >> tsh;
-    T->tbase[l] = tiles; T->pbase[l] = prows;
-    tiles += T->ntx[l] * nty;
-    prows += T->ntx[l] * nty * (ts + 1) * (ts + 1);
+    if (Hh < 1 || Ww < 1 || Hh > 32766 || Ww > 32766) return false;
+    T->Hl[l] = Hh; T->Wl[l] = Ww; T->lsi[l] = tok;
+    T->ntx[l] = (Ww + 1 + MSDA_T_TS - 1) / MSDA_T_TS;
+    T->nty[l] = (Hh + 1 + tsy_max - 1) / tsy_max;
+    T->tsx[l] = (Ww + 1 + T->ntx[l] - 1) / T->ntx[l];
+    T->tsy[l] = (Hh + 1 + T->nty[l] - 1) / T->nty[l];
+    const long tiles = (long)T->ntx[l] * T->nty[l];
+    long nch = (target + tiles / 2) / tiles;
+    nch = std::max<long>(1, std::min<long>(std::min<long>(nch, 64), SP / 512));
+    T->nch[l] = (int)nch;
+    T->wbase[l] = nw;
+    if (tiles * nch > (1 << 20)) return false;
+    nw += (int)(tiles * nch);
     tok += Hh * Ww;
   }
   for (int l = L; l < MSDA_T_MAXL; ++l) {
-    T->Hl[l] = T->Wl[l] = 1; T->lsi[l] = tok; T->tsh[l] = 1; T->ntx[l] = 1; T->tbase[l] = tiles; T->pbase[l] = prows;
+    T->Hl[l] = T->Wl[l] = 1; T->lsi[l] = tok; T->tsx[l] = T->tsy[l] = 2; T->ntx[l] = T->nty[l] = 1; T->nch[l] = 1; T->wbase[l] = nw;
   }
-  T->NT = tiles; T->prows = prows;
-  return tok == Nk && tiles <= MSDA_T_MAXNT;
+  T->NW = nw;
+  return tok == Nk && nw <= (1 << 20);
 }
 
 struct MsdaTileWs {
-  long tbl, rec, part, total;  // byte offsets
-  int NCH;
+  long rec, binw, part, total;  // byte offsets
 };
 
-static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, long S, int D) {
+static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, long SP, int D) {
   MsdaTileWs w;
-  w.NCH = (int)((S + MSDA_T_CH - 1) / MSDA_T_CH);
   long o = 0;
-  w.tbl = o; o += (long)BH * w.NCH * T.NT * 8;
-  o = (o + 15) & ~15L;
-  w.rec = o; o += (long)BH * S * 16;
-  w.part = o; o += (long)BH * T.prows * D * 4;
+  w.rec = o; o += (long)BH * T.L * SP * 16;
+  w.binw = o; o += (long)BH * T.L * ((SP + 3) & ~3L) * 4;  // (rows padded to whole 16-byte loads)
+  w.part = o; o += (long)BH * T.NW * MSDA_T_CW * ((D >= 32 ? 8 : 16) + 1) * D * 4;
   w.total = o;
   return w;
 }
 
-template <int P>
-__global__ __launch_bounds__(64) void msda_tile_part_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                            int2* __restrict__ tbl, int4* __restrict__ rec, MsdaTiles T,
-                                                            int Nq, int H, int S, int NCH) {
-  __shared__ int run[MSDA_T_MAXNT], off[MSDA_T_MAXNT];
-  __shared__ int gH[MSDA_T_MAXL], gW[MSDA_T_MAXL], gS[MSDA_T_MAXL], gN[MSDA_T_MAXL], gB[MSDA_T_MAXL];
-  constexpr int R = MSDA_T_CH / 64;
-  const int lane = threadIdx.x, chunk = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int LP = T.L * P;
-  if (lane < MSDA_T_MAXL) {
-    gH[lane] = T.Hl[lane]; gW[lane] = T.Wl[lane]; gS[lane] = T.tsh[lane]; gN[lane] = T.ntx[lane]; gB[lane] = T.tbase[lane];
+// Per-D geometry of the tile kernel: TB threads own one BIN (two for D >= 32: CH = D / TB channels each), 256 threads per
+// workgroup, so a tile has 256 / TB bins: 16 x 16 (D = 16) or 16 x 8 (D = 32, 64).
+template <int D>
+struct MsdaTileGeom {
+  static constexpr int TB = D >= 32 ? 2 : 1;
+  static constexpr int CH = D / TB;
+  static constexpr int V = CH / 4;                 // float4 per thread and row
+  static constexpr int U = CH <= 16 ? 4 : 2;       // samples in flight per thread in the walk
+  static constexpr int TSY = 256 / TB / MSDA_T_TS;  // bins per tile along y
+  static constexpr int NBIN = MSDA_T_TS * TSY;
+  static constexpr int NCELL = MSDA_T_CW * (TSY + 1);
+  static constexpr size_t lds_bytes() {
+    return (size_t)NCELL * D * 4 + (size_t)MSDA_T_CAP * (4 + 2 + 2) + (4 * NBIN + NBIN + 4 + 8 + 4) * 4;
   }
-  for (int i = lane; i < T.NT; i += 64) run[i] = 0;
-  __syncthreads();
-  float2 xy[R];
-  int key[R], rank[R];
-  const long rowbase = ((long)b * Nq * H + h) * LP;  // + q * H * LP + lp
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
-    xy[j] = make_float2(-9.f, -9.f);  // "outside": no bin
-    if (sid < S) {
-      const int q = sid / LP, lp = sid - q * LP;
-      xy[j] = *reinterpret_cast<const float2*>(loc + (rowbase + (long)q * H * LP + lp) * 2);
-    }
-  }
-  const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
-    const int lp = sid % LP, l = lp / P;
-    const int Hl = gH[l], Wl = gW[l];
-    const float h_im = xy[j].y * (float)Hl - 0.5f, w_im = xy[j].x * (float)Wl - 0.5f;
-    const bool in = sid < S && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
-    int k = -1;
-    if (in) {
-      const int x0 = (int)floorf(w_im), y0 = (int)floorf(h_im);
-      const int tsh = gS[l];
-      k = gB[l] + (max(y0, 0) >> tsh) * gN[l] + (max(x0, 0) >> tsh);
-    }
-    // stable rank among the lanes of equal tile (wave-uniform loop over the distinct tiles of this round)
-    int rk = 0, cnt = 0;
-    bool leader = false;
-    unsigned long long rem = __ballot(k >= 0);
-    while (rem) {
-      const int src = __ffsll((long long)rem) - 1;
-      const int kk = __shfl(k, src, 64);
-      const unsigned long long m = __ballot(k == kk);
-      if (k == kk) {
-        rk = __popcll(m & below);
-        cnt = __popcll(m);
-        leader = lane == src;
-      }
-      rem &= ~m;
-    }
-    const int old = k >= 0 ? run[k] : 0;  // every lane reads before the leaders write (one wavefront, program order)
-    if (leader) run[k] = old + cnt;
-    key[j] = k;
-    rank[j] = old + rk;
-  }
-  __syncthreads();
-  {  // exclusive scan of the chunk's per-tile totals -> off[]; table row of the chunk
-    const int per = (T.NT + 63) / 64;
-    const int i0 = min(T.NT, lane * per), i1 = min(T.NT, i0 + per);
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += run[i];
-    int inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    int r = inc - sum;
-    int2* row = tbl + ((long)bh * NCH + chunk) * T.NT;
-    for (int i = i0; i < i1; ++i) {
-      const int c = run[i];
-      off[i] = r;
-      row[i] = make_int2(r, c);
-      r += c;
-    }
-  }
-  __syncthreads();
-  int4* out = rec + (long)bh * S + (long)chunk * MSDA_T_CH;
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    if (key[j] < 0) continue;
-    const int sid = chunk * MSDA_T_CH + j * 64 + lane;
-    const int q = sid / LP, lp = sid - q * LP, l = lp / P;
-    const int Hl = gH[l], Wl = gW[l], tsh = gS[l];
-    const float h_im = xy[j].y * (float)Hl - 0.5f, w_im = xy[j].x * (float)Wl - 0.5f;
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int x0 = (int)wf, y0 = (int)hf;
-    // local top-left cell (+1: -1 .. ts-1 -> 0 .. ts) inside the tile's block
-    const int lx = x0 - ((max(x0, 0) >> tsh) << tsh) + 1, ly = y0 - ((max(y0, 0) >> tsh) << tsh) + 1;
-    const float a = attn[rowbase + (long)q * H * LP + lp];
-    out[off[key[j]] + rank[j]] = make_int4(q | (lx << 20) | (ly << 25), __float_as_int(a), __float_as_int(w_im - wf),
-                                           __float_as_int(h_im - hf));
-  }
-}
-
-struct TileRec {
-  int4 r;
-  bool ok;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void msda_tile_acc_kernel(const float* __restrict__ grad_out, const int2* __restrict__ tbl,
-                                                            const int4* __restrict__ rec, float* __restrict__ part, MsdaTiles T,
-                                                            int Nq, int H, int S, int NCH, int BH) {
-  constexpr int G = D / 4, SPW = kWave / G, U = 2;  // lanes per sample, samples per wavefront step, steps per iteration
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int s_scan[2][4];
-  const int bh = blockIdx.x % BH, tile = blockIdx.x / BH;  // blockIdx % 8 == head (H = 8): one head's grad_out rows per XCD's L2
-  const int b = bh / H, h = bh - b * H;
-  int l = 0;
-  while (l + 1 < T.L && tile >= T.tbase[l + 1]) ++l;
-  const int tsh = T.tsh[l], ts = 1 << tsh, ntx = T.ntx[l];
-  const int tl = tile - T.tbase[l], ty = tl / ntx, tx = tl - ty * ntx;
-  const int Wl = T.Wl[l], Hl = T.Hl[l];
-  const int bw = ts + 1, ncell = bw * bw;
-  float* acc = smem;                                          // [ncell][D]
-  int* s_pre = reinterpret_cast<int*>(smem + 17 * 17 * D);    // [K + 1] exclusive prefix of the segment lengths
-  int* s_adr = s_pre + NCH + 1;                               // [K] first record of the segment
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < ncell * D; i += 256) acc[i] = 0.f;
-  // non-empty (chunk, tile) segments in chunk order: thread t takes a contiguous run of chunks
-  int K, n;
-  {
-    constexpr int PER = MSDA_T_MAXCH / 256;
-    const int per = (NCH + 255) / 256;
-    int2 e[PER];
-    int mine = 0, msum = 0;
+// exclusive prefix sum of one int per thread over the 256 threads of the workgroup; *total = the sum.  `scratch`: 4 ints
+// of LDS nobody else touches between the two barriers inside.
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = tid * per + i;
-      e[i] = make_int2(0, 0);
-      if (i < per && c < NCH) e[i] = tbl[((long)bh * NCH + c) * T.NT + tile];
-      if (e[i].y > 0) { ++mine; msum += e[i].y; }
-    }
-    int ia = mine, ib = msum;  // inclusive scans over the workgroup
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
-      if (lane >= o) { ia += ta; ib += tb; }
-    }
-    if (lane == 63) { s_scan[0][wave] = ia; s_scan[1][wave] = ib; }
-    __syncthreads();
-    int oa = 0, ob = 0, ta = 0, tb = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) { oa += s_scan[0][w]; ob += s_scan[1][w]; }
-      ta += s_scan[0][w]; tb += s_scan[1][w];
-    }
-    K = ta; n = tb;
-    int k = oa + ia - mine, p = ob + ib - msum;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      if (e[i].y > 0) {
-        s_pre[k] = p;
-        s_adr[k] = (tid * per + i) * MSDA_T_CH + e[i].x;
-        ++k;
-        p += e[i].y;
-      }
-    }
-    if (tid == 0) s_pre[K] = n;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
   }
+  if (lane == 63) scratch[w] = inc;
   __syncthreads();
-
-  const int grp = lane / G, sub = lane - grp * G;
-  const int px = wave & 1, py = wave >> 1;  // tap parity this wavefront owns
-  const int4* rb = rec + (long)bh * S;
-  const float* gb = grad_out + ((long)b * Nq * H + h) * D + sub * 4;
-  const int niter = (n + SPW * U - 1) / (SPW * U);
-  int cur = 0;  // segment cursor of this lane group (its sample index only grows)
-  auto load_rec = [&](int it, TileRec (&r)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = (it * U + u) * SPW + grp;
-      r[u].ok = j < n;
-      r[u].r = make_int4(0, 0, 0, 0);
-      if (r[u].ok) {
-        while (j >= s_pre[cur + 1]) ++cur;
-        r[u].r = rb[s_adr[cur] + (j - s_pre[cur])];
-      }
-    }
-  };
-  auto load_go = [&](const TileRec (&r)[U], float4 (&g)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      g[u] = r[u].ok ? *reinterpret_cast<const float4*>(gb + (long)(r[u].r.x & 0xFFFFF) * H * D) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-  auto accumulate = [&](const TileRec (&r)[U], const float4 (&g)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int cell = -1;
-      float w = 0.f;
-      if (r[u].ok) {
-        const int lx = (r[u].r.x >> 20) & 31, ly = (r[u].r.x >> 25) & 31;  // local top-left cell + 1
-        const int dx = px ^ ((lx + 1) & 1), dy = py ^ ((ly + 1) & 1);      // the tap of this wavefront's parity (ts is even)
-        const int cx = lx - 1 + dx, cy = ly - 1 + dy;
-        const int x = (tx << tsh) + cx, y = (ty << tsh) + cy;
-        if (x >= 0 && y >= 0 && x < Wl && y < Hl) {
-          const float a = __int_as_float(r[u].r.y), lw = __int_as_float(r[u].r.z), lh = __int_as_float(r[u].r.w);
-          w = a * (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
-          cell = cy * bw + cx;
-        }
-      }
-      // The SPW samples of this step may hit the same cell: they are applied in sample order, one round per rank among
-      // the samples of equal cell (plain LDS read-add-write: no LDS float atomics — those run at about one lane per
-      // clock per CU on gfx950 and made this kernel 10x slower).  Nearly always one round.
-      int rank = 0;
-#pragma unroll
-      for (int g2 = 0; g2 < SPW; ++g2) {
-        const int c2 = __shfl(cell, g2 * G, 64);
-        if (g2 < grp && c2 == cell) ++rank;
-      }
-      for (int rd = 0; __any(cell >= 0 && rank >= rd); ++rd) {
-        if (cell >= 0 && rank == rd) {
-          float4* dst = reinterpret_cast<float4*>(acc + cell * D + sub * 4);
-          float4 v = *dst;
-          v.x += w * g[u].x; v.y += w * g[u].y; v.z += w * g[u].z; v.w += w * g[u].w;
-          *dst = v;
-        }
-      }
-    }
-  };
-  if (niter > 0) {  // three-stage software pipeline: records two iterations ahead, grad_out rows one iteration ahead
-    TileRec r0[U], r1[U], r2[U];
-    float4 g0[U], g1[U];
-    load_rec(0, r0);
-    load_rec(1, r1);
-    load_go(r0, g0);
-    for (int it = 0; it < niter; ++it) {
-      load_rec(it + 2, r2);
-      load_go(r1, g1);
-      accumulate(r0, g0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; g0[u] = g1[u]; }
-    }
-  }
+  const int s0 = scratch[0], s1 = scratch[1], s2 = scratch[2], s3 = scratch[3];
+  const int before = (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+  *total = s0 + s1 + s2 + s3;
   __syncthreads();
-  float* prow = part + ((long)bh * T.prows + T.pbase[l] + (long)tl * ncell) * D;
-  for (int i = tid; i < ncell * D; i += 256) prow[i] = acc[i];
+  return before + inc - v;
 }
 
-// grad_value row of every token = own tile's cell + the neighbours' halo cells that alias it, fixed order
+// One 256-thread workgroup per (b, h, level, tile, chunk): see the header of this section.  A thread keeps the four tap
+// rows of ITS bin (its CH channels) in registers for the whole life of the workgroup: the walk over the sorted list needs
+// no barrier and no LDS accumulator — a thread reads the records of its bin in order, gathers each sample's grad_out row
+// (its part) once and feeds the four accumulators; the rows meet in the tile's cells only at the very end.
+template <int D>
+__global__ __launch_bounds__(256) void msda_tile_kernel(const float* __restrict__ go, const int4* __restrict__ rec,
+                                                        const int* __restrict__ binw, float* __restrict__ part, MsdaTiles T,
+                                                        int Nq, int pshift, int H, int BH, int dbg) {
+  using Gm = MsdaTileGeom<D>;
+  constexpr int TB = Gm::TB, CH = Gm::CH, V = Gm::V, U = Gm::U, NBIN = Gm::NBIN, NCELL = Gm::NCELL;
+  constexpr int R = 4;  // consecutive records per thread and scan round (one 16-byte load of bin words)
+  extern __shared__ __attribute__((aligned(16))) float t_lds[];
+  float* acc = t_lds;                                                   // [NCELL][D] (filled at the very end)
+  int* lrec = reinterpret_cast<int*>(acc + NCELL * D);                  // [CAP] sample index << 8 | local bin (kept list)
+  unsigned short* order = reinterpret_cast<unsigned short*>(lrec + MSDA_T_CAP);  // [CAP] list positions sorted by bin
+  unsigned short* rank = order + MSDA_T_CAP;                            // [CAP]
+  int* hist = reinterpret_cast<int*>(rank + MSDA_T_CAP);                // [4][NBIN]
+  int* binstart = hist + 4 * NBIN;                                      // [NBIN + 1]
+  int* wtot = binstart + NBIN + 4;                                      // [2][4] kept records per wavefront (two buffers)
+  int* scratch = wtot + 8;                                              // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // all workgroups of a (b, h) on one XCD (round-robin dispatch: XCD = id % 8): its records, grad_out slices and
+  // partial tiles stay in that L2
+  const int x8 = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int bh = x8 + 8 * (j / T.NW), e = j % T.NW;
+  if (bh >= BH) return;
+  const int b = bh / H, h = bh - b * H;
+  int l = 0;
+  while (l + 1 < T.L && e >= T.wbase[l + 1]) ++l;
+  const int r = e - T.wbase[l];
+  const int nch = T.nch[l], chunk = r % nch, tile = r / nch;
+  const int ty = tile / T.ntx[l], tx = tile - ty * T.ntx[l];
+  const int bx0 = tx * T.tsx[l], by0 = ty * T.tsy[l], bx1 = bx0 + T.tsx[l], by1 = by0 + T.tsy[l];
+  const int SP = Nq << pshift;  // (< 2^23: the host checks Nq < 2^20; a multiple of 4 or the host keeps nch = 1 ... see c0)
+  // chunk bounds on multiples of 4 records (16-byte loads of bin words)
+  const int c0 = (int)((long)SP * chunk / nch) & ~3, c1 = chunk + 1 == nch ? SP : (int)((long)SP * (chunk + 1) / nch) & ~3;
+  const int4* src = rec + ((long)bh * T.L + l) * SP;
+  const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
+
+  const int bin = tid / TB, sub = tid % TB;  // this thread's bin and channel part
+  const float* gob = go + ((long)b * Nq * H + h) * D + sub * CH;  // + q * H * D
+  const int qstride = H * D;
+  float4 a1[V], a2[V], a3[V], a4[V];  // the bin's four tap rows (this thread's channels)
+#pragma unroll
+  for (int v = 0; v < V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // sort the n kept records by bin (stable), then every thread adds the records of its bin to its accumulators
+  auto flush = [&](int n) {
+    if (dbg == 1) return;
+    for (int i = tid; i < 4 * NBIN; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int nw = ((n + 3) / 4 + 63) & ~63;  // records per wavefront (whole rounds of 64)
+    const int i0 = w * nw, i1 = min(n, i0 + nw);
+    // one wavefront walks its quarter in program order: the rank inside (wavefront, bin) depends on the data only
+    for (int i = i0 + lane; i < i1; i += 64) rank[i] = (unsigned short)atomicAdd(&hist[w * NBIN + (lrec[i] & 255)], 1);
+    __syncthreads();
+    {
+      int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+      if (tid < NBIN) { h0 = hist[tid]; h1 = hist[NBIN + tid]; h2 = hist[2 * NBIN + tid]; h3 = hist[3 * NBIN + tid]; }
+      int total;
+      const int start = block_exclusive_scan_256(h0 + h1 + h2 + h3, scratch, &total);
+      if (tid < NBIN) {
+        binstart[tid] = start;
+        hist[tid] = start; hist[NBIN + tid] = start + h0; hist[2 * NBIN + tid] = start + h0 + h1; hist[3 * NBIN + tid] = start + h0 + h1 + h2;
+      }
+      if (tid == 0) binstart[NBIN] = total;
+    }
+    __syncthreads();
+    for (int i = i0 + lane; i < i1; i += 64) order[hist[w * NBIN + (lrec[i] & 255)] + rank[i]] = (unsigned short)i;
+    __syncthreads();
+    if (dbg == 2) return;
+    const int s0 = binstart[bin], s1 = binstart[bin + 1];
+#pragma unroll 1
+    for (int i = s0; i < s1; i += U) {  // U samples in flight per thread, applied in list (= sample) order
+      int4 rr[U];
+      float4 g[U][V];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int sidx = lrec[order[min(i + u, s1 - 1)]] >> 8;
+        if (dbg == 3) sidx = c0 + (sidx & 63);  // (experiment: every gather a cache hit)
+        rr[u] = src[sidx];  // (re-read: L2-hot, the sample kernel has just written it)
+        const float4* row = reinterpret_cast<const float4*>(gob + (long)(sidx >> pshift) * qstride);
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[u][v] = row[v];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i + u < s1) {
+          const float aw = __int_as_float(rr[u].y), lw = __int_as_float(rr[u].z), lh = __int_as_float(rr[u].w);
+          const float hw = 1.f - lw, hh = 1.f - lh;
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float4 top = scale4(g[u][v], aw);
+            a1[v].x += top.x * w1; a1[v].y += top.y * w1; a1[v].z += top.z * w1; a1[v].w += top.w * w1;
+            a2[v].x += top.x * w2; a2[v].y += top.y * w2; a2[v].z += top.z * w2; a2[v].w += top.w * w2;
+            a3[v].x += top.x * w3; a3[v].y += top.y * w3; a3[v].z += top.z * w3; a3[v].w += top.w * w3;
+            a4[v].x += top.x * w4; a4[v].y += top.y * w4; a4[v].z += top.z * w4; a4[v].w += top.w * w4;
+          }
+        }
+      }
+    }
+    __syncthreads();  // (the lists are rewritten by the scan that follows)
+  };
+
+  // scan: one 16-byte load of R = 4 consecutive bin words per thread and round (one barrier per 1024 records), two rounds
+  // requested ahead; the kept list is in sample order (thread-major inside a round = index order)
+  int n = 0, it = 0;
+  const int4 none = make_int4(-1, -1, -1, -1);
+  auto fetch = [&](int base) {
+    const int i = base + tid * R;
+    return i < c1 ? *reinterpret_cast<const int4*>(bsrc + i) : none;  // (c1 on a multiple of 4 or the padded end)
+  };
+  int4 nx0 = fetch(c0), nx1 = fetch(c0 + 256 * R);
+  for (int base = c0; base < c1; base += 256 * R, ++it) {
+    const int4 c4 = nx0;
+    nx0 = nx1;
+    nx1 = fetch(base + 2 * 256 * R);
+    const int cur[R] = {c4.x, c4.y, c4.z, c4.w};
+    bool sel[R];
+    int before = 0, wsum = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int bx = cur[k] & 0xffff, by = cur[k] >> 16;  // (-1: by = -1: outside every tile)
+      sel[k] = cur[k] >= 0 && bx >= bx0 && bx < bx1 && by >= by0 && by < by1 && base + tid * R + k < SP;
+      const unsigned long long m = __ballot(sel[k]);
+      before += __popcll(m & ((1ull << lane) - 1ull));
+      wsum += __popcll(m);
+    }
+    int* wt = wtot + (it & 1) * 4;
+    if (lane == 0) wt[w] = wsum;
+    __syncthreads();
+    const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
+    int pos = n + before + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (sel[k]) {
+        const int bx = cur[k] & 0xffff, by = cur[k] >> 16;
+        lrec[pos++] = ((base + tid * R + k) << 8) | ((by - by0) * MSDA_T_TS + (bx - bx0));
+      }
+    }
+    n += t0 + t1 + t2 + t3;
+    if (n > MSDA_T_CAP - 256 * R) {
+      __syncthreads();
+      flush(n);
+      n = 0;
+    }
+  }
+  __syncthreads();
+  if (n > 0) flush(n);
+  // the bins' tap rows meet in the tile's cells: tap k of bin (x, y) belongs to cell (x + (k & 1), y + (k >> 1)); one tap
+  // at a time, so that no two threads touch a cell together and every cell sums its (at most four) rows in tap order
+  for (int i = tid; i < NCELL * D / 4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    const int lbx = bin & (MSDA_T_TS - 1), lby = bin / MSDA_T_TS;
+    float4* c = reinterpret_cast<float4*>(acc + (lby * MSDA_T_CW + lbx) * D + sub * CH);
+    constexpr int CS = D / 4;  // float4 per cell
+    auto add = [](float4* p, const float4& v) { float4 o = *p; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *p = o; };
+#pragma unroll
+    for (int v = 0; v < V; ++v) add(c + v, a1[v]);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; ++v) add(c + CS + v, a2[v]);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, a3[v]);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, a4[v]);
+    __syncthreads();
+  }
+  float4* dst = reinterpret_cast<float4*>(part + ((long)bh * T.NW + e) * NCELL * D);
+  for (int i = tid; i < NCELL * D / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(acc)[i];
+}
+
+// grad_value row of every token = the cells that alias it in the (at most four) tiles that hold it, every sample chunk, in
+// fixed order.  D/4 lanes per token; workgroups mapped like msda_tile_kernel (one XCD per (b, h)).
 template <int D>
 __global__ __launch_bounds__(256) void msda_tile_combine_kernel(const float* __restrict__ part, float* __restrict__ grad_value,
-                                                                MsdaTiles T, int Nk, int H, int BH) {
-  constexpr int G = D / 4;
-  const long total = (long)BH * Nk * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c4 = (int)(i % G);
-    const long r = i / G;
-    const int tok = (int)(r % Nk), bh = (int)(r / Nk);
-    const int b = bh / H, h = bh - b * H;
-    int l = 0;
-    while (l + 1 < T.L && tok >= T.lsi[l + 1]) ++l;
-    const int Wl = T.Wl[l], tsh = T.tsh[l], ts = 1 << tsh, bw = ts + 1, ntx = T.ntx[l];
-    const int rr = tok - T.lsi[l], y = rr / Wl, x = rr - y * Wl;
-    const int tx = x >> tsh, ty = y >> tsh, lx = x & (ts - 1), ly = y & (ts - 1);
-    const float* base = part + ((long)bh * T.prows + T.pbase[l]) * D + c4 * 4;
-    auto cellp = [&](int ttx, int tty, int cy, int cx) {
-      return *reinterpret_cast<const float4*>(base + ((long)(tty * ntx + ttx) * bw * bw + cy * bw + cx) * D);
-    };
-    float4 v = cellp(tx, ty, ly, lx);
-    if (lx == 0 && tx > 0) { const float4 u = cellp(tx - 1, ty, ly, ts); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    if (ly == 0 && ty > 0) { const float4 u = cellp(tx, ty - 1, ts, lx); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    if (lx == 0 && tx > 0 && ly == 0 && ty > 0) { const float4 u = cellp(tx - 1, ty - 1, ts, ts); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + tok) * H + h) * D + c4 * 4) = v;
-  }
+                                                                MsdaTiles T, int Nk, int H, int BH, int bpb) {
+  constexpr int G = D / 4, TPB = 256 / G;
+  constexpr int NCELL = MsdaTileGeom<D>::NCELL;
+  const int x8 = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int bh = x8 + 8 * (j / bpb), blk = j % bpb;
+  if (bh >= BH) return;
+  const int tok = blk * TPB + threadIdx.x / G, c4 = threadIdx.x % G;
+  if (tok >= Nk) return;
+  const int b = bh / H, h = bh - b * H;
+  int l = 0;
+  while (l + 1 < T.L && tok >= T.lsi[l + 1]) ++l;
+  const int Wl = T.Wl[l], tsx = T.tsx[l], tsy = T.tsy[l], ntx = T.ntx[l], nch = T.nch[l];
+  const int rr = tok - T.lsi[l], y = rr / Wl, x = rr - y * Wl;
+  const int cx = x + 1, cy = y + 1;  // extended-grid cell of the token
+  const int tx = cx / tsx, ty = cy / tsy, lx = cx - tx * tsx, ly = cy - ty * tsy;
+  const float* base = part + ((long)bh * T.NW + T.wbase[l]) * NCELL * D + c4 * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto tile_cells = [&](int ttx, int tty, int ccy, int ccx) {
+    const float* p = base + ((long)(tty * ntx + ttx) * nch * NCELL + ccy * MSDA_T_CW + ccx) * D;
+    for (int c = 0; c < nch; ++c) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (long)c * NCELL * D);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+  };
+  const bool hx = lx == 0 && tx > 0, hy = ly == 0 && ty > 0;  // also the halo column / row of the left / upper tile
+  if (hx && hy) tile_cells(tx - 1, ty - 1, tsy, tsx);
+  if (hy) tile_cells(tx, ty - 1, tsy, lx);
+  if (hx) tile_cells(tx - 1, ty, ly, tsx);
+  tile_cells(tx, ty, ly, lx);
+  *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + tok) * H + h) * D + c4 * 4) = v;
 }
 
 template <int D, int P>
@@ -1081,24 +1076,29 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
                              const MsdaTiles& T, char* ws, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
+  const size_t shm = (size_t)QB * L * P * 10 * sizeof(float);  // + 16-byte records staged for a coalesced store
   const int BH = B * H;
-  const long S = (long)Nq * L * P;
-  const MsdaTileWs W = msda_tile_ws(T, BH, S, D);
-  int2* tbl = reinterpret_cast<int2*>(ws + W.tbl);
+  const long SP = (long)Nq * P;
+  const MsdaTileWs W = msda_tile_ws(T, BH, SP, D);
   int4* rec = reinterpret_cast<int4*>(ws + W.rec);
+  int* binw = reinterpret_cast<int*>(ws + W.binw);
   float* part = reinterpret_cast<float*>(ws + W.part);
-  msda_tile_part_kernel<P><<<dim3(W.NCH, BH), 64, 0, s>>>(loc, attn, tbl, rec, T, Nq, H, (int)S, W.NCH);
-  // grad_loc / grad_attn by sample (independent of the partition: the two kernels overlap at the launch boundary)
+  // grad_loc / grad_attn by sample + one record and one bin word per sample
   msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, Nk, Nq, H, L, ntiles, 0);
-  const size_t acc_lds = ((size_t)17 * 17 * D + 2 * (W.NCH + 1)) * sizeof(float);
-  if (acc_lds > 48 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_acc_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)acc_lds);
-  msda_tile_acc_kernel<D><<<dim3((unsigned)((long)BH * T.NT)), 256, acc_lds, s>>>(go, tbl, rec, part, T, Nq, H, (int)S, W.NCH, BH);
-  const long items = (long)BH * Nk * (D / 4);
-  msda_tile_combine_kernel<D><<<(unsigned)std::min<long>((items + 255) / 256, 4096), 256, 0, s>>>(part, gv, T, Nk, H, BH);
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, rec, binw, Nk, Nq, H, L, ntiles, 0);
+  constexpr size_t lds = MsdaTileGeom<D>::lds_bytes();
+  static const bool attr_set = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return true;
+  }();
+  (void)attr_set;
+  const unsigned bh8 = (unsigned)((BH + 7) / 8) * 8;
+  static const int dbg = [] { const char* e = getenv("RSCOTR_MSDA_TILE_DBG"); return e ? atoi(e) : 0; }();
+  int pshift = 0;
+  while ((1 << pshift) < P) ++pshift;
+  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, part, T, Nq, pshift, H, BH, dbg);
+  const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
+  msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1135,7 +1135,7 @@ static void launch_bwd(const float* value, const int64_t* shapes, const int64_t*
   const int ntiles = (Nq + QB - 1) / QB;
   const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
   msda_bwd_kernel<D, P, 1><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, Nk, Nq, H, L, ntiles, 0);
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, 0);
 }
 
 // sorted / pull strategy: grad_loc + grad_attn by sample, grad_value by destination token
@@ -1162,10 +1162,10 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
     // grad_value zeroed for the scatter the sample kernel falls back to; on the sorted path the pull kernel overwrites it
     hipMemsetAsync(gv, 0, (size_t)B * Nk * H * D * sizeof(float), s);
     msda_bwd_kernel<D, P, 2><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, Nk, Nq, H, L, ntiles, W.lds_words);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, W.lds_words);
   } else {
     msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, Nk, Nq, H, L, ntiles, 0);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, 0);
   }
   msda_binsum_kernel<<<dim3((W.NEmax + 255) / 256, BH), 256, 0, s>>>(shapes, ws, W, L);
   msda_plan_kernel<D><<<BH, 1024, hist_lds, s>>>(shapes, lsi, ws, W, gv, Nk, H, L);
@@ -1233,10 +1233,8 @@ extern "C" int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L
 extern "C" int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L,
                                                    int P) {
   MsdaTiles T;
-  if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || !msda_tiles_build(&T, shapes_host, L, Nk)) return 0;
-  const long S = (long)Nq * L * P;
-  if ((S + MSDA_T_CH - 1) / MSDA_T_CH > MSDA_T_MAXCH || Nq >= (1 << 20)) return 0;
-  return msda_tile_ws(T, B * H, S, D).total;
+  if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || Nq >= (1 << 20) || !msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) return 0;
+  return msda_tile_ws(T, B * H, (long)Nq * P, D).total;
 }
 
 extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes,
@@ -1255,11 +1253,11 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: read value, read-modify-write grad_value, read loc/attn/grad_out, write grad_loc/grad_attn
   ProfScope prof(PROF_MSDA_BWD, 4.0 * B * (3.0 * Nk * H * D + (double)Nq * H * L * P * 6 + (double)Nq * H * D), s,
-                 "rscotr_msda_bwd<%d, %d> (hist + sample + plan + fill + pull kernels)", D, P);
+                 "rscotr_msda_bwd<%d, %d> (sample + tile + combine kernels)", D, P);
   if (workspace && shapes_host && Nk > 0) {
     MsdaTiles T;
     const int64_t need_t = rscotr_msda_bwd_tiled_workspace(shapes_host, B, Nk, Nq, H, D, L, P);
-    if (need_t > 0 && workspace_bytes >= need_t && msda_tiles_build(&T, shapes_host, L, Nk)) {
+    if (need_t > 0 && workspace_bytes >= need_t && msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) {
       if (!aligned16(workspace)) return fail(RSCOTR_E_ALIGN, "rscotr_msda_bwd: workspace must be 16-byte aligned");
 #define CALL(DD, PP)                                                                                    \
   launch_bwd_tiled<DD, PP>(value, spatial_shapes, level_start_index, loc, attn, grad_out, grad_value, \

@@ -228,9 +228,10 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 # multi-scale deformable attention sampling (mmcv MultiScaleDeformableAttnFunction contract)
 # ------------------------------------------------------------------------------------------
-# 'sorted' (default): counting sort by destination token + pull, bit-reproducible; 'tiled': per-tile LDS accumulation in
-# sample order, bit-reproducible, slower; 'scatter': atomic accumulation (order-dependent).  Tests run all three.
-MSDA_BWD_STRATEGY = os.environ.get('RSCOTR_MSDA_BWD', 'sorted')
+# 'tiled' (default): per-tile scan + LDS sort + register accumulation in sample order, bit-reproducible, 3 launches;
+# 'sorted': counting sort by destination token + pull, bit-reproducible, 8 launches; 'scatter': atomic accumulation
+# (order-dependent).  Tests run all three.
+MSDA_BWD_STRATEGY = os.environ.get('RSCOTR_MSDA_BWD', 'tiled')
 
 # host copies of the level-shape tensors (the mmcv contract keeps spatial_shapes on the device; the tile-accumulation
 # backward sizes its launches from the shapes): data_ptr -> int64 numpy array, registered by whoever builds the device
