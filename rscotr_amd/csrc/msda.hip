@@ -171,6 +171,14 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) {
   return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
 }
 
+// Tile geometry the sample kernel needs for the BLOCK MASKS of the tile-accumulation backward (see that section): per level,
+// reciprocal tile edges (in bins) and tiles per row.  mask[(b h, level, query tile of the sample kernel)] has bit
+// (tile & 63) set iff one of the block's samples has its bin in that tile: the tile workgroups skip the other blocks.
+struct MsdaMaskGeom {
+  float itx[8], ity[8];
+  int ntx[8];
+};
+
 // SCATTER: 0 = grad_loc / grad_attn only (grad_value comes from the pull kernel), 1 = also scatter grad_value with
 // atomics, 2 = scatter iff the level pyramid has more than `bins_cap` extended bins (the sorted path stood down).
 template <int D, int P, int SCATTER>
@@ -179,7 +187,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attn, const float* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int4* __restrict__ rec, int* __restrict__ binw, int Nk, int Nq, int H, int L, int ntiles, int bins_cap) {
+    int4* __restrict__ rec, int* __restrict__ binw, unsigned long long* __restrict__ mask, MsdaMaskGeom MG, int Nk, int Nq,
+    int H, int L, int ntiles, int bins_cap) {
   constexpr int G = D / 4;
   constexpr int QW = kWave / G;
   constexpr int QB = 4 * QW;
@@ -199,6 +208,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
   // weight, lw, lh} per sample, laid out (b h, level, q, p); staged [L][QB][P] for a coalesced store (the launch then
   // brings QB * LP * 16 more bytes of LDS)
   int4* s_rec = reinterpret_cast<int4*>(smem + QB * LP * 6);
+  unsigned* s_mask = reinterpret_cast<unsigned*>(smem + QB * LP * 10);  // [L][2] (rec != nullptr only)
+  if (rec && threadIdx.x < 2 * L) s_mask[threadIdx.x] = 0u;  // (ordered before the atomics by the barrier below)
 
   const int bid = blockIdx.x;
   const int h = bid % H;
@@ -281,9 +292,14 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       ga = group_sum<G>(ga);
       if (sub == 0) {
         const bool in = g[p].in;
-        if (rec)
+        if (rec) {
           s_rec[(l * QB + r) * P + p] = make_int4(in ? ((g[p].h_low + 1) << 16) | (g[p].w_low + 1) : -1, __float_as_int(aw[p]),
                                                   __float_as_int(lw), __float_as_int(lh));
+          if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
+            const int t = (int)(((float)(g[p].h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(g[p].w_low + 1) + 0.5f) * MG.itx[l]);
+            atomicOr(&s_mask[2 * l + ((t >> 5) & 1)], 1u << (t & 31));
+          }
+        }
         s_gloc[(r * LP + l * P + p) * 2 + 0] = in ? (float)Wl * gw : 0.f;
         s_gloc[(r * LP + l * P + p) * 2 + 1] = in ? (float)Hl * gh : 0.f;
         s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
         binw[((long)(b * H + h) * L + l) * ((SP + 3) & ~3L) + (long)q0 * P + rem] = s_rec[i].x;  // (the scan reads these only)
       }
     }
+    if (tid < L) mask[((long)(b * H + h) * L + tid) * ntiles + tile] = (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
   }
 }
 
@@ -768,6 +785,10 @@ constexpr int MSDA_T_TS = 16;      // bins per tile edge (at most)
 constexpr int MSDA_T_CW = 17;      // cells per tile edge
 constexpr int MSDA_T_CAP = 3072;   // kept records per sort + accumulate round (list entries: 8 bytes)
 constexpr int MSDA_T_TARGET = 16;  // workgroups per (b, h, level) aimed at
+#ifndef MSDA_T_OCC
+#define MSDA_T_OCC(D) ((D) <= 32 ? 3 : 2)
+#endif
+constexpr int MSDA_T_SEGB = 2048;  // blocks of the sample kernel per scan segment (their numbers live in LDS)
 
 struct MsdaTiles {
   int L, NW;                                       // levels, workgroups (= partial tiles) per (b, h)
@@ -809,14 +830,18 @@ static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, in
 }
 
 struct MsdaTileWs {
-  long rec, binw, part, total;  // byte offsets
+  long rec, binw, mask, part, total;  // byte offsets
 };
 
-static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, long SP, int D) {
+static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, int Nq, int P, int D) {
   MsdaTileWs w;
+  const long SP = (long)Nq * P;
   long o = 0;
   w.rec = o; o += (long)BH * T.L * SP * 16;
   w.binw = o; o += (long)BH * T.L * ((SP + 3) & ~3L) * 4;  // (rows padded to whole 16-byte loads)
+  const int QB = 4 * (kWave / (D / 4));  // queries per workgroup of the sample kernel
+  const long nqt = (Nq + QB - 1) / QB;
+  w.mask = o; o += (((long)BH * T.L * nqt * 8) + 15) & ~15L;
   w.part = o; o += (long)BH * T.NW * MSDA_T_CW * ((D >= 32 ? 8 : 16) + 1) * D * 4;
   w.total = o;
   return w;
@@ -834,7 +859,7 @@ struct MsdaTileGeom {
   static constexpr int NBIN = MSDA_T_TS * TSY;
   static constexpr int NCELL = MSDA_T_CW * (TSY + 1);
   static constexpr size_t lds_bytes() {
-    return (size_t)NCELL * D * 4 + (size_t)MSDA_T_CAP * (4 + 2 + 2) + (4 * NBIN + NBIN + 4 + 8 + 4) * 4;
+    return (size_t)NCELL * D * 4 + (size_t)MSDA_T_CAP * (4 + 2 + 2) + (4 * NBIN + NBIN + 4 + 8 + 4) * 4 + MSDA_T_SEGB * 2;
   }
 };
 
@@ -862,9 +887,10 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int
 // no barrier and no LDS accumulator — a thread reads the records of its bin in order, gathers each sample's grad_out row
 // (its part) once and feeds the four accumulators; the rows meet in the tile's cells only at the very end.
 template <int D>
-__global__ __launch_bounds__(256) void msda_tile_kernel(const float* __restrict__ go, const int4* __restrict__ rec,
-                                                        const int* __restrict__ binw, float* __restrict__ part, MsdaTiles T,
-                                                        int Nq, int pshift, int H, int BH, int dbg) {
+__global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const float* __restrict__ go, const int4* __restrict__ rec,
+                                                        const int* __restrict__ binw, const unsigned long long* __restrict__ mask,
+                                                        float* __restrict__ part, MsdaTiles T, int Nq, int pshift, int bshift,
+                                                        int nqt, int H, int BH, int dbg) {
   using Gm = MsdaTileGeom<D>;
   constexpr int TB = Gm::TB, CH = Gm::CH, V = Gm::V, U = Gm::U, NBIN = Gm::NBIN, NCELL = Gm::NCELL;
   constexpr int R = 4;  // consecutive records per thread and scan round (one 16-byte load of bin words)
@@ -877,6 +903,7 @@ __global__ __launch_bounds__(256) void msda_tile_kernel(const float* __restrict_
   int* binstart = hist + 4 * NBIN;                                      // [NBIN + 1]
   int* wtot = binstart + NBIN + 4;                                      // [2][4] kept records per wavefront (two buffers)
   int* scratch = wtot + 8;                                              // [4]
+  unsigned short* blist = reinterpret_cast<unsigned short*>(scratch + 4);  // [MSDA_T_SEGB] blocks of the segment to scan
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // all workgroups of a (b, h) on one XCD (round-robin dispatch: XCD = id % 8): its records, grad_out slices and
@@ -892,8 +919,9 @@ __global__ __launch_bounds__(256) void msda_tile_kernel(const float* __restrict_
   const int ty = tile / T.ntx[l], tx = tile - ty * T.ntx[l];
   const int bx0 = tx * T.tsx[l], by0 = ty * T.tsy[l], bx1 = bx0 + T.tsx[l], by1 = by0 + T.tsy[l];
   const int SP = Nq << pshift;  // (< 2^23: the host checks Nq < 2^20; a multiple of 4 or the host keeps nch = 1 ... see c0)
-  // chunk bounds on multiples of 4 records (16-byte loads of bin words)
-  const int c0 = (int)((long)SP * chunk / nch) & ~3, c1 = chunk + 1 == nch ? SP : (int)((long)SP * (chunk + 1) / nch) & ~3;
+  // chunk bounds on whole blocks of the sample kernel (BS = 1 << bshift records, >= 16: 16-byte loads of bin words)
+  const int BS = 1 << bshift;
+  const int c0 = (int)((long)SP * chunk / nch) & ~(BS - 1), c1 = chunk + 1 == nch ? SP : (int)((long)SP * (chunk + 1) / nch) & ~(BS - 1);
   const int4* src = rec + ((long)bh * T.L + l) * SP;
   const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
 
@@ -963,48 +991,74 @@ __global__ __launch_bounds__(256) void msda_tile_kernel(const float* __restrict_
     __syncthreads();  // (the lists are rewritten by the scan that follows)
   };
 
-  // scan: one 16-byte load of R = 4 consecutive bin words per thread and round (one barrier per 1024 records), two rounds
-  // requested ahead; the kept list is in sample order (thread-major inside a round = index order)
+  // scan: only the blocks whose mask names this tile (kept in order in `blist`, a segment of MSDA_T_SEGB blocks at a
+  // time); one 16-byte load of R = 4 consecutive bin words per thread and round (one barrier per 1024 records), two rounds
+  // requested ahead; the kept list is in sample order (blocks ascending, thread-major inside a round = index order)
   int n = 0, it = 0;
   const int4 none = make_int4(-1, -1, -1, -1);
-  auto fetch = [&](int base) {
-    const int i = base + tid * R;
-    return i < c1 ? *reinterpret_cast<const int4*>(bsrc + i) : none;  // (c1 on a multiple of 4 or the padded end)
-  };
-  int4 nx0 = fetch(c0), nx1 = fetch(c0 + 256 * R);
-  for (int base = c0; base < c1; base += 256 * R, ++it) {
-    const int4 c4 = nx0;
-    nx0 = nx1;
-    nx1 = fetch(base + 2 * 256 * R);
-    const int cur[R] = {c4.x, c4.y, c4.z, c4.w};
-    bool sel[R];
-    int before = 0, wsum = 0;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int bx = cur[k] & 0xffff, by = cur[k] >> 16;  // (-1: by = -1: outside every tile)
-      sel[k] = cur[k] >= 0 && bx >= bx0 && bx < bx1 && by >= by0 && by < by1 && base + tid * R + k < SP;
-      const unsigned long long m = __ballot(sel[k]);
-      before += __popcll(m & ((1ull << lane) - 1ull));
-      wsum += __popcll(m);
+  const unsigned long long* msrc = mask + ((long)bh * T.L + l) * nqt;
+  const int mbit = tile & 63;
+  const int blk0 = c0 >> bshift, nblk = (c1 - c0 + BS - 1) >> bshift;
+  const int slot = (tid * R) >> bshift, off = (tid * R) & (BS - 1), BPR = (256 * R) >> bshift;  // blocks per round
+  for (int seg = 0; seg < nblk; seg += MSDA_T_SEGB) {
+    const int segn = min(nblk - seg, MSDA_T_SEGB);
+    int cnt = 0;
+    for (int j0 = 0; j0 < segn; j0 += 256, ++it) {
+      const int jj = j0 + tid;
+      const bool keep = jj < segn && ((msrc[blk0 + seg + jj] >> mbit) & 1ull) != 0ull;
+      const unsigned long long m = __ballot(keep);
+      int* wt = wtot + (it & 1) * 4;
+      if (lane == 0) wt[w] = __popcll(m);
+      __syncthreads();
+      const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
+      if (keep) blist[cnt + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0) + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)jj;
+      cnt += t0 + t1 + t2 + t3;
     }
-    int* wt = wtot + (it & 1) * 4;
-    if (lane == 0) wt[w] = wsum;
     __syncthreads();
-    const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
-    int pos = n + before + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
+    auto index = [&](int rb) {  // first record of this thread in the round that starts at list position rb (-1: none)
+      const int k = rb + slot;
+      return k < cnt ? ((blk0 + seg + (int)blist[k]) << bshift) + off : -1;
+    };
+    auto fetch = [&](int i) { return i >= 0 ? *reinterpret_cast<const int4*>(bsrc + i) : none; };
+    int i0 = index(0), i1 = index(BPR);
+    int4 nx0 = fetch(i0), nx1 = fetch(i1);
+    for (int rb = 0; rb < cnt; rb += BPR, ++it) {
+      const int4 c4 = nx0;
+      const int ib = i0;
+      nx0 = nx1; i0 = i1;
+      i1 = index(rb + 2 * BPR);
+      nx1 = fetch(i1);
+      const int cur[R] = {c4.x, c4.y, c4.z, c4.w};
+      bool sel[R];
+      int before = 0, wsum = 0;
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      if (sel[k]) {
-        const int bx = cur[k] & 0xffff, by = cur[k] >> 16;
-        lrec[pos++] = ((base + tid * R + k) << 8) | ((by - by0) * MSDA_T_TS + (bx - bx0));
+      for (int k = 0; k < R; ++k) {
+        const int bx = cur[k] & 0xffff, by = cur[k] >> 16;  // (-1: by = -1: outside every tile)
+        sel[k] = ib >= 0 && cur[k] >= 0 && bx >= bx0 && bx < bx1 && by >= by0 && by < by1 && ib + k < SP;
+        const unsigned long long m = __ballot(sel[k]);
+        before += __popcll(m & ((1ull << lane) - 1ull));
+        wsum += __popcll(m);
+      }
+      int* wt = wtot + (it & 1) * 4;
+      if (lane == 0) wt[w] = wsum;
+      __syncthreads();
+      const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
+      int pos = n + before + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (sel[k]) {
+          const int bx = cur[k] & 0xffff, by = cur[k] >> 16;
+          lrec[pos++] = ((ib + k) << 8) | ((by - by0) * MSDA_T_TS + (bx - bx0));
+        }
+      }
+      n += t0 + t1 + t2 + t3;
+      if (n > MSDA_T_CAP - 256 * R) {
+        __syncthreads();
+        flush(n);
+        n = 0;
       }
     }
-    n += t0 + t1 + t2 + t3;
-    if (n > MSDA_T_CAP - 256 * R) {
-      __syncthreads();
-      flush(n);
-      n = 0;
-    }
+    __syncthreads();  // (blist is rebuilt)
   }
   __syncthreads();
   if (n > 0) flush(n);
@@ -1076,16 +1130,18 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
                              const MsdaTiles& T, char* ws, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 10 * sizeof(float);  // + 16-byte records staged for a coalesced store
+  const size_t shm = (size_t)QB * L * P * 10 * sizeof(float) + 64;  // + 16-byte records staged for a coalesced store, + masks
   const int BH = B * H;
-  const long SP = (long)Nq * P;
-  const MsdaTileWs W = msda_tile_ws(T, BH, SP, D);
+  const MsdaTileWs W = msda_tile_ws(T, BH, Nq, P, D);
   int4* rec = reinterpret_cast<int4*>(ws + W.rec);
   int* binw = reinterpret_cast<int*>(ws + W.binw);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + W.mask);
   float* part = reinterpret_cast<float*>(ws + W.part);
-  // grad_loc / grad_attn by sample + one record and one bin word per sample
+  MsdaMaskGeom MG;
+  for (int l = 0; l < 8; ++l) { MG.itx[l] = 1.f / (float)T.tsx[l]; MG.ity[l] = 1.f / (float)T.tsy[l]; MG.ntx[l] = T.ntx[l]; }
+  // grad_loc / grad_attn by sample + one record and one bin word per sample + one tile mask per block of QB queries
   msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, rec, binw, Nk, Nq, H, L, ntiles, 0);
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, rec, binw, mask, MG, Nk, Nq, H, L, ntiles, 0);
   constexpr size_t lds = MsdaTileGeom<D>::lds_bytes();
   static const bool attr_set = [] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1094,9 +1150,10 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
   (void)attr_set;
   const unsigned bh8 = (unsigned)((BH + 7) / 8) * 8;
   static const int dbg = [] { const char* e = getenv("RSCOTR_MSDA_TILE_DBG"); return e ? atoi(e) : 0; }();
-  int pshift = 0;
+  int pshift = 0, bshift = 0;
   while ((1 << pshift) < P) ++pshift;
-  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, part, T, Nq, pshift, H, BH, dbg);
+  while ((1 << bshift) < QB * P) ++bshift;
+  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, mask, part, T, Nq, pshift, bshift, ntiles, H, BH, dbg);
   const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
   msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
 }
@@ -1135,7 +1192,7 @@ static void launch_bwd(const float* value, const int64_t* shapes, const int64_t*
   const int ntiles = (Nq + QB - 1) / QB;
   const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
   msda_bwd_kernel<D, P, 1><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, 0);
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
 }
 
 // sorted / pull strategy: grad_loc + grad_attn by sample, grad_value by destination token
@@ -1162,10 +1219,10 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
     // grad_value zeroed for the scatter the sample kernel falls back to; on the sorted path the pull kernel overwrites it
     hipMemsetAsync(gv, 0, (size_t)B * Nk * H * D * sizeof(float), s);
     msda_bwd_kernel<D, P, 2><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, W.lds_words);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, W.lds_words);
   } else {
     msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, Nk, Nq, H, L, ntiles, 0);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
   }
   msda_binsum_kernel<<<dim3((W.NEmax + 255) / 256, BH), 256, 0, s>>>(shapes, ws, W, L);
   msda_plan_kernel<D><<<BH, 1024, hist_lds, s>>>(shapes, lsi, ws, W, gv, Nk, H, L);
@@ -1234,7 +1291,7 @@ extern "C" int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, i
                                                    int P) {
   MsdaTiles T;
   if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || Nq >= (1 << 20) || !msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) return 0;
-  return msda_tile_ws(T, B * H, (long)Nq * P, D).total;
+  return msda_tile_ws(T, B * H, Nq, P, D).total;
 }
 
 extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes,
