@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
     Bilinear g[P];
     float aw[P];
     float4 v1[P], v2[P], v3[P], v4[P];
+    unsigned mlo = 0u, mhi = 0u;  // tiles of this level this lane's samples fall in (rec != nullptr)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float2 xy = *reinterpret_cast<const float2*>(my_loc + (l * P + p) * 2);
@@ -297,12 +298,23 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
                                                   __float_as_int(lw), __float_as_int(lh));
           if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
             const int t = (int)(((float)(g[p].h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(g[p].w_low + 1) + 0.5f) * MG.itx[l]);
-            atomicOr(&s_mask[2 * l + ((t >> 5) & 1)], 1u << (t & 31));
+            if (t & 32) mhi |= 1u << (t & 31); else mlo |= 1u << (t & 31);
           }
         }
         s_gloc[(r * LP + l * P + p) * 2 + 0] = in ? (float)Wl * gw : 0.f;
         s_gloc[(r * LP + l * P + p) * 2 + 1] = in ? (float)Hl * gh : 0.f;
         s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
+      }
+    }
+    if (rec) {  // the wavefront's tiles of this level: one LDS atomic per word and wavefront
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mlo |= (unsigned)__shfl_xor((int)mlo, o, 64);
+        mhi |= (unsigned)__shfl_xor((int)mhi, o, 64);
+      }
+      if (lane == 0) {
+        if (mlo) atomicOr(&s_mask[2 * l], mlo);
+        if (mhi) atomicOr(&s_mask[2 * l + 1], mhi);
       }
     }
   }
@@ -784,7 +796,7 @@ constexpr int MSDA_T_MAXL = 8;     // levels the tile path handles
 constexpr int MSDA_T_TS = 16;      // bins per tile edge (at most)
 constexpr int MSDA_T_CW = 17;      // cells per tile edge
 constexpr int MSDA_T_CAP = 3072;   // kept records per sort + accumulate round (list entries: 8 bytes)
-constexpr int MSDA_T_TARGET = 16;  // workgroups per (b, h, level) aimed at
+constexpr int MSDA_T_TARGET = 10;  // mean run length (samples per bin and thread) a sample chunk is sized for
 #ifndef MSDA_T_OCC
 #define MSDA_T_OCC(D) ((D) <= 32 ? 3 : 2)
 #endif
@@ -802,7 +814,7 @@ struct MsdaTiles {
 static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, int Nk, long SP, int D) {
   const int tsy_max = D >= 32 ? 8 : 16;  // MsdaTileGeom<D>::TSY
   if (!shapes_host || L < 1 || L > MSDA_T_MAXL) return false;
-  static const int target = [] { const char* e = getenv("RSCOTR_MSDA_TILE_WGS"); const int v = e ? atoi(e) : MSDA_T_TARGET; return v > 0 ? v : MSDA_T_TARGET; }();
+  static const int target = [] { const char* e = getenv("RSCOTR_MSDA_TILE_RUN"); const int v = e ? atoi(e) : MSDA_T_TARGET; return v > 0 ? v : MSDA_T_TARGET; }();
   T->L = L;
   int nw = 0, tok = 0;
   for (int l = 0; l < L; ++l) {
@@ -814,7 +826,11 @@ static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, in
     T->tsx[l] = (Ww + 1 + T->ntx[l] - 1) / T->ntx[l];
     T->tsy[l] = (Hh + 1 + T->nty[l] - 1) / T->nty[l];
     const long tiles = (long)T->ntx[l] * T->nty[l];
-    long nch = (target + tiles / 2) / tiles;
+    // sample chunks: the walk of the tile kernel is a chain of gathers per thread as long as the longest run of equal bin,
+    // so a level is cut into as many chunks as keep the MEAN run (samples of the chunk per bin, per thread sharing a bin)
+    // near `target` — the coarse levels receive as many samples as the fine ones on a fraction of the bins
+    const long nbt = (long)T->tsx[l] * T->tsy[l], sf = std::max<long>(1, std::min<long>(4, (D >= 32 ? 128 : 256) / nbt));
+    long nch = (SP + (long)(Hh + 1) * (Ww + 1) * sf * target - 1) / ((long)(Hh + 1) * (Ww + 1) * sf * target);
     nch = std::max<long>(1, std::min<long>(std::min<long>(nch, 64), SP / 512));
     T->nch[l] = (int)nch;
     T->wbase[l] = nw;
@@ -925,12 +941,20 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   const int4* src = rec + ((long)bh * T.L + l) * SP;
   const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
 
-  const int bin = tid / TB, sub = tid % TB;  // this thread's bin and channel part
+  // this thread's bin, channel part, and — tiles with few bins (the coarse levels, whose bins hold long runs) — its share of
+  // the bin's run: SF threads (pairs) per bin take consecutive parts of the run, their rows are added in part order
+  const int tsx = T.tsx[l], tsy = T.tsy[l], nbt = tsx * tsy;
+  const int SF = max(1, min(4, (256 / TB) / nbt));
+  const int pair = tid / TB, sub = tid % TB;
+  const bool active = pair < nbt * SF;
+  const int bidx = active ? pair / SF : 0, seg = pair % SF;
+  const int bin = (bidx / tsx) * MSDA_T_TS + bidx % tsx;
   const float* gob = go + ((long)b * Nq * H + h) * D + sub * CH;  // + q * H * D
   const int qstride = H * D;
-  float4 a1[V], a2[V], a3[V], a4[V];  // the bin's four tap rows (this thread's channels)
+  typedef float v2f __attribute__((ext_vector_type(2)));  // (pairs: v_pk_fma_f32 does two channels per instruction)
+  v2f a1[2 * V], a2[2 * V], a3[2 * V], a4[2 * V];  // the bin's four tap rows (this thread's channels)
 #pragma unroll
-  for (int v = 0; v < V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int v = 0; v < 2 * V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = v2f{0.f, 0.f};
 
   // sort the n kept records by bin (stable), then every thread adds the records of its bin to its accumulators
   auto flush = [&](int n) {
@@ -957,7 +981,12 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
     for (int i = i0 + lane; i < i1; i += 64) order[hist[w * NBIN + (lrec[i] & 255)] + rank[i]] = (unsigned short)i;
     __syncthreads();
     if (dbg == 2) return;
-    const int s0 = binstart[bin], s1 = binstart[bin + 1];
+    int s0 = binstart[bin], s1 = binstart[bin + 1];
+    {
+      const int per = (s1 - s0 + SF - 1) / SF;
+      s0 = active ? s0 + seg * per : s1;
+      s1 = min(s1, s0 + per);
+    }
 #pragma unroll 1
     for (int i = s0; i < s1; i += U) {  // U samples in flight per thread, applied in list (= sample) order
       int4 rr[U];
@@ -976,14 +1005,16 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
         if (i + u < s1) {
           const float aw = __int_as_float(rr[u].y), lw = __int_as_float(rr[u].z), lh = __int_as_float(rr[u].w);
           const float hw = 1.f - lw, hh = 1.f - lh;
-          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          const float ah = aw * hh, al = aw * lh;  // the tap weights carry the attention weight
+          const float w1 = ah * hw, w2 = ah * lw, w3 = al * hw, w4 = al * lw;
+          const v2f W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3}, W4 = {w4, w4};
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            const float4 top = scale4(g[u][v], aw);
-            a1[v].x += top.x * w1; a1[v].y += top.y * w1; a1[v].z += top.z * w1; a1[v].w += top.w * w1;
-            a2[v].x += top.x * w2; a2[v].y += top.y * w2; a2[v].z += top.z * w2; a2[v].w += top.w * w2;
-            a3[v].x += top.x * w3; a3[v].y += top.y * w3; a3[v].z += top.z * w3; a3[v].w += top.w * w3;
-            a4[v].x += top.x * w4; a4[v].y += top.y * w4; a4[v].z += top.z * w4; a4[v].w += top.w * w4;
+            const v2f lo = {g[u][v].x, g[u][v].y}, hi = {g[u][v].z, g[u][v].w};
+            a1[2 * v] += lo * W1; a1[2 * v + 1] += hi * W1;
+            a2[2 * v] += lo * W2; a2[2 * v + 1] += hi * W2;
+            a3[2 * v] += lo * W3; a3[2 * v + 1] += hi * W3;
+            a4[2 * v] += lo * W4; a4[2 * v + 1] += hi * W4;
           }
         }
       }
@@ -1071,18 +1102,38 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
     float4* c = reinterpret_cast<float4*>(acc + (lby * MSDA_T_CW + lbx) * D + sub * CH);
     constexpr int CS = D / 4;  // float4 per cell
     auto add = [](float4* p, const float4& v) { float4 o = *p; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *p = o; };
+    for (int sg = 0; sg < SF; ++sg) {
+      const bool mine = active && seg == sg;
+      if (mine) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) add(c + v, a1[v]);
-    __syncthreads();
+        for (int v = 0; v < V; ++v) add(c + v, make_float4(a1[2 * v].x, a1[2 * v].y, a1[2 * v + 1].x, a1[2 * v + 1].y));
+      }
+      __syncthreads();
+    }
+    for (int sg = 0; sg < SF; ++sg) {
+      const bool mine = active && seg == sg;
+      if (mine) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) add(c + CS + v, a2[v]);
-    __syncthreads();
+        for (int v = 0; v < V; ++v) add(c + CS + v, make_float4(a2[2 * v].x, a2[2 * v].y, a2[2 * v + 1].x, a2[2 * v + 1].y));
+      }
+      __syncthreads();
+    }
+    for (int sg = 0; sg < SF; ++sg) {
+      const bool mine = active && seg == sg;
+      if (mine) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, a3[v]);
-    __syncthreads();
+        for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, make_float4(a3[2 * v].x, a3[2 * v].y, a3[2 * v + 1].x, a3[2 * v + 1].y));
+      }
+      __syncthreads();
+    }
+    for (int sg = 0; sg < SF; ++sg) {
+      const bool mine = active && seg == sg;
+      if (mine) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, a4[v]);
-    __syncthreads();
+        for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, make_float4(a4[2 * v].x, a4[2 * v].y, a4[2 * v + 1].x, a4[2 * v + 1].y));
+      }
+      __syncthreads();
+    }
   }
   float4* dst = reinterpret_cast<float4*>(part + ((long)bh * T.NW + e) * NCELL * D);
   for (int i = tid; i < NCELL * D / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(acc)[i];
