@@ -182,7 +182,7 @@ struct MsdaMaskGeom {
 // SCATTER: 0 = grad_loc / grad_attn only (grad_value comes from the pull kernel), 1 = also scatter grad_value with
 // atomics, 2 = scatter iff the level pyramid has more than `bins_cap` extended bins (the sorted path stood down).
 template <int D, int P, int SCATTER>
-__global__ __launch_bounds__(256) void msda_bwd_kernel(
+__global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attn, const float* __restrict__ grad_out,
@@ -262,6 +262,15 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       aw[p] = my_attn[l * P + p];
       g[p] = bilinear_setup(xy.x, xy.y, Hl, Wl);
       if (!qok) g[p].in = g[p].ok1 = g[p].ok2 = g[p].ok3 = g[p].ok4 = false;
+      if (rec && sub == 0) {  // (here, before the gathers: the top-left tap need not stay in registers)
+        const bool in = g[p].in;
+        s_rec[(l * QB + r) * P + p] = make_int4(in ? ((g[p].h_low + 1) << 16) | (g[p].w_low + 1) : -1, __float_as_int(aw[p]),
+                                                __float_as_int(g[p].lw), __float_as_int(g[p].lh));
+        if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
+          const int t = (int)(((float)(g[p].h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(g[p].w_low + 1) + 0.5f) * MG.itx[l]);
+          if (t & 32) mhi |= 1u << (t & 31); else mlo |= 1u << (t & 31);
+        }
+      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -293,14 +302,6 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       ga = group_sum<G>(ga);
       if (sub == 0) {
         const bool in = g[p].in;
-        if (rec) {
-          s_rec[(l * QB + r) * P + p] = make_int4(in ? ((g[p].h_low + 1) << 16) | (g[p].w_low + 1) : -1, __float_as_int(aw[p]),
-                                                  __float_as_int(lw), __float_as_int(lh));
-          if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
-            const int t = (int)(((float)(g[p].h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(g[p].w_low + 1) + 0.5f) * MG.itx[l]);
-            if (t & 32) mhi |= 1u << (t & 31); else mlo |= 1u << (t & 31);
-          }
-        }
         s_gloc[(r * LP + l * P + p) * 2 + 0] = in ? (float)Wl * gw : 0.f;
         s_gloc[(r * LP + l * P + p) * 2 + 1] = in ? (float)Hl * gh : 0.f;
         s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
