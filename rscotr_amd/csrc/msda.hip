@@ -907,7 +907,7 @@ template <int D>
 __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const float* __restrict__ go, const int4* __restrict__ rec,
                                                         const int* __restrict__ binw, const unsigned long long* __restrict__ mask,
                                                         float* __restrict__ part, MsdaTiles T, int Nq, int pshift, int bshift,
-                                                        int nqt, int H, int BH, int dbg) {
+                                                        int nqt, int H, int BH) {
   using Gm = MsdaTileGeom<D>;
   constexpr int TB = Gm::TB, CH = Gm::CH, V = Gm::V, U = Gm::U, NBIN = Gm::NBIN, NCELL = Gm::NCELL;
   constexpr int R = 4;  // consecutive records per thread and scan round (one 16-byte load of bin words)
@@ -959,7 +959,6 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
 
   // sort the n kept records by bin (stable), then every thread adds the records of its bin to its accumulators
   auto flush = [&](int n) {
-    if (dbg == 1) return;
     for (int i = tid; i < 4 * NBIN; i += 256) hist[i] = 0;
     __syncthreads();
     const int nw = ((n + 3) / 4 + 63) & ~63;  // records per wavefront (whole rounds of 64)
@@ -981,7 +980,6 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
     __syncthreads();
     for (int i = i0 + lane; i < i1; i += 64) order[hist[w * NBIN + (lrec[i] & 255)] + rank[i]] = (unsigned short)i;
     __syncthreads();
-    if (dbg == 2) return;
     int s0 = binstart[bin], s1 = binstart[bin + 1];
     {
       const int per = (s1 - s0 + SF - 1) / SF;
@@ -994,8 +992,7 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
       float4 g[U][V];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        int sidx = lrec[order[min(i + u, s1 - 1)]] >> 8;
-        if (dbg == 3) sidx = c0 + (sidx & 63);  // (experiment: every gather a cache hit)
+        const int sidx = lrec[order[min(i + u, s1 - 1)]] >> 8;
         rr[u] = src[sidx];  // (re-read: L2-hot, the sample kernel has just written it)
         const float4* row = reinterpret_cast<const float4*>(gob + (long)(sidx >> pshift) * qstride);
 #pragma unroll
@@ -1201,11 +1198,10 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
   }();
   (void)attr_set;
   const unsigned bh8 = (unsigned)((BH + 7) / 8) * 8;
-  static const int dbg = [] { const char* e = getenv("RSCOTR_MSDA_TILE_DBG"); return e ? atoi(e) : 0; }();
   int pshift = 0, bshift = 0;
   while ((1 << pshift) < P) ++pshift;
   while ((1 << bshift) < QB * P) ++bshift;
-  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, mask, part, T, Nq, pshift, bshift, ntiles, H, BH, dbg);
+  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, mask, part, T, Nq, pshift, bshift, ntiles, H, BH);
   const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
   msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
 }

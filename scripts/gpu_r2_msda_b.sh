@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for cfg in ${CFGS:-"1 0 16"}; do
   IFS=, read B dbg wgs <<< "$cfg"
-  RSCOTR_MSDA_TILE_RUN=$wgs RSCOTR_MSDA_TILE_DBG=$dbg RSCOTR_MSDA_BWD=tiled timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$cfg -o p -- python $R/scripts/bench_msda.py --iters 20 --B $B > /tmp/log_$cfg.log 2>&1
+  RSCOTR_MSDA_TILE_RUN=$wgs RSCOTR_MSDA_BWD=tiled timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$cfg -o p -- python $R/scripts/bench_msda.py --iters 20 --B $B > /tmp/log_$cfg.log 2>&1
   f=$(find /tmp/prof_$cfg -name '*kernel_stats.csv' | head -1)
   python - "$f" "$cfg" <<'PY'
 import csv, sys

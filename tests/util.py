@@ -107,7 +107,15 @@ def patch_ops_with_oracle(monkeypatch):
                 out[p, torch.from_numpy(cs)] = torch.from_numpy(rs).int()
         return out
 
-    def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None):
+    def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None):
+        # (ops.mha: the positional adds happen inside; k_pos None in self-attention means q_pos)
+        kx = x if kx is None else kx
+        vx = kx if vx is None else vx
+        if k_pos is None and kx is x:
+            k_pos = q_pos
+        q_in = x if q_pos is None else x + q_pos
+        k_in = kx if k_pos is None else kx + k_pos
+        v_in = vx
         B, Lq, C = q_in.shape
         Lk, hd = k_in.shape[1], C // heads
         q = F.linear(q_in, in_w[:C], in_b[:C]).view(B, Lq, heads, hd).transpose(1, 2)
@@ -141,6 +149,24 @@ def patch_ops_with_oracle(monkeypatch):
         else:
             loc = r[:, :, None, :, None, :2] + off / P * r[:, :, None, :, None, 2:] * 0.5
         return loc, aw
+
+    def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes, level_start_index,
+                       offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+        # mmcv MultiScaleDeformableAttention.forward (batch-first), as ops._MSDAAttn computes it
+        B, Nq, C = x.shape
+        q = x if q_pos is None else x + q_pos
+        val = x if value is None else value
+        v = F.linear(val, w_v, b_v)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        off = F.linear(q, w_off, b_off).view(B, Nq, heads, L * P * 2)
+        logit = F.linear(q, w_aw, b_aw).view(B, Nq, heads, L * P)
+        loc, aw = msda_prep(off, logit, reference_points, offset_norm, L, P)
+        out = O.msda_sample(v.view(B, -1, heads, C // heads), spatial_shapes, level_start_index, loc, aw)
+        y = F.linear(out.reshape(B, Nq, C), w_o, b_o)
+        return y if identity is None else identity + y
+
+    monkeypatch.setattr(ops, 'msda_attention', msda_attention)
 
     def match_cost_batched(cls_score, bbox_pred, gt_bboxes, gt_labels, factors, w_cls, w_l1, w_iou, alpha, gamma, eps):
         S, B, Q, C = cls_score.shape
