@@ -159,14 +159,16 @@ int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C, int M, in
 int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream);
 /* Grouped launch of deferred weight gradients: n problems dW_i = A_i^T B_i (both operands k-major) with small outputs run
  * as ONE launch on tiles x k-slices; every problem leaves `splits` slabs (+ row-sum partials when rs_slabs != 0) for
- * rscotr_splitk_flush.  variant 0: fp32 matrix pipe, 64 x 64 tiles with bounds handling (any problem); variant 2: bf16x6
- * split product (fp32-accurate, three bf16 planes per operand) on 128 x 128 tiles — M, N multiples of 128, K and ksplit_len
- * multiples of 16, 16-byte aligned operands with lda, ldb multiples of 4 (caller-checked).  table = device (n, 16) int64
- * rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len (multiple of 16 unless splits == 1), splits,
- * first workgroup, krows_per_scale, 0, 0}; problem i occupies 8 * ceil(tiles / 8) * splits workgroups, tiles = ceil(M / 64)
- * * ceil(N / 64) (variant 2: (M / 128) * (N / 128)); total_wgs = their sum.  Replaces ~110 short launches per co-training
- * round (torch autograd's per-Linear weight-gradient GEMMs behind mmcv's FFN / MultiheadAttention /
- * MultiScaleDeformableAttention modules). */
+ * rscotr_splitk_flush.  variant 0: fp32 matrix pipe, 64 x 64 tiles with bounds handling (any problem); variant 2 / 3: bf16x6
+ * split product (fp32-accurate, three bf16 planes per operand) on 128 x 128 / 64 x 64 tiles — M, N multiples of the tile edge,
+ * K and ksplit_len multiples of 16 / 32, 16-byte aligned operands with lda, ldb multiples of 4 (caller-checked).  table =
+ * device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len (a multiple of 16 / 32
+ * unless splits == 1), splits, first workgroup of the row's BUNDLE, krows_per_scale, 0, workgroups of the problem = tiles *
+ * splits}, tiles = ceil(M / 64) * ceil(N / 64) (variant 2: (M / 128) * (N / 128)), n a multiple of 8: rows come in bundles of
+ * 8 (padded with all-zero rows) that occupy 8 * max(workgroups of the bundle's rows) consecutive workgroup ids, row x of a
+ * bundle taking the ids = x mod 8 — one problem per XCD, so that its operands enter one L2 once; total_wgs = the sum over
+ * the bundles.  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient GEMMs behind
+ * mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules). */
 int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, void* stream);
 
 /* nb0 * nb1 independent products of one shape, problem (b0, b1) at element offsets b0*s?0 + b1*s?1 of A, B, C

@@ -1508,24 +1508,33 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const int64_t* __res
 // (so few slices per problem: the slab traffic of 31-slice launches goes away), slabs + row-sum partials go to the deferred
 // combine (rscotr_splitk_flush), which orders problems that share a destination.
 // table: device (n, 16) int64 rows {A, B, slabs, rs_slabs | 0, kscale | 0, M, N, K, lda, ldb, ksplit_len, splits,
-// first workgroup, krows_per, split-product flag, 0}; a problem occupies 8 * ceil(tiles / 8) * splits consecutive workgroups,
-// tiles = ceil(M / 64) * ceil(N / 64) (every problem starts on a multiple of 8: workgroup id % 8 is the XCD).
+// first workgroup OF THE BUNDLE, krows_per, 0, workgroups of the problem = tiles * splits}, n a multiple of 8: rows come in
+// bundles of 8 (padded with rows of 0 workgroups) that occupy 8 * max(workgroups of the bundle's rows) consecutive ids,
+// row x of a bundle taking the ids = x mod 8 (see the kernel).
 constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<128, 128, true, true, 0>();  // 24 KB (>= the fp32 body's 17 KB)
 // X6 = false: fp32 matrix pipe on 64 x 64 tiles with bounds handling (any problem); X6 = true: the bf16x6 split product on
 // 128 x 128 tiles (interior problems: M, N multiples of 128, k-slices multiples of 16, 16-byte aligned operands).  Two
 // instantiations rather than one kernel with both bodies: the 128 x 128 body's registers (114 + 64 accumulators) would
 // halve the residency of the fp32 body's workgroups (measured: 950 -> 1500 us for the launch).
-template <bool X6>
+// VAR: 0 = fp32 64 x 64 (any problem), 2 = bf16x6 128 x 128, 3 = bf16x6 64 x 64 software-pipelined (32 k per step: M, N
+// multiples of 64, k-slices multiples of 32, 16-byte aligned operands)
+template <int VAR>
 __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
   extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-  // the problem of this workgroup: binary search over the first-workgroup column (every thread, uniform: no static LDS in
-  // front of the dynamic region the body carves with 16-byte accesses)
-  int lo = 0, hi = n - 1;
+  // the problem of this workgroup.  The table comes in BUNDLES of 8 rows that share the first-workgroup column: workgroup
+  // first + 8 j + x is the j-th workgroup of the bundle's row x, so that (round-robin dispatch: XCD = id % 8) ALL tiles and
+  // k-slices of a problem run on one XCD and its operands are fetched into that L2 once (with the tiles of a problem
+  // spread over the XCDs a 256 x 256 x 10880 problem pulled its operands from HBM three times over).  Binary search over
+  // the bundles (every thread, uniform: no static LDS in front of the dynamic region the body carves with 16-byte accesses)
+  int lo = 0, hi = (n >> 3) - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if ((int)table[(long)mid * 16 + 12] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if ((int)table[(long)mid * 8 * 16 + 12] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const int64_t* t = table + (long)lo * 16;
+  const int rel = (int)blockIdx.x - (int)table[(long)lo * 8 * 16 + 12];
+  const int64_t* t = table + ((long)lo * 8 + (rel & 7)) * 16;
+  const int jwg = rel >> 3;
+  if (jwg >= (int)t[15]) return;  // (rows of a bundle differ in size; empty rows have 0 workgroups)
   GemmParams p;
   p.A = reinterpret_cast<const float*>(t[0]);
   p.B = reinterpret_cast<const float*>(t[1]);
@@ -1542,15 +1551,22 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
   p.vecC = 0;
   p.nb1 = 0; p.nb2 = 1;
-  p.tiles = X6 ? (p.M / 128) * (p.N / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  const int first = (int)t[12];
-  const int nblk = 8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * p.splits;
-  const int gx = p.splits > 1 ? nblk : p.tiles;  // (one k-slice: the body's single-slice tile order, result still as slab 0)
-  if ((int)blockIdx.x - first >= gx) return;    // padding workgroups: every problem starts on a multiple of 8 (XCD affinity)
-  if constexpr (X6) {
-    gemm_bf16x6_body<128, 128, true, true, 0, true>(p, (int)blockIdx.x - first, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  p.tiles = VAR == 2 ? (p.M / 128) * (p.N / 128) : VAR == 3 ? (p.M / 64) * (p.N / 64) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  // the bodies decode (tile, k-slice) from a workgroup id laid out for XCD runs (x = id & 7 owns a run of tiles, id >> 3 =
+  // slice * run + position in the run): build the id whose decoding is (tile = jwg % tiles, slice = jwg / tiles)
+  const int tl_ = jwg % p.tiles, sl_ = jwg / p.tiles;
+  const int q_ = p.tiles >> 3, r_ = p.tiles & 7, run_ = q_ + (r_ ? 1 : 0);
+  int x_, pos_;
+  if (tl_ < r_ * (q_ + 1)) { x_ = tl_ / (q_ + 1); pos_ = tl_ - x_ * (q_ + 1); }
+  else { const int u_ = tl_ - r_ * (q_ + 1); x_ = r_ + u_ / q_; pos_ = u_ - (x_ - r_) * q_; }
+  const int bx = 8 * (sl_ * run_ + pos_) + x_;
+  const int gx = p.splits > 1 ? 8 * run_ * p.splits : p.tiles;  // (one k-slice: the single-slice tile order, result still as slab 0)
+  if constexpr (VAR == 2) {
+    gemm_bf16x6_body<128, 128, true, true, 0, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  } else if constexpr (VAR == 3) {
+    gemm_bf16x6_body<64, 64, true, true, 2, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else {
-    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, (int)blockIdx.x - first, gx, 0);
+    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, bx, gx, 0);
   }
 }
 
@@ -2573,11 +2589,13 @@ extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, 
   if (n == 0 || total_wgs == 0) return RSCOTR_OK;
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
   if (variant == 0) {
-    gemm_f32_group_kernel<false><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
+    gemm_f32_group_kernel<0><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else if (variant == 2) {
-    gemm_f32_group_kernel<true><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
+    gemm_f32_group_kernel<2><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
+  } else if (variant == 3) {
+    gemm_f32_group_kernel<3><<<dim3((unsigned)total_wgs), 256, 4 * (size_t)bf16x6_lds_words<64, 64, true, true, 2>(), (hipStream_t)stream>>>(table, n);
   } else {
-    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles) or 2 (bf16x6 128 x 128 tiles)");
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128) or 3 (bf16x6 64 x 64)");
   }
   return check_launch("rscotr_gemm_dw_group");
 }

@@ -438,32 +438,46 @@ class _DeferredCombine:
         def kind(p):
             a, b, _, _, _, M, N, K, lda, ldb, _ = p
             ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
+            if self.group_x6 == 3:  # bf16x6 on 64 x 64 tiles, 32 k per step
+                return 3 if ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512 else 0
             return 2 if ok and M % 128 == 0 and N % 128 == 0 else 0
         kinds = [kind(p) for p in probs]
-        tiles = [(M // 128) * (N // 128) if k == 2 else ((M + 63) // 64) * ((N + 63) // 64)
+        tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
         work = sum(t * p[7] * (4 if k == 2 else 1) for t, k, p in zip(tiles, kinds, probs))
         klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
         dev = self.group_keep[0].device
         launches, ents = [], []
-        for variant in (0, 2):
-            rows, first = [], 0
+        for variant in (0, 2, 3):
+            rows = []
             for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
                 if x6 != variant:
                     continue
                 sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
-                klen = -(-(-(-K // sp)) // 16) * 16
+                kq = 32 if x6 == 3 else 16
+                klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
                 if sp == 1:
                     klen = K
                 slab = self.reserve(sp * (M * N + M) * 4, dev)
                 rs_slab = slab + sp * M * N * 4 if rs else 0
-                rows.append((a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, first, max(kper, 1), 0, 0))
+                rows.append([a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, 0, max(kper, 1), 0, t * sp])
                 ents.append((slab, rs_slab, out, rs, M, N, N, sp))
-                first += 8 * ((t + 7) // 8) * sp
             if rows:
+                # bundles of 8 problems of similar size, one problem per XCD (the kernel's id layout): largest first
+                rows.sort(key=lambda r: -r[15])
+                rows += [[0] * 16 for _ in range(-len(rows) % 8)]
+                first = 0
+                for b0 in range(0, len(rows), 8):
+                    for r in rows[b0:b0 + 8]:
+                        r[12] = first
+                    first += 8 * rows[b0][15]
                 launches.append((self._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first, variant))
+                if os.environ.get('RSCOTR_DW_GROUP_DUMP'):  # (tuning aid: the problems of one grouped launch)
+                    print(f'[dw group] variant {variant}: {len(rows)} problems, {first} workgroups, k-slice target {klen_t}')
+                    for r in rows:
+                        print(f'    M={r[5]} N={r[6]} K={r[7]} klen={r[10]} splits={r[11]} rowsum={int(r[3] != 0)}')
         return launches, ents
 
     def prepare_capture(self, n=4):

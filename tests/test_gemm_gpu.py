@@ -422,9 +422,9 @@ def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
         assert _rel(acc, ref + C0.double()) < 2e-6, mode
 
 
-@pytest.mark.parametrize('x6', [0, 1])
+@pytest.mark.parametrize('x6', [0, 1, 3])
 def test_grouped_deferred_weight_gradients(cuda, x6, monkeypatch):
-    """(x6 = 1: interior problems on the bf16x6 128 x 128 variant, a second launch.)  rscotr_gemm_dw_group through ops.DEFER: a batch of dW = A^T B problems of the step's small-output shapes (ragged
+    """(x6 = 1 / 3: interior problems on the bf16x6 128 x 128 / 64 x 64 variant, a second launch.)  rscotr_gemm_dw_group through ops.DEFER: a batch of dW = A^T B problems of the step's small-output shapes (ragged
     M / N / K, a destination shared by two problems, bias gradients riding along, per-sample k scaling) computed by ONE
     grouped launch + the deferred combine, against fp64; destinations are ACCUMULATED into."""
     from rscotr_amd import ops
