@@ -289,6 +289,20 @@ int rscotr_upsample_ce_bwd(const float* logit, const int64_t* label, const float
  * gradient (the reference points are detached). */
 int rscotr_sine_embed4(const float* pos, float* out, int64_t rows, void* stream);
 
+/* Level embeddings of the multi-scale token maps: out[b, t, :] = x[b, t, :] + cst[b | 0, t, :] + w[level(t), :] over the
+ * concatenated levels (sizes[l] tokens each, host array, sum = N); x and cst may be null, image b of x starts at element
+ * b * x_bstride (rows dense), cst is (B, N, C) when cst_batched else (N, C); out is dense.  Replaces the per-level `pos + level_embed[lvl].view(1, 1, -1)` adds + concatenation of
+ * models/multi/bbox_head/transformer.py:196-207 (lvl_pos_embed), models/multi/seg_head/pixel_decoder.py:108-118
+ * (level_encoding) and models/multi/seg_head/mask2former_head.py:152-156 (level_embed).  C a multiple of 4, L <= 8. */
+int rscotr_level_embed_fwd(const float* x, int64_t x_bstride, const float* cst, int cst_batched, const float* w,
+                           float* out, const int* sizes, int L, int B, int N, int C, void* stream);
+/* Gradient of the embedding rows: dw[l, :] (+)= sum over b and the tokens of level l of g[b, t, :], fixed summation
+ * order (bit-reproducible), one launch.  workspace: rscotr_level_embed_bwd_workspace(L, C) bytes; counters: L ints, zero
+ * before the first call (the kernel returns them to zero). */
+int64_t rscotr_level_embed_bwd_workspace(int L, int C);
+int rscotr_level_embed_bwd(const float* g, float* dw, const int* sizes, int L, int B, int N, int C, int accumulate,
+                           float* workspace, int* counters, void* stream);
+
 /* Masked-attention mask of the seg decoder (models/multi/seg_head/mask2former_head.py:126-136, :177-178):
  * mask_pred (rows, h, w) -> bilinear resize to (th, tw), align_corners=False -> sigmoid < 0.5 -> rows that are
  * all-True reset to all-False -> out (rows, th*tw) bool (1 byte each, 1 = blocked). */

@@ -27,7 +27,8 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for p in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")):
+    for p in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+            [os.path.join(HERE, "..", "include", "rscotr.h")]:
         h.update(p.encode())
         with open(p, "rb") as fh:
             h.update(fh.read())
@@ -56,10 +57,23 @@ def build_library(force=False, verbose=True):
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
     procs = []
+    hdr = hashlib.sha256()
+    for h in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+            [os.path.join(HERE, "..", "include", "rscotr.h")]:
+        with open(h, "rb") as fh:
+            hdr.update(fh.read())
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         extra = HOST_FLAGS if src.endswith(".cpp") else []
+        # per-object stamp: a source whose text, headers and flags are unchanged keeps its object
+        with open(src, "rb") as fh:
+            odig = hashlib.sha256(fh.read() + hdr.digest() + " ".join(FLAGS + extra).encode()).hexdigest()
+        ostamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
+        with open(ostamp, "w") as fh:
+            fh.write(odig)
         cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj,
                "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
         if verbose:
@@ -68,6 +82,7 @@ def build_library(force=False, verbose=True):
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
+            os.remove(os.path.join(objdir, os.path.basename(src) + ".o.stamp"))
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:

@@ -1,0 +1,122 @@
+// Small fused kernels for the glue between the attention blocks (what the reference leaves to chains of element-wise ATen
+// ops and autograd's generic backward nodes): level-embedding adds with their segment-sum gradient, ...
+#include "common.h"
+#include "rscotr.h"
+
+namespace rscotr {
+
+struct LevelStarts {
+  int n;
+  int start[9];  // start[n] = N (tokens of all levels)
+};
+
+__device__ __forceinline__ int level_of(const LevelStarts& ls, int tok) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) l += (i < ls.n && tok >= ls.start[i]) ? 1 : 0;
+  return l;
+}
+
+// out[b, t, :] = (x ? x[b * x_bstride + t * C ...] : 0) + (cst ? cst[b * cst_bstride + t * C ...] : 0) + w[level(t), :]; one thread per float4
+__global__ __launch_bounds__(256) void level_embed_fwd_kernel(const float4* __restrict__ x, long x_bstride4,
+                                                              const float4* __restrict__ cst, long cst_bstride4,
+                                                              const float4* __restrict__ w,
+                                                              float4* __restrict__ out, LevelStarts ls, int B, int N, int C4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)N * C4;
+  if (i >= per * B) return;
+  const int b = (int)(i / per);
+  const long r = i - (long)b * per;
+  const int t = (int)(r / C4), c = (int)(r - (long)t * C4);
+  float4 v = w[level_of(ls, t) * C4 + c];
+  if (x) { const float4 a = x[(long)b * x_bstride4 + r]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+  if (cst) { const float4 a = cst[(long)b * cst_bstride4 + r]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+  out[i] = v;
+}
+
+// dw[l, c] (+)= sum over b and the tokens t of level l of g[b, t, c], in a FIXED order (bit-reproducible): workgroup
+// (chunk k, level l) sums its rows of the level (rows = b * n_l + position) column by column, leaves a partial, and the
+// LAST workgroup of a level to finish folds the partials k = 0.. in order (counter[l] returns to 0: self-resetting).
+__global__ __launch_bounds__(256) void level_embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ part,
+                                                              int* __restrict__ counter, float* __restrict__ dw,
+                                                              LevelStarts ls, int B, int N, int C, int accumulate) {
+  const int l = blockIdx.y, k = blockIdx.x, chunks = gridDim.x;
+  const int s0 = ls.start[l], nl = ls.start[l + 1] - s0;
+  const long rows = (long)B * nl;
+  const long r0 = rows * k / chunks, r1 = rows * (k + 1) / chunks;
+  __shared__ int last;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {  // four independent chains, folded in a fixed order
+      const long q0 = r, q1 = r + 1, q2 = r + 2, q3 = r + 3;
+      a0 += g[((q0 / nl) * N + s0 + q0 % nl) * C + c];
+      a1 += g[((q1 / nl) * N + s0 + q1 % nl) * C + c];
+      a2 += g[((q2 / nl) * N + s0 + q2 % nl) * C + c];
+      a3 += g[((q3 / nl) * N + s0 + q3 % nl) * C + c];
+    }
+    for (; r < r1; ++r) a0 += g[((r / nl) * N + s0 + r % nl) * C + c];
+    part[((long)l * chunks + k) * C + c] = (a0 + a1) + (a2 + a3);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(&counter[l], 1) == chunks - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < chunks; ++j) s += __builtin_nontemporal_load(&part[((long)l * chunks + j) * C + c]);
+    dw[(long)l * C + c] = accumulate ? dw[(long)l * C + c] + s : s;
+  }
+  if (threadIdx.x == 0) counter[l] = 0;
+}
+
+static int level_starts(const char* who, const int* sizes, int L, int N, LevelStarts* ls) {
+  if (L < 1 || L > 8) return fail(RSCOTR_E_SHAPE, "%s: 1..8 levels supported, got %d", who, L);
+  if (!sizes) return fail(RSCOTR_E_ARG, "%s: null sizes", who);
+  ls->n = L;
+  int s = 0;
+  for (int i = 0; i < L; ++i) {
+    if (sizes[i] < 0) return fail(RSCOTR_E_SHAPE, "%s: negative level size", who);
+    ls->start[i] = s;
+    s += sizes[i];
+  }
+  ls->start[L] = s;
+  for (int i = L + 1; i < 9; ++i) ls->start[i] = s;
+  if (s != N) return fail(RSCOTR_E_SHAPE, "%s: level sizes sum to %d, N = %d", who, s, N);
+  return RSCOTR_OK;
+}
+
+}  // namespace rscotr
+
+using namespace rscotr;
+
+extern "C" int rscotr_level_embed_fwd(const float* x, int64_t x_bstride, const float* cst, int cst_batched, const float* w,
+                                      float* out, const int* sizes, int L, int B, int N, int C, void* stream) {
+  if (B < 0 || N < 0 || C <= 0 || (C & 3)) return fail(RSCOTR_E_SHAPE, "rscotr_level_embed_fwd: C must be a positive multiple of 4");
+  LevelStarts ls;
+  if (int e = level_starts("rscotr_level_embed_fwd", sizes, L, N, &ls)) return e;
+  const long total = (long)B * N * (C / 4);
+  if (total == 0) return RSCOTR_OK;
+  if (!w || !out) return fail(RSCOTR_E_ARG, "rscotr_level_embed_fwd: null pointer");
+  if (x && (x_bstride & 3)) return fail(RSCOTR_E_ALIGN, "rscotr_level_embed_fwd: x batch stride must be a multiple of 4");
+  if (!aligned16(w) || !aligned16(out) || (x && !aligned16(x)) || (cst && !aligned16(cst)))
+    return fail(RSCOTR_E_ALIGN, "rscotr_level_embed_fwd: 16-byte aligned tensors required");
+  level_embed_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float4*>(x), (long)(x_bstride / 4), reinterpret_cast<const float4*>(cst), cst_batched ? (long)N * (C / 4) : 0,
+      reinterpret_cast<const float4*>(w), reinterpret_cast<float4*>(out), ls, B, N, C / 4);
+  return check_launch("rscotr_level_embed_fwd");
+}
+
+extern "C" int64_t rscotr_level_embed_bwd_workspace(int L, int C) { return (int64_t)L * 32 * C * 4; }
+
+extern "C" int rscotr_level_embed_bwd(const float* g, float* dw, const int* sizes, int L, int B, int N, int C,
+                                      int accumulate, float* workspace, int* counters, void* stream) {
+  if (B < 0 || N < 0 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_level_embed_bwd: bad shape");
+  LevelStarts ls;
+  if (int e = level_starts("rscotr_level_embed_bwd", sizes, L, N, &ls)) return e;
+  if (!g || !dw || !workspace || !counters) return fail(RSCOTR_E_ARG, "rscotr_level_embed_bwd: null pointer");
+  level_embed_bwd_kernel<<<dim3(32, (unsigned)L), 256, 0, (hipStream_t)stream>>>(g, workspace, counters, dw, ls, B, N, C, accumulate);
+  return check_launch("rscotr_level_embed_bwd");
+}

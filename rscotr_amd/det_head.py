@@ -373,6 +373,7 @@ class DinoTransformer(nn.Module):
         self.enc_output_norm = nn.LayerNorm(self.embed_dims)
         self.query_embed = nn.Embedding(two_stage_num_proposals, self.embed_dims)
         self._geom_cache = {}
+        self._pos_cache = {}
 
     def init_weights(self):
         from .layers import MultiScaleDeformableAttention
@@ -432,18 +433,25 @@ class DinoTransformer(nn.Module):
                 encoder, reg_branches=None, cls_branches=None, record=None, **kwargs):
         assert self.as_two_stage and query_embed is None, 'as_two_stage must be True for DINO'
         device = mlvl_feats[0].device
-        feat_f, mask_f, pos_f, shapes = [], [], [], []
-        for lvl, (feat, mask, pos) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
+        feat_f, mask_f, shapes = [], [], []
+        for lvl, (feat, mask) in enumerate(zip(mlvl_feats, mlvl_masks)):
             shapes.append(tuple(feat.shape[-2:]))
             feat_f.append(feat.flatten(2).transpose(1, 2))
             mask_f.append(mask.flatten(1))
-            pos_f.append(pos.flatten(2).transpose(1, 2) + self.level_embeds[lvl].view(1, 1, -1))
         feat = torch.cat(feat_f, 1)
         mask_flat = torch.cat(mask_f, 1)
-        pos = torch.cat(pos_f, 1)
         # no padded image in the batch (known on the host): the padding mask is all-False and every masked_fill
         # with it is the identity — skipped (the reference executes them: detr_head.py / transformer.py:183-241)
         unpadded = kwargs.get('unpadded', False)
+        # lvl_pos_embed = pos + level_embeds[lvl] per level, concatenated (transformer.py:196-207): one launch over the
+        # token-layout encoding (a constant per level shapes when nothing is padded)
+        pkey = (tuple(shapes), str(device)) if unpadded else None
+        pos_tok = self._pos_cache.get(pkey) if pkey is not None else None
+        if pos_tok is None:
+            pos_tok = torch.cat([(p[:1] if unpadded else p).flatten(2).transpose(1, 2) for p in mlvl_pos_embeds], 1).contiguous()
+            if pkey is not None:
+                self._pos_cache[pkey] = pos_tok
+        pos = ops.level_embed_add(None, self.level_embeds, [h * w for h, w in shapes], const=pos_tok, batch=feat.shape[0])
         kpm = None if unpadded else mask_flat
         geom = LevelGeometry.get(shapes, device)
         # without padding the valid ratios are ones and the reference points / proposal geometry depend on the level

@@ -5,6 +5,7 @@ torch stream with raw device pointers (PyTorch only provides memory, streams and
 bookkeeping).  There is NO CPU / eager fallback: a missing library, a CPU tensor, or a non-zero
 return code raises.
 """
+import ctypes
 import os
 
 import torch
@@ -357,6 +358,73 @@ def sine_embed4(pos):
     out = torch.empty(p.shape[:-1] + (512,), dtype=torch.float32, device=p.device)
     lib.call('rscotr_sine_embed4', p.data_ptr(), out.data_ptr(), p.numel() // 4, _stream())
     return out
+
+
+_LEVEL_COUNTERS = {}
+
+
+class _LevelEmbedAdd(Function):
+    """out[b, t] = x[b, t] + const[b | 0, t] + weight[row0 + level(t)] over concatenated levels, ONE launch; backward:
+    d(x) = the incoming gradient itself, d(weight) = fixed-order segment sums (one launch, straight into the gradient arena
+    when the parameter is sunk) — instead of a broadcast add + concatenation per level forward and a sum-reduce / select
+    zero-fill / copy / accumulate chain per level in backward.  x may be a batch-strided view with dense rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, const, sizes, batch, row0):
+        L = len(sizes)
+        N = int(sum(sizes))
+        C = weight.shape[-1]
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        if x is not None and not (x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == C):
+            x = _f32c(x)
+        c2 = None if const is None else _f32c(const)
+        B = x.shape[0] if x is not None else (batch or c2.shape[0])
+        assert weight.shape[0] >= row0 + L and (x is None or x.shape == (B, N, C))
+        assert c2 is None or (c2.shape[1:] == (N, C) and c2.shape[0] in (1, B))
+        _chk(w, c2)
+        assert x is None or x.is_cuda
+        out = torch.empty((B, N, C), dtype=torch.float32, device=w.device)
+        arr = (ctypes.c_int * L)(*[int(v) for v in sizes])
+        lib.call('rscotr_level_embed_fwd', _ptr(x), 0 if x is None else x.stride(0), _ptr(c2),
+                 int(c2 is not None and c2.shape[0] == B and B > 1), w.data_ptr() + row0 * C * 4, out.data_ptr(), arr, L, B, N,
+                 C, _stream())
+        ctx.sizes, ctx.geom, ctx.weight = tuple(int(v) for v in sizes), (B, N, C, L, row0), weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, C, L, row0 = ctx.geom
+        need = ctx.needs_input_grad
+        gw = None
+        if need[1]:
+            g2 = _f32c(g)
+            dev = g2.device
+            sk = _sink(ctx.weight)
+            if sk is not None:
+                dw, acc = sk[1], 1
+            else:
+                dw = gw = (torch.zeros if ctx.weight.shape[0] > L else torch.empty)(
+                    tuple(ctx.weight.shape), dtype=torch.float32, device=dev)
+                acc = 0
+            cnt = _LEVEL_COUNTERS.get((dev, _stream()))
+            if cnt is None:  # (zero once; the kernel returns its counters to zero)
+                cnt = _LEVEL_COUNTERS[(dev, _stream())] = torch.zeros(8, dtype=torch.int32, device=dev)
+            nws = lib.rscotr_level_embed_bwd_workspace(L, C)
+            ws = _WS.get(nws, dev)
+            arr = (ctypes.c_int * L)(*ctx.sizes)
+            lib.call('rscotr_level_embed_bwd', g2.data_ptr(), dw.data_ptr() + row0 * C * 4, arr, L, B, N, C, acc, ws.data_ptr(),
+                     cnt.data_ptr(), _stream())
+            if sk is not None:
+                GRAD_SINK.grad_written(sk[0])
+        return (g if need[0] else None), gw, None, None, None, None
+
+
+def level_embed_add(x, weight, sizes, const=None, batch=None, row0=0):
+    """x (B,N,C) | None, const (B|1, N, C) | None (no gradient), weight (>= len(sizes), C): every token of level l gets
+    weight[l] added (levels concatenated along N, sizes[l] tokens each; level l takes row row0 + l); batch = B of the result when x is None."""
+    if const is not None:
+        const = const.detach()
+    return _LevelEmbedAdd.apply(x, weight, const, tuple(sizes), batch, row0)
 
 
 def msda_prep(off, logit, reference_points, offset_norm, L, P):

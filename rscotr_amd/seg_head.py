@@ -41,6 +41,7 @@ class MlvlSegPixelDecoder(nn.Module):
         self.output_convs = nn.ModuleList()
         self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1, stride=1, padding=0)
         self.num_outs = num_outs
+        self._pe_cache = {}
 
     def init_weights(self):
         nn.init.kaiming_uniform_(self.mask_feature.weight, a=1)  # caffe2_xavier_init
@@ -50,18 +51,23 @@ class MlvlSegPixelDecoder(nn.Module):
     def forward(self, encoder, neck_feats, backbone_feats):
         B = backbone_feats[0].shape[0]
         device = neck_feats[0].device
-        inputs, poss, shapes, refs = [], [], [], []
+        inputs, shapes, refs = [], [], []
         for i in range(self.num_encoder_levels):
             level_idx = self.num_input_levels - i - 1  # low -> high resolution
             f = neck_feats[level_idx]
             h, w = f.shape[-2:]
-            pe = self.postional_encoding.unpadded(B, h, w, device)
-            poss.append((self.level_encoding.weight[i].view(1, -1, 1, 1) + pe).flatten(2).transpose(1, 2))
             inputs.append(f.flatten(2).transpose(1, 2))
             shapes.append((h, w))
             refs.append(_grid_refs(h, w, self.strides[level_idx], device))
         x = torch.cat(inputs, 1)
-        pos = torch.cat(poss, 1)
+        # level_encoding.weight[i] + positional encoding per level, concatenated (pixel_decoder.py:108-118): one launch
+        # over the token-layout encoding of the level shapes (a constant)
+        pkey = (tuple(shapes), str(device))
+        pe_tok = self._pe_cache.get(pkey)
+        if pe_tok is None:
+            pe_tok = self._pe_cache[pkey] = torch.cat(
+                [self.postional_encoding.unpadded(1, h, w, device).flatten(2).transpose(1, 2) for h, w in shapes], 1).contiguous()
+        pos = ops.level_embed_add(None, self.level_encoding.weight, [h * w for h, w in shapes], const=pe_tok, batch=B)
         geom = LevelGeometry.get(shapes, device)
         ref = torch.cat(refs, 0)[None, :, None].expand(B, -1, self.num_encoder_levels, -1)
         # the reference passes an all-False padding mask: value.masked_fill is the identity
@@ -153,7 +159,9 @@ class Mask2FormerHead(nn.Module):
         dec_in, dec_pos = [], []
         for i in range(self.num_transformer_feat_level):
             m = memorys[i]
-            dec_in.append(m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1))
+            # (the map is a channels-last view of this level's rows of the encoder memory: read in place, batch-strided)
+            dec_in.append(ops.level_embed_add(m.flatten(2).transpose(1, 2), self.level_embed.weight,
+                                              [m.shape[-2] * m.shape[-1]], row0=i))
             dec_pos.append(self.decoder_positional_encoding.unpadded(B, m.shape[-2], m.shape[-1], device)
                            .flatten(2).transpose(1, 2))
         query_feat = self.query_feat.weight[None].expand(B, -1, -1)

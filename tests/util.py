@@ -168,6 +168,16 @@ def patch_ops_with_oracle(monkeypatch):
 
     monkeypatch.setattr(ops, 'msda_attention', msda_attention)
 
+    def level_embed_add(x, weight, sizes, const=None, batch=None, row0=0):
+        rows = torch.cat([weight[row0 + l].view(1, -1).expand(int(n), -1) for l, n in enumerate(sizes)], 0)[None]
+        out = rows if x is None else x + rows
+        if const is not None:
+            out = out + const.detach()
+        B = x.shape[0] if x is not None else (batch or const.shape[0])
+        return out.expand(B, -1, -1) if out.shape[0] != B else out
+
+    monkeypatch.setattr(ops, 'level_embed_add', level_embed_add)
+
     def match_cost_batched(cls_score, bbox_pred, gt_bboxes, gt_labels, factors, w_cls, w_l1, w_iou, alpha, gamma, eps):
         S, B, Q, C = cls_score.shape
         G = gt_bboxes.shape[1]
