@@ -215,6 +215,10 @@ def main():
                 print(f'[bench] iter {runner.iter} {(time.perf_counter() - t_it) * 1e3:.1f} ms'
                       f'{"" if a.verbose else " (host only)"}', file=sys.stderr, flush=True)
 
+    # the whole loop runs with the runner's stream current (runner.on_stream(): no per-iteration stream hand-over; the
+    # events below are recorded on that stream)
+    _loop_stream = contextlib.ExitStack()
+    _loop_stream.enter_context(runner.on_stream())
     # set-up outside the W warm-up steps: first round eager (parameter liveness, workspaces), second
     # round captures the shape-static tasks into hipGraphs (rscotr_amd.runner.GraphedTask)
     for _ in range(2):
@@ -266,6 +270,7 @@ def main():
         torch.cuda.synchronize()
         runner.force_eager = False
         hold['cycles'] = 0
+    _loop_stream.close()
     prof = []
     if rank == 0 and not a.no_roofline and (eager_timed or runner.graphed):
         import ctypes

@@ -75,12 +75,16 @@ int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int N
  *   loc (B,Nq,H,L,P,2) = ref_xy + off / norm[l]            for ref (B,Nq,L,2), norm (L,2) = (W_l, H_l), or
  *                      = ref_xy + off / P * ref_wh * 0.5   for ref (B,Nq,L,4) (norm unused, may be NULL);
  * backward: grad_off from grad_loc, grad_logit = attn * (grad_attn - sum attn*grad_attn); the reference points get
- * no gradient (they are detached on this path: bbox_head/transformer.py:115-121).  L*P <= 64. */
+ * no gradient (they are detached on this path: bbox_head/transformer.py:115-121).  L*P <= 64.
+ * Row (b, q) of off / grad_off starts at element (b*Nq+q) * ld_off (>= H*L*P*2, even), of logit / grad_logit at
+ * (b*Nq+q) * ld_logit (>= H*L*P): the two projections may be the column blocks of ONE (B*Nq, 3*H*L*P) product.
+ * ref_levels = L, or 1 for reference points shared by the levels (ref (B,Nq,1,.): valid ratios all one). */
 int rscotr_msda_prep_fwd(const float* off, const float* logit, const float* ref, const float* norm, float* loc,
-                         float* attn, int B, int Nq, int H, int L, int P, int refdim, void* stream);
+                         float* attn, int B, int Nq, int H, int L, int P, int refdim, int ld_off, int ld_logit,
+                         int ref_levels, void* stream);
 int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn, const float* ref,
                          const float* norm, float* grad_off, float* grad_logit, int B, int Nq, int H, int L, int P,
-                         int refdim, void* stream);
+                         int refdim, int ld_off, int ld_logit, int ref_levels, void* stream);
 
 /* ---- fp32 GEMM on the matrix cores, fused epilogue ----------------------------------------------
  * Replaces torch F.linear / nn.Linear and 1x1 / patchify nn.Conv2d (and the two backward
@@ -299,6 +303,11 @@ int rscotr_level_embed_fwd(const float* x, int64_t x_bstride, const float* cst, 
 /* Gradient of the embedding rows: dw[l, :] (+)= sum over b and the tokens of level l of g[b, t, :], fixed summation
  * order (bit-reproducible), one launch.  workspace: rscotr_level_embed_bwd_workspace(L, C) bytes; counters: L ints, zero
  * before the first call (the kernel returns them to zero). */
+/* out = [a | b | c | d]: flat concatenation of up to four fp32 arrays in one launch (packs the rows and biases of Linear
+ * layers that read the same operand, e.g. mmcv MultiScaleDeformableAttention's sampling_offsets and attention_weights,
+ * so that they run as one product). */
+int rscotr_pack4(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* d,
+                 int64_t nd, float* out, void* stream);
 int64_t rscotr_level_embed_bwd_workspace(int L, int C);
 int rscotr_level_embed_bwd(const float* g, float* dw, const int* sizes, int L, int B, int N, int C, int accumulate,
                            float* workspace, int* counters, void* stream);

@@ -71,18 +71,20 @@ template <int G>
 __global__ __launch_bounds__(256) void msda_prep_fwd_kernel(const float* __restrict__ off, const float* __restrict__ logit,
                                                             const float* __restrict__ ref, const float* __restrict__ norm,
                                                             float* __restrict__ loc, float* __restrict__ attn, long groups,
-                                                            int Nq, int H, int L, int P, int refdim) {
+                                                            int Nq, int H, int L, int P, int refdim, int ld_off,
+                                                            int ld_logit, int ref_levels) {
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
   const int s = threadIdx.x % G, LP = L * P;
   const bool in = gid < groups && s < LP;
   const long e = gid * LP + s;
   float lg = -3.0e38f;
   if (in) {
-    lg = logit[e];
     const long bq = gid / H;                // b * Nq + q
+    const int h = (int)(gid - bq * H);
+    lg = logit[bq * ld_logit + h * LP + s];
     const int l = s / P;
-    const float* r = ref + (bq * L + l) * refdim;
-    const float2 o = reinterpret_cast<const float2*>(off)[e];
+    const float* r = ref + (bq * ref_levels + (ref_levels > 1 ? l : 0)) * refdim;
+    const float2 o = *reinterpret_cast<const float2*>(off + bq * ld_off + (h * LP + s) * 2);
     float2 out;
     if (refdim == 2) {
       out.x = r[0] + o.x / norm[2 * l];
@@ -105,16 +107,17 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restr
                                                             const float* __restrict__ attn, const float* __restrict__ ref,
                                                             const float* __restrict__ norm, float* __restrict__ goff,
                                                             float* __restrict__ glogit, long groups, int Nq, int H, int L,
-                                                            int P, int refdim) {
+                                                            int P, int refdim, int ld_off, int ld_logit, int ref_levels) {
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
   const int s = threadIdx.x % G, LP = L * P;
   const bool in = gid < groups && s < LP;
   const long e = gid * LP + s;
+  const long bq = gid / H;
+  const int h = (int)(gid - bq * H);
   float p = 0.f, ga = 0.f;
   if (in) {
     p = attn[e];
     ga = gattn[e];
-    const long bq = gid / H;
     const int l = s / P;
     const float2 g = reinterpret_cast<const float2*>(gloc)[e];
     float2 out;
@@ -122,22 +125,26 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restr
       out.x = g.x / norm[2 * l];
       out.y = g.y / norm[2 * l + 1];
     } else {
-      const float* r = ref + (bq * L + l) * refdim;
+      const float* r = ref + (bq * ref_levels + (ref_levels > 1 ? l : 0)) * refdim;
       out.x = g.x * (r[2] * 0.5f) / (float)P;
       out.y = g.y * (r[3] * 0.5f) / (float)P;
     }
-    reinterpret_cast<float2*>(goff)[e] = out;
+    *reinterpret_cast<float2*>(goff + bq * ld_off + (h * LP + s) * 2) = out;
   }
   const float dot = group_sum<G>(p * ga);
-  if (in) glogit[e] = p * (ga - dot);
+  if (in) glogit[bq * ld_logit + h * LP + s] = p * (ga - dot);
 }
 
 }  // namespace rscotr
 
 using namespace rscotr;
 
-static int msda_prep_check(const char* fn, int B, int Nq, int H, int L, int P, int refdim) {
+static int msda_prep_check(const char* fn, int B, int Nq, int H, int L, int P, int refdim, int ld_off, int ld_logit,
+                           int ref_levels) {
   if (B < 0 || Nq < 0 || H <= 0 || L <= 0 || P <= 0) return fail(RSCOTR_E_SHAPE, "%s: bad shape", fn);
+  if (ld_off < H * L * P * 2 || (ld_off & 1) || ld_logit < H * L * P)
+    return fail(RSCOTR_E_SHAPE, "%s: row strides must cover a row (offsets: even)", fn);
+  if (ref_levels != L && ref_levels != 1) return fail(RSCOTR_E_SHAPE, "%s: ref_levels must be L or 1", fn);
   if (L * P > 64) return fail(RSCOTR_E_SHAPE, "%s: L*P = %d > 64", fn, L * P);
   if (refdim != 2 && refdim != 4) return fail(RSCOTR_E_SHAPE, "%s: reference points must be 2- or 4-d", fn);
   return RSCOTR_OK;
@@ -152,14 +159,15 @@ static int msda_prep_check(const char* fn, int B, int Nq, int H, int L, int P, i
   } while (0)
 
 extern "C" int rscotr_msda_prep_fwd(const float* off, const float* logit, const float* ref, const float* norm, float* loc,
-                                    float* attn, int B, int Nq, int H, int L, int P, int refdim, void* stream) {
-  if (int e = msda_prep_check("rscotr_msda_prep_fwd", B, Nq, H, L, P, refdim)) return e;
+                                    float* attn, int B, int Nq, int H, int L, int P, int refdim, int ld_off, int ld_logit,
+                                    int ref_levels, void* stream) {
+  if (int e = msda_prep_check("rscotr_msda_prep_fwd", B, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)) return e;
   const long groups = (long)B * Nq * H;
   if (groups == 0) return RSCOTR_OK;
   if (!off || !logit || !ref || !loc || !attn || (refdim == 2 && !norm))
     return fail(RSCOTR_E_ARG, "rscotr_msda_prep_fwd: null pointer");
 #define CALL(G) \
-  msda_prep_fwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(off, logit, ref, norm, loc, attn, groups, Nq, H, L, P, refdim)
+  msda_prep_fwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(off, logit, ref, norm, loc, attn, groups, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)
   MSDA_PREP_DISPATCH(L * P, CALL);
 #undef CALL
   return check_launch("rscotr_msda_prep_fwd");
@@ -167,14 +175,14 @@ extern "C" int rscotr_msda_prep_fwd(const float* off, const float* logit, const 
 
 extern "C" int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn, const float* ref,
                                     const float* norm, float* grad_off, float* grad_logit, int B, int Nq, int H, int L,
-                                    int P, int refdim, void* stream) {
-  if (int e = msda_prep_check("rscotr_msda_prep_bwd", B, Nq, H, L, P, refdim)) return e;
+                                    int P, int refdim, int ld_off, int ld_logit, int ref_levels, void* stream) {
+  if (int e = msda_prep_check("rscotr_msda_prep_bwd", B, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)) return e;
   const long groups = (long)B * Nq * H;
   if (groups == 0) return RSCOTR_OK;
   if (!grad_loc || !grad_attn || !attn || !ref || !grad_off || !grad_logit || (refdim == 2 && !norm))
     return fail(RSCOTR_E_ARG, "rscotr_msda_prep_bwd: null pointer");
 #define CALL(G) \
-  msda_prep_bwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_loc, grad_attn, attn, ref, norm, grad_off, grad_logit, groups, Nq, H, L, P, refdim)
+  msda_prep_bwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_loc, grad_attn, attn, ref, norm, grad_off, grad_logit, groups, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)
   MSDA_PREP_DISPATCH(L * P, CALL);
 #undef CALL
   return check_launch("rscotr_msda_prep_bwd");

@@ -338,17 +338,22 @@ class DinoTransformerDecoder(TransformerLayerSequence):
             outs.append(torch.stack((p[:, :, 0::2].sin(), p[:, :, 1::2].cos()), dim=3).flatten(2))
         return torch.cat(outs, dim=2)
 
-    def forward(self, query, value, reference_points, valid_ratios, reg_branches, attn_mask, key_padding_mask, geom):
+    def forward(self, query, value, reference_points, valid_ratios, reg_branches, attn_mask, key_padding_mask, geom,
+                unit_ratios=False):
         """Batch-first. Returns (normed outputs of the nl layers, each (B,Q,C); the nl+1 reference sets, each (B,Q,4)) as
         LISTS: the head applies a different branch to every layer's output, and indexing a stacked tensor would cost a
         full-size zero-fill + copy per use and an add per layer in backward (35 launches on 10 MB tensors per step)."""
         output = query
         inter, inter_ref = [], [reference_points]
-        vr4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+        vr4 = None if unit_ratios else torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         for lid, layer in enumerate(self.layers):
             assert reference_points.shape[-1] == 4
-            rp_in = reference_points[:, :, None] * vr4
-            query_pos = _mlp(ops.sine_embed4(rp_in[:, :, 0, :]), self.ref_point_head)
+            if unit_ratios:  # nothing padded: the valid ratios are ones, every level sees the reference points themselves
+                rp_in = reference_points[:, :, None]        # (B, Q, 1, 4): shared by the levels (no product, no copy)
+                query_pos = _mlp(ops.sine_embed4(reference_points), self.ref_point_head)
+            else:
+                rp_in = reference_points[:, :, None] * vr4
+                query_pos = _mlp(ops.sine_embed4(rp_in[:, :, 0, :]), self.ref_point_head)
             output = layer(output, None, value, query_pos=query_pos, attn_masks=attn_mask,
                            key_padding_mask=key_padding_mask, reference_points=rp_in, **geom.kwargs())
             tmp = _mlp(output, reg_branches[lid])
@@ -490,7 +495,7 @@ class DinoTransformer(nn.Module):
         refp = torch.cat([dn_bbox_query, topk_unact], dim=1) if dn_bbox_query is not None else topk_unact
         refp = refp.sigmoid()
         inter_states, inter_refs = self.decoder(query, memory, refp, valid_ratios, reg_branches, attn_mask,
-                                                kpm, geom)
+                                                kpm, geom, unit_ratios=unpadded)
         return inter_states, inter_refs, topk_score, topk_anchor
 
 

@@ -316,21 +316,31 @@ def msda(value, spatial_shapes, level_start_index, loc, attn):
     return _MSDA.apply(value, spatial_shapes, level_start_index, loc, attn)
 
 
-def _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P):
+def _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P, ld_off=None, ld_logit=None):
+    """off / logit: dense (B*Nq, H*L*P*2) / (B*Nq, H*L*P), or column blocks of one wider row (ld_* = its row stride);
+    ref (B,Nq,L|1,2|4)."""
     refdim = ref.shape[-1]
     loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=off.device)
     attn = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=off.device)
     lib.call('rscotr_msda_prep_fwd', off.data_ptr(), logit.data_ptr(), ref.data_ptr(), _ptr(norm), loc.data_ptr(),
-             attn.data_ptr(), B, Nq, H, L, P, refdim, _stream())
+             attn.data_ptr(), B, Nq, H, L, P, refdim, ld_off or H * L * P * 2, ld_logit or H * L * P, ref.shape[-2], _stream())
     return loc, attn
 
 
-def _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P):
-    goff = torch.empty((B, Nq, H, L * P * 2), dtype=torch.float32, device=attn.device)
-    glogit = torch.empty((B, Nq, H, L * P), dtype=torch.float32, device=attn.device)
+def _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P, packed=False):
+    """-> (grad_off, grad_logit); packed: the two as column blocks [0, 2n) and [2n, 3n) of ONE (B*Nq, 3n) tensor (n = H*L*P),
+    returned as (that tensor, None)."""
+    n = H * L * P
+    if packed:
+        both = torch.empty((B * Nq, 3 * n), dtype=torch.float32, device=attn.device)
+        goff, glogit, ldo, ldl = both, both[:, 2 * n:], 3 * n, 3 * n
+    else:
+        goff = torch.empty((B, Nq, H, L * P * 2), dtype=torch.float32, device=attn.device)
+        glogit = torch.empty((B, Nq, H, L * P), dtype=torch.float32, device=attn.device)
+        ldo, ldl = 2 * n, n
     lib.call('rscotr_msda_prep_bwd', gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), ref.data_ptr(), _ptr(norm),
-             goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, ref.shape[-1], _stream())
-    return goff, glogit
+             goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, ref.shape[-1], ldo, ldl, ref.shape[-2], _stream())
+    return (both, None) if packed else (goff, glogit)
 
 
 class _MSDAPrep(Function):
@@ -1220,10 +1230,11 @@ def gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, nb0, nb1, 
 MASK_NONE, MASK_SHARED, MASK_PER_IMAGE, MASK_PER_HEAD = 0, 1, 2, 3
 
 
-def _linear_param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b):
+def _linear_param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b, lda=None):
     """Parameter gradients of y = x W^T + b from A = dy (K rows, M columns as the k-major operand) and Bm = x:
     dW[row0:row0+M] (+)= A^T Bm, db[row0:row0+M] (+)= column sums of A (riding the dW contraction); straight into the
-    gradient arena when the parameter is sunk (then nothing is returned for it).  Returns (gw, gb, sink_w, sink_b)."""
+    gradient arena when the parameter is sunk (then nothing is returned for it).  `lda`: row stride of A when it is a column
+    block of a wider tensor.  Returns (gw, gb, sink_w, sink_b)."""
     dev = A.device
     skw = _sink(w_handle) if want_w else None
     skb = _sink(b_handle) if want_b else None
@@ -1236,16 +1247,20 @@ def _linear_param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b)
             rs = gb = torch.empty(M, dtype=torch.float32, device=dev)
     if want_w:
         if skw is not None and (skb is not None or not want_b):
-            _off_path(lambda: gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True,
+            _off_path(lambda: gemm(A, Bm, M, N, K, lda or M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True,
                                    rowsum=rs, rowsum_accumulate=rs_acc), A, Bm)
         elif skw is not None:
-            gemm(A, Bm, M, N, K, M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True, rowsum=rs,
+            gemm(A, Bm, M, N, K, lda or M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True, rowsum=rs,
                  rowsum_accumulate=rs_acc)
         else:
-            gw = gemm(A, Bm, M, N, K, M, N, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc)
+            gw = gemm(A, Bm, M, N, K, lda or M, N, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc)
     elif want_b:
+        assert lda is None or lda == M
         colsum(A, K, M, out=rs, accumulate=rs_acc)
     return gw, gb, skw, skb
+
+
+MSDA_PACKED_PROJ = os.environ.get('RSCOTR_MSDA_PACKED', '1') != '0'  # (A/B switch)
 
 
 class _MSDAAttn(Function):
@@ -1279,14 +1294,28 @@ class _MSDAAttn(Function):
         if kpm is not None:
             v.view(B, Nk, C).masked_fill_(kpm[..., None], 0.0)
         n_off, n_aw = H * L * P * 2, H * L * P
-        off = gemm(q2, ws[0], M, n_off, C, C, C, 0, 0, bias=b_off)
-        logit = gemm(q2, ws[1], M, n_aw, C, C, C, 0, 0, bias=b_aw)
-        loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
+        # sampling_offsets | attention_weights as ONE product over the packed rows of the two weights (one small packing
+        # launch instead of a second GEMM on the same operand; backward: one d(query) product over K = 3 n)
+        packed = MSDA_PACKED_PROJ and b_off is not None and b_aw is not None and n_off % 4 == 0 and C % 4 == 0
+        if packed:
+            n3 = n_off + n_aw
+            wb = torch.empty(n3 * C + n3, dtype=torch.float32, device=x2.device)
+            lib.call('rscotr_pack4', ws[0].data_ptr(), n_off * C, ws[1].data_ptr(), n_aw * C, b_off.data_ptr(), n_off,
+                     b_aw.data_ptr(), n_aw, wb.data_ptr(), _stream())
+            w_cat = wb[:n3 * C].view(n3, C)
+            both = gemm(q2, w_cat, M, n3, C, C, C, 0, 0, bias=wb[n3 * C:])
+            loc, attn = _msda_prep_fwd_raw(both, both.view(-1)[n_off:], ref, norm, B, Nq, H, L, P, ld_off=n3, ld_logit=n3)
+        else:
+            w_cat = None
+            off = gemm(q2, ws[0], M, n_off, C, C, C, 0, 0, bias=b_off)
+            logit = gemm(q2, ws[1], M, n_aw, C, C, C, 0, 0, bias=b_aw)
+            loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
         out = _msda_fwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn)
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(M, C))
         y = gemm(out.view(M, C), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2)
         ctx.save_for_backward(q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, *ws)
         ctx.kpm = kpm
+        ctx.w_cat = w_cat  # (a temporary of this node: not an autograd-tracked tensor)
         ctx.params = (w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)  # handles for the gradient sink
         ctx.geom = (B, Nq, Nk, C, H, D, L, P)
         ctx.flags = (v_is_x, id_is_x, q_pos is not None, identity is not None)
@@ -1311,13 +1340,21 @@ class _MSDAAttn(Function):
         d_out = gemm(g, w_o, M, C, C, C, C, 0, 1)
         # sampling kernel and the location / softmax arithmetic
         gv, gloc, gattn = _msda_bwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn, d_out.view(B, Nq, C))
-        goff, glogit = _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P)
-        goff, glogit, gv = goff.view(M, n_off), glogit.view(M, n_aw), gv.view(Mk, C)
+        w_cat = ctx.w_cat
+        packed = w_cat is not None
+        n3 = n_off + n_aw
+        goff, glogit = _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P, packed=packed)
+        gv = gv.view(Mk, C)
+        if packed:
+            both = goff                             # (M, 3 n): [d(offsets) | d(logits)]
+            goff, glogit, ldg = both.view(-1), both.view(-1)[n_off:], n3   # (flat aliases: column blocks with row stride 3 n)
+        else:
+            goff, glogit, ldg = goff.view(M, n_off), glogit.view(M, n_aw), None
         if ctx.kpm is not None:
             gv.view(B, Nk, C).masked_fill_(ctx.kpm[..., None], 0.0)
-        gw_off, gb_off, s1, s2 = _linear_param_grad(goff, q2, n_off, C, M, p_off, pb_off, 0, need[12], pb_off is not None and need[13])
+        gw_off, gb_off, s1, s2 = _linear_param_grad(goff, q2, n_off, C, M, p_off, pb_off, 0, need[12], pb_off is not None and need[13], lda=ldg)
         sinks += [s1, s2]
-        gw_aw, gb_aw, s1, s2 = _linear_param_grad(glogit, q2, n_aw, C, M, p_aw, pb_aw, 0, need[14], pb_aw is not None and need[15])
+        gw_aw, gb_aw, s1, s2 = _linear_param_grad(glogit, q2, n_aw, C, M, p_aw, pb_aw, 0, need[14], pb_aw is not None and need[15], lda=ldg)
         sinks += [s1, s2]
         gw_v, gb_v, s1, s2 = _linear_param_grad(gv, val2, C, C, Mk, p_v, pb_v, 0, need[16], pb_v is not None and need[17])
         sinks += [s1, s2]
@@ -1331,15 +1368,18 @@ class _MSDAAttn(Function):
         d_x = d_pos = d_val = None
         merge_id = id_is_x and want_x
         if want_x or want_pos:
-            pure = gemm(goff, w_off, M, C, n_off, n_off, C, 0, 1)
-            if want_pos and want_x and (merge_id or v_is_x):
-                d_x = torch.empty_like(pure)  # pure = d(query_pos); d_x = pure (+ dy) (+ d(value) below)
-                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True, out2=d_x,
-                     resid=g if merge_id else None)
+            two = want_pos and want_x and (merge_id or v_is_x)
+            res = g if (merge_id and (two or not want_pos)) else None
+            if two:
+                d_x = torch.empty((M, C), dtype=torch.float32, device=g.device)  # pure = d(query_pos); d_x = pure (+ dy) (+ d(value) below)
+            if packed:
+                pure = gemm(both, w_cat, M, C, n3, n3, C, 0, 1, out2=d_x if two else None, resid=res)
+            else:
+                pure = gemm(goff, w_off, M, C, n_off, n_off, C, 0, 1)
+                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True, out2=d_x if two else None, resid=res)
+            if two:
                 d_pos = pure
             else:
-                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True,
-                     resid=g if (merge_id and not want_pos) else None)
                 d_x = pure if want_x else None
                 d_pos = pure if want_pos else None
             if v_is_x and want_x:

@@ -5,6 +5,7 @@ Per iteration: batch = next(MultiDataLoader) -> model.train_step -> zero_grad ->
 [gradient buckets all-reduced while backward runs] -> clip_grad_norm_ -> AdamW.step -> LR
 schedule / logging.  Hook order is the reference's: zero_grad, backward, clip, step.
 """
+import contextlib
 import os
 import time
 from collections import OrderedDict
@@ -248,8 +249,8 @@ class IterBasedRunner:
         for h in self.hooks:
             if hasattr(h, 'before_train_iter'):
                 h.before_train_iter(self)
-        if self.stream is None:
-            out = self._train_iter()
+        if self.stream is None or torch.cuda.current_stream() == self.stream:
+            out = self._train_iter()  # (inside on_stream(): no stream hand-over per iteration)
         else:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -322,9 +323,27 @@ class IterBasedRunner:
                                                        if k.endswith('.loss')))
         return out
 
+    @contextlib.contextmanager
+    def on_stream(self):
+        """Make the runner's stream the current stream for a whole loop.  A train_iter() called from another stream hands
+        over to the runner's stream and back with two cross-stream event waits; on this runtime the two streams sit on
+        different hardware queues and every such hand-over stalls the device for ~0.3 ms (measured: 2.1 ms per round of
+        three iterations, the gain of GPU_MAX_HW_QUEUES=1) — inside this context there is one hand-over per loop."""
+        if self.stream is None or torch.cuda.current_stream() == self.stream:
+            yield self
+            return
+        outer = torch.cuda.current_stream()
+        self.stream.wait_stream(outer)
+        try:
+            with torch.cuda.stream(self.stream):
+                yield self
+        finally:
+            outer.wait_stream(self.stream)
+
     def run(self, max_iters):
-        while self.iter < max_iters:
-            self.train_iter()
+        with self.on_stream():
+            while self.iter < max_iters:
+                self.train_iter()
 
 
 def build_runner(model, cfg, data_loader, **kwargs):

@@ -35,3 +35,37 @@ def test_level_embed_add_and_gradient(cuda, B, sizes, C, rows, row0, batched):
         w.grad = None
         ops.level_embed_add(xin, w, sizes, const=cst, batch=B, row0=row0).backward(go)
         assert torch.equal(first, w.grad)
+
+
+@pytest.mark.parametrize('refdim', [2, 4])
+def test_msda_prep_strided_rows_and_shared_reference_points(cuda, refdim):
+    """rscotr_msda_prep_fwd / _bwd with the offsets | logits read from (written to) the column blocks of ONE (B*Nq, 3n)
+    tensor and with reference points shared by the levels (ref_levels = 1) give bit-identical results to the dense,
+    per-level form (mmcv MultiScaleDeformableAttention.forward's element-wise lines)."""
+    from rscotr_amd import ops
+    B, Nq, H, L, P = 2, 37, 8, 4, 4
+    n = H * L * P
+    g = torch.Generator(device='cpu').manual_seed(5)
+    both = torch.randn(B * Nq, 3 * n, generator=g).to(cuda)
+    off, logit = both[:, :2 * n].contiguous(), both[:, 2 * n:].contiguous()
+    ref1 = torch.rand(B, Nq, 1, refdim, generator=g).to(cuda)
+    refL = ref1.expand(B, Nq, L, refdim).contiguous()
+    norm = torch.tensor([[64., 64.], [32., 32.], [16., 16.], [8., 8.]], device=cuda)
+    loc0, attn0 = ops._msda_prep_fwd_raw(off, logit, refL, norm, B, Nq, H, L, P)
+    loc1, attn1 = ops._msda_prep_fwd_raw(both, both.view(-1)[2 * n:], ref1, norm, B, Nq, H, L, P, ld_off=3 * n, ld_logit=3 * n)
+    assert torch.equal(loc0, loc1) and torch.equal(attn0, attn1)
+    gloc, gattn = torch.randn(loc0.shape, generator=g).to(cuda), torch.randn(attn0.shape, generator=g).to(cuda)
+    goff0, glogit0 = ops._msda_prep_bwd_raw(gloc, gattn, attn0, refL, norm, B, Nq, H, L, P)
+    packed, none = ops._msda_prep_bwd_raw(gloc, gattn, attn0, ref1, norm, B, Nq, H, L, P, packed=True)
+    assert none is None and packed.shape == (B * Nq, 3 * n)
+    assert torch.equal(packed[:, :2 * n], goff0.view(B * Nq, 2 * n)) and torch.equal(packed[:, 2 * n:], glogit0.view(B * Nq, n))
+
+
+def test_pack4(cuda):
+    from rscotr_amd import ops
+    from rscotr_amd._lib import lib
+    parts = [torch.randn(k, device=cuda) for k in (1000, 7, 0, 333)]
+    out = torch.empty(1340, device=cuda)
+    lib.call('rscotr_pack4', parts[0].data_ptr(), 1000, parts[1].data_ptr(), 7, 0, 0, parts[3].data_ptr(), 333, out.data_ptr(),
+             ops._stream())
+    assert torch.equal(out, torch.cat(parts))
