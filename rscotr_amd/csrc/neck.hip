@@ -107,6 +107,7 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, float* __rest
   if (i >= B * G) return;
   const int b = i / G, g = i - b * G;
   float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
   for (int c = 0; c < chunks; ++c) {
     const float* row = part + ((long)b * chunks + c) * (2 * G + 2 * C);
     s1 += row[2 * g];
@@ -125,6 +126,7 @@ __global__ void gn_finalize_bwd_kernel(const float* __restrict__ part, float* __
   if (i < B * G) {
     const int b = i / G, g = i - b * G;
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int c = 0; c < chunks; ++c) {
       const float* row = part + ((long)b * chunks + c) * (2 * G + 2 * C);
       s1 += row[2 * g];
@@ -137,6 +139,7 @@ __global__ void gn_finalize_bwd_kernel(const float* __restrict__ part, float* __
     float* dst = i < C ? dgamma : dbeta;
     if (dst) {
       float s = 0.f;
+#pragma unroll 8
       for (int r = 0; r < B * chunks; ++r) s += part[(long)r * (2 * G + 2 * C) + 2 * G + i];
       dst[i < C ? i : i - C] += s;
     }
@@ -229,7 +232,9 @@ static int gn_check(const char* fn, int B, int L, int C, int G) {
 }
 
 static dim3 gn_stats_grid(int B, int L, int* tpb) {
-  int chunks = std::max(1, std::min((L + 255) / 256, 32));
+  // ~32 tokens per workgroup, at most 128 chunks per image: 2 x 128 workgroups on the largest level (with 32 chunks of
+  // 128 tokens the 64 workgroups of a (2, 4096, 256) level ran 16-28 us, latency-bound on a quarter of the chip)
+  int chunks = std::max(1, std::min((L + 31) / 32, 128));
   *tpb = (L + chunks - 1) / chunks;
   chunks = (L + *tpb - 1) / *tpb;
   return dim3(chunks, B);

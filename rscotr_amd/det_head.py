@@ -216,7 +216,7 @@ class DetStatic:
     uploaded; `update_into` refreshes a captured iteration's static copies."""
 
     KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
-            'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r')
+            'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales')
 
     def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None):
         gen = head.dn_generator
@@ -292,6 +292,27 @@ class DetStatic:
         # 282-283) averages one of these four numbers over the ranks: one small all-reduce, here, outside
         # any captured region
         self.t['norms_r'] = ops.dist_mean_tensor(self.t['norms']).clone()
+        # loss_weight / (max(normaliser, 1) + eps) of the three losses, for the matching part (row 0) and the denoising
+        # part (row 1) (detr_head.py:379-396): six numbers known with the counts — on one rank they are computed on the
+        # host with the fp32 operations torch would run (clamp, add, reciprocal, multiply) and ride the upload
+        w3 = (head.loss_cls.loss_weight, head.loss_bbox.loss_weight, head.loss_iou.loss_weight)
+        if ops.dist_world() == 1:
+            f32 = np.float32
+            rows = []
+            for ci, pi in ((0, 1), (2, 3)):
+                rc = f32(1.0) / (np.maximum(norms[ci], f32(1.0)) + f32(FP32_EPS))
+                rp = f32(1.0) / (np.maximum(norms[pi], f32(1.0)) + f32(FP32_EPS))
+                rows.append([rc * f32(w3[0]), rp * f32(w3[1]), rp * f32(w3[2])])
+            self.t['scales'] = torch.from_numpy(np.asarray(rows, dtype=np.float32)).to(device, non_blocking=True)
+        else:
+            nr, nn_ = self.t['norms_r'], self.t['norms']
+            rows = []
+            for ci, pi in ((0, 1), (2, 3)):
+                cavg = (nr if head.sync_cls_avg_factor else nn_)[ci]
+                rc = 1.0 / (cavg.clamp(min=1) + FP32_EPS)
+                rp = 1.0 / (nr[pi].clamp(min=1.0) + FP32_EPS)
+                rows.append(torch.stack([rc * w3[0], rp * w3[1], rp * w3[2]]))
+            self.t['scales'] = torch.stack(rows)
 
     def key(self):
         return (self.gcap, self.padcap, tuple(self.img_shapes))
@@ -527,6 +548,7 @@ class DINOHead(nn.Module):
         self.loss_cls, self.loss_bbox, self.loss_iou = MODELS.build(loss_cls), MODELS.build(loss_bbox), MODELS.build(loss_iou)
         self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid else num_classes + 1
         self.positional_encoding = MODELS.build(positional_encoding)
+        self._zero_masks = {}
         self.transformer = MODELS.build(transformer)
         self.embed_dims = self.transformer.embed_dims
         assert positional_encoding['num_feats'] * 2 == self.embed_dims
@@ -601,13 +623,10 @@ class DINOHead(nn.Module):
             .scatter_(2, idx, t['gt_lab'][None].expand(S, -1, -1))[:, :, :Q]
         bbox_t = torch.zeros((S, B, Q + 1, 4), device=dev).scatter_(2, idx4, t['gt_boxn'][None].expand(S, -1, -1, -1))[:, :, :Q]
         bbox_w = torch.zeros((S, B, Q + 1, 4), device=dev).scatter_(2, idx4, torch.ones((S, B, G, 4), device=dev))[:, :, :Q]
-        norms = t['norms_r']
-        cavg = norms[0] if self.sync_cls_avg_factor else t['norms'][0]
-        cavg_dn = norms[2] if self.sync_cls_avg_factor else t['norms'][2]
-        npos_r, npos_dn_r = norms[1], norms[3]
-        l_cls, l_box, l_iou = self._set_losses(cls_sets, box_sets, labels, bbox_t, bbox_w, cavg, npos_r, st.img_shapes,
-                                               factors=t['factors'])
-        m3 = torch.stack([l_cls, l_box, l_iou], 1)  # (S, 3): rows = interm, d0..d{nl-2}, final
+        # (S, 3) = [cls, bbox, iou] sums of every set times the batch's precomputed weight / normaliser (DetStatic.scales)
+        m3 = self._set_losses(cls_sets, box_sets, labels, bbox_t, bbox_w, None, None, st.img_shapes,
+                              factors=t['factors'], scales=t['scales'][0])  # rows = interm, d0..d{nl-2}, final
+        l_cls, l_box, l_iou = m3[:, 0], m3[:, 1], m3[:, 2]
         d = dict()
         d['interm_loss_cls'], d['interm_loss_bbox'], d['interm_loss_iou'] = l_cls[0], l_box[0], l_iou[0]
         d['loss_cls'], d['loss_bbox'], d['loss_iou'] = l_cls[S - 1], l_box[S - 1], l_iou[S - 1]
@@ -620,14 +639,14 @@ class DINOHead(nn.Module):
         dbt = t['gt_boxn'].reshape(-1, 4)[t['slot_src']] * pos.unsqueeze(-1)
         dbw = pos.unsqueeze(-1).expand(-1, -1, 4)
         exp = lambda x: x[None].expand(nl, *x.shape)
-        l_cls, l_box, l_iou = self._set_losses(dn_cls, dn_box, exp(dlabels), exp(dbt), exp(dbw), cavg_dn, npos_dn_r,
-                                               st.img_shapes, factors=t['factors'], cls_weight=exp(t['slot_inpad']))
+        d3 = self._set_losses(dn_cls, dn_box, exp(dlabels), exp(dbt), exp(dbw), None, None, st.img_shapes,
+                              factors=t['factors'], cls_weight=exp(t['slot_inpad']), scales=t['scales'][1])
+        l_cls, l_box, l_iou = d3[:, 0], d3[:, 1], d3[:, 2]  # (nl, 3): rows = d0..d{nl-2}, final
         d['dn_loss_cls'], d['dn_loss_bbox'], d['dn_loss_iou'] = l_cls[nl - 1], l_box[nl - 1], l_iou[nl - 1]
         for l in range(nl - 1):
             d[f'd{l}.dn_loss_cls'], d[f'd{l}.dn_loss_bbox'], d[f'd{l}.dn_loss_iou'] = l_cls[l], l_box[l], l_iou[l]
         # the same 39 scalars as ONE vector in key order, for MTL.pack_losses: summing / stacking 39 0-d views one by one
         # costs ~200 tiny launches per iteration (forward and the select / expand / add chain of their backward)
-        d3 = torch.stack([l_cls, l_box, l_iou], 1)  # (nl, 3): rows = d0..d{nl-2}, final
         perm = getattr(self, '_loss_perm', None)
         if perm is None or perm[0].numel() != S or perm[0].device != m3.device:
             perm = self._loss_perm = (torch.tensor([0, S - 1] + list(range(1, S - 1)), device=m3.device),
@@ -669,7 +688,10 @@ class DINOHead(nn.Module):
                 mask = torch.nn.functional.interpolate(img_masks[None], size=(h, w)).to(torch.bool).squeeze(0)
                 mlvl_pos.append(self.positional_encoding(mask))
             else:
-                mask = torch.zeros((B, h, w), dtype=torch.bool, device=device)
+                mkey = (B, h, w, str(device))
+                mask = self._zero_masks.get(mkey)
+                if mask is None:  # (a constant: nothing is padded)
+                    mask = self._zero_masks[mkey] = torch.zeros((B, h, w), dtype=torch.bool, device=device)
                 mlvl_pos.append(self.positional_encoding.unpadded(B, h, w, device))
             mlvl_masks.append(mask)
         hs, inter_references, topk_score, topk_anchor = self.transformer(
@@ -714,7 +736,12 @@ class DINOHead(nn.Module):
     def extract_dn_outputs(all_cls_scores, all_bbox_preds, dn_meta):
         if dn_meta is not None:
             p = dn_meta['pad_size']
-            return all_cls_scores[:, :, p:], all_bbox_preds[:, :, p:], all_cls_scores[:, :, :p], all_bbox_preds[:, :, :p]
+            # one split per tensor: its backward is ONE concatenation (two slices cost a full-size zero-fill + copy each
+            # and an add where they meet)
+            q = all_cls_scores.shape[2] - p
+            dn_cls, m_cls = torch.split(all_cls_scores, [p, q], dim=2)
+            dn_box, m_box = torch.split(all_bbox_preds, [p, q], dim=2)
+            return m_cls, m_box, dn_cls, dn_box
         return all_cls_scores, all_bbox_preds, None, None
 
     def _match(self, cls_sets, box_sets, gt_bboxes, gt_labels, img_shapes, record=None):
@@ -757,10 +784,19 @@ class DINOHead(nn.Module):
         return packed[0], packed[1], packed[2], packed[3]
 
     def _set_losses(self, cls_sets, box_sets, labels, bbox_targets, bbox_weights, cls_avg, npos, img_shapes,
-                    factors=None, cls_weight=None):
+                    factors=None, cls_weight=None, scales=None):
         """detr_head.py:372-415 for S sets at once. `cls_avg` / `npos` are the (rank-averaged)
-        normalisers before clamping. Returns three (S,) tensors."""
+        normalisers before clamping. Returns three (S,) tensors; with `scales` (3,) = weight / (clamped normaliser + eps)
+        of [cls, bbox, iou] given instead of the normalisers: ONE (S, 3) tensor [cls, bbox, iou] (one stack + one multiply
+        instead of a clamp / add / reciprocal / multiply chain per loss)."""
         S, B, Q, C = cls_sets.shape
+        if scales is not None:
+            assert Q > 0
+            raw_cls = ops.sigmoid_focal_loss_sum(cls_sets.reshape(S, B * Q, C), labels.reshape(S, B * Q),
+                                                 self.loss_cls.gamma, self.loss_cls.alpha,
+                                                 None if cls_weight is None else cls_weight.reshape(S, B * Q))
+            l1, gi = ops.box_loss_sums(box_sets, bbox_targets, bbox_weights, factors.view(B, 4), self.loss_iou.eps)
+            return torch.stack([raw_cls, l1, gi], 1) * scales
         cls_avg = ops.clamp_min(cls_avg, 1)
         if Q > 0:
             loss_cls = ops.sigmoid_focal_loss_sum(cls_sets.reshape(S, B * Q, C), labels.reshape(S, B * Q),
