@@ -303,6 +303,20 @@ int rscotr_level_embed_fwd(const float* x, int64_t x_bstride, const float* cst, 
 /* Gradient of the embedding rows: dw[l, :] (+)= sum over b and the tokens of level l of g[b, t, :], fixed summation
  * order (bit-reproducible), one launch.  workspace: rscotr_level_embed_bwd_workspace(L, C) bytes; counters: L ints, zero
  * before the first call (the kernel returns them to zero). */
+/* Contrastive denoising queries of DINO in slot layout (models/multi/bbox_head/query_denoising.py:104-178: label flip,
+ * box jitter of the positive / negative copies, clamp, cxcywh, inverse_sigmoid(eps = 1e-3), label-embedding lookup) in ONE
+ * launch.  Slot s copies ground truth slot_src[s] (index into gt_lab (.,) / gt_boxn (., 4), normalised cxcywh); slot_valid /
+ * slot_neg (n_slots) floats 0 | 1; u (n_slots, 10) = [label_p, new_label, sign x 4, part x 4]: raw uniforms in [0, 1) when
+ * uniform != 0 (new_label = floor(u * num_classes), sign = u >= 0.5), else the reference's own draws (integer-valued).
+ * label_thr = label_noise_scale / 2 (<= 0: no flips), box_scale = box_noise_scale (<= 0: no jitter).  Outputs: kl_out
+ * (n_slots) the noised labels, q_label (n_slots, C) = embed[kl] (zero rows for invalid slots), q_bbox (n_slots, 4).
+ * rscotr_cdn_embed_grad: d(embed)[r] (+)= sum of g[s] over the valid slots with kl[s] == r, in slot order. */
+int rscotr_cdn_queries(const int64_t* gt_lab, const float* gt_boxn, const int64_t* slot_src, const float* slot_valid,
+                       const float* slot_neg, const float* u, int uniform, const float* embed, float label_thr,
+                       float box_scale, int num_classes, int64_t* kl_out, float* q_label, float* q_bbox, int n_slots, int C,
+                       void* stream);
+int rscotr_cdn_embed_grad(const float* g, const int64_t* kl, const float* slot_valid, float* dw, int rows, int n_slots,
+                          int C, int accumulate, void* stream);
 /* out = [a | b | c | d]: flat concatenation of up to four fp32 arrays in one launch (packs the rows and biases of Linear
  * layers that read the same operand, e.g. mmcv MultiScaleDeformableAttention's sampling_offsets and attention_weights,
  * so that they run as one product). */

@@ -87,6 +87,73 @@ __global__ __launch_bounds__(256) void pack4_kernel(const float* __restrict__ a,
   if (i < nd) out[o] = d[i];
 }
 
+
+// ---- contrastive denoising queries in slot layout (models/multi/bbox_head/query_denoising.py:104-178) ---------------------
+// One wavefront per denoising slot: lane 0 derives the noised label and box of the slot from its ground truth and its ten
+// random numbers u = [label_p, new_label, sign x 4, part x 4] (uniform != 0: raw uniforms — new_label = floor(u * classes),
+// sign = u >= 0.5; else already the reference's draws, integer-valued), all lanes then gather the label-embedding row.
+__global__ __launch_bounds__(256) void cdn_queries_kernel(const int64_t* __restrict__ gt_lab, const float* __restrict__ gt_boxn,
+                                                          const int64_t* __restrict__ slot_src, const float* __restrict__ slot_valid,
+                                                          const float* __restrict__ slot_neg, const float* __restrict__ u,
+                                                          int uniform, const float* __restrict__ embed, float label_thr,
+                                                          float box_scale, int num_classes, int64_t* __restrict__ kl_out,
+                                                          float* __restrict__ q_label, float* __restrict__ q_bbox, int n, int C) {
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slot >= n) return;
+  const long src = slot_src[slot];
+  const bool valid = slot_valid[slot] > 0.f;
+  long kl = gt_lab[src];
+  const float* r = u + (long)slot * 10;
+  if (label_thr > 0.f && r[0] < label_thr) {
+    kl = uniform ? min((long)(r[1] * (float)num_classes), (long)num_classes - 1) : (long)r[1];
+  }
+  if (lane == 0) {
+    const float cx = gt_boxn[src * 4], cy = gt_boxn[src * 4 + 1], w = gt_boxn[src * 4 + 2], h = gt_boxn[src * 4 + 3];
+    float kb[4] = {cx, cy, w, h};
+    if (box_scale > 0.f) {
+      const float hw = w / 2.f, hh = h / 2.f;
+      float xy[4] = {cx - hw, cy - hh, cx + hw, cy + hh};
+      const float df[4] = {hw, hh, hw, hh};
+      const float neg = slot_neg[slot];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sg = uniform ? (r[2 + k] >= 0.5f ? 1.f : 0.f) : r[2 + k];
+        const float part = (r[6 + k] + neg) * (sg * 2.0f - 1.0f);
+        xy[k] = fminf(fmaxf(xy[k] + part * df[k] * box_scale, 0.f), 1.f);
+      }
+      kb[0] = (xy[0] + xy[2]) / 2.f; kb[1] = (xy[1] + xy[3]) / 2.f; kb[2] = xy[2] - xy[0]; kb[3] = xy[3] - xy[1];
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {  // inverse_sigmoid(kb, eps = 1e-3)
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float x = fminf(fmaxf(kb[k], 0.f), 1.f);
+        v[k] = logf(fmaxf(x, 1e-3f) / fmaxf(1.f - x, 1e-3f));
+      }
+      o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    reinterpret_cast<float4*>(q_bbox)[slot] = o;
+    kl_out[slot] = kl;
+  }
+  const float4* row = reinterpret_cast<const float4*>(embed + kl * C);
+  float4* dst = reinterpret_cast<float4*>(q_label + (long)slot * C);
+  for (int c = lane; c < (C >> 2); c += 64) dst[c] = valid ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// d(embedding)[r, :] (+)= sum over the valid slots with label r of g[slot, :], slots in order (bit-reproducible)
+__global__ __launch_bounds__(256) void cdn_embed_grad_kernel(const float* __restrict__ g, const int64_t* __restrict__ kl,
+                                                             const float* __restrict__ slot_valid, float* __restrict__ dw,
+                                                             int n, int C, int accumulate) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int s = 0; s < n; ++s)
+      if (kl[s] == r && slot_valid[s] > 0.f) acc += g[(long)s * C + c];
+    dw[(long)r * C + c] = accumulate ? dw[(long)r * C + c] + acc : acc;
+  }
+}
+
 static int level_starts(const char* who, const int* sizes, int L, int N, LevelStarts* ls) {
   if (L < 1 || L > 8) return fail(RSCOTR_E_SHAPE, "%s: 1..8 levels supported, got %d", who, L);
   if (!sizes) return fail(RSCOTR_E_ARG, "%s: null sizes", who);
@@ -144,4 +211,29 @@ extern "C" int rscotr_pack4(const float* a, int64_t na, const float* b, int64_t 
   if (!out || (na && !a) || (nb && !b) || (nc && !c) || (nd && !d)) return fail(RSCOTR_E_ARG, "rscotr_pack4: null pointer");
   pack4_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, na, b, nb, c, nc, d, nd, out);
   return check_launch("rscotr_pack4");
+}
+
+extern "C" int rscotr_cdn_queries(const int64_t* gt_lab, const float* gt_boxn, const int64_t* slot_src, const float* slot_valid,
+                                  const float* slot_neg, const float* u, int uniform, const float* embed, float label_thr,
+                                  float box_scale, int num_classes, int64_t* kl_out, float* q_label, float* q_bbox,
+                                  int n_slots, int C, void* stream) {
+  if (n_slots < 0 || C <= 0 || (C & 3) || num_classes <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_cdn_queries: bad shape");
+  if (n_slots == 0) return RSCOTR_OK;
+  if (!gt_lab || !gt_boxn || !slot_src || !slot_valid || !slot_neg || !u || !embed || !kl_out || !q_label || !q_bbox)
+    return fail(RSCOTR_E_ARG, "rscotr_cdn_queries: null pointer");
+  if (!aligned16(embed) || !aligned16(q_label) || !aligned16(q_bbox))
+    return fail(RSCOTR_E_ALIGN, "rscotr_cdn_queries: 16-byte aligned embedding / outputs required");
+  cdn_queries_kernel<<<(unsigned)((n_slots + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, embed, label_thr, box_scale, num_classes, kl_out, q_label,
+      q_bbox, n_slots, C);
+  return check_launch("rscotr_cdn_queries");
+}
+
+extern "C" int rscotr_cdn_embed_grad(const float* g, const int64_t* kl, const float* slot_valid, float* dw, int rows,
+                                     int n_slots, int C, int accumulate, void* stream) {
+  if (rows < 0 || n_slots < 0 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_cdn_embed_grad: bad shape");
+  if (rows == 0) return RSCOTR_OK;
+  if (!g || !kl || !slot_valid || !dw) return fail(RSCOTR_E_ARG, "rscotr_cdn_embed_grad: null pointer");
+  cdn_embed_grad_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(g, kl, slot_valid, dw, n_slots, C, accumulate);
+  return check_launch("rscotr_cdn_embed_grad");
 }

@@ -165,30 +165,19 @@ class CdnQueryGenerator:
         t = st.t
         B, PC = t['slot_src'].shape
         dev = t['slot_src'].device
-        lab = t['gt_lab'].reshape(-1)[t['slot_src']]
-        boxn = t['gt_boxn'].reshape(-1, 4)[t['slot_src']]
+        # ten random numbers per slot, u = [label_p, new_label, sign x 4, part x 4]: ONE draw of raw uniforms on the device
+        # (capturable), or the reference-order draws gathered into slots; label flip, box jitter, inverse sigmoid and the
+        # label-embedding lookup then run as one launch (ops.cdn_queries) instead of ~35 element-wise ones
         if rnd is None:
-            label_p = torch.rand((B, PC), device=dev)
-            new_label = torch.randint(0, self.num_classes, (B, PC), device=dev)
-            rand_sign = torch.randint(0, 2, (B, PC, 4), device=dev).float()
-            rand_part = torch.rand((B, PC, 4), device=dev)
+            u, uniform = torch.rand((B, PC, 10), device=dev), True
         else:
             k = t['slot_k']
-            label_p, new_label = rnd['label_p'][k], rnd['new_label'][k]
-            rand_sign, rand_part = rnd['rand_sign'][k], rnd['rand_part'][k]
-        kl, kb = lab, boxn
-        if self.label_noise_scale > 0:
-            kl = torch.where(label_p < self.label_noise_scale * 0.5, new_label, lab)
-        if self.box_noise_scale > 0:
-            half = boxn[..., 2:] / 2
-            xyxy = torch.cat([boxn[..., :2] - half, boxn[..., :2] + half], -1)
-            diff = torch.cat([half, half], -1)
-            part = (rand_part + t['slot_neg'].unsqueeze(-1)) * (rand_sign * 2.0 - 1.0)
-            xyxy = (xyxy + part * diff * self.box_noise_scale).clamp(min=0.0, max=1.0)
-            kb = torch.cat([(xyxy[..., :2] + xyxy[..., 2:]) / 2, xyxy[..., 2:] - xyxy[..., :2]], -1)
-        valid = t['slot_valid'].unsqueeze(-1)
-        q_label = label_enc(kl.long()) * valid
-        q_bbox = torch.where(valid > 0, inverse_sigmoid(kb, eps=1e-3), torch.zeros_like(kb))
+            u = torch.cat([rnd['label_p'][k].unsqueeze(-1), rnd['new_label'][k].unsqueeze(-1).float(),
+                           rnd['rand_sign'][k].float(), rnd['rand_part'][k]], -1)
+            uniform = False
+        q_label, q_bbox = ops.cdn_queries(label_enc.weight, t['gt_lab'].reshape(-1), t['gt_boxn'].reshape(-1, 4),
+                                          t['slot_src'], t['slot_valid'], t['slot_neg'], u, uniform,
+                                          self.label_noise_scale, self.box_noise_scale, self.num_classes)
         return q_label, q_bbox, t['attn_mask'], dict(pad_size=PC, num_dn_group=st.ng)
 
 

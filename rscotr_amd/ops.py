@@ -437,6 +437,53 @@ def level_embed_add(x, weight, sizes, const=None, batch=None, row0=0):
     return _LevelEmbedAdd.apply(x, weight, const, tuple(sizes), batch, row0)
 
 
+class _CdnQueries(Function):
+    """The denoising queries of a det batch in slot layout, one launch (rscotr_cdn_queries); the only gradient is the
+    label embedding's (fixed-order scatter, straight into the arena when the parameter is sunk)."""
+
+    @staticmethod
+    def forward(ctx, weight, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, label_thr, box_scale, num_classes):
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        gt_lab, gt_boxn, slot_src = gt_lab.contiguous(), _f32c(gt_boxn), slot_src.contiguous()
+        slot_valid, slot_neg, u = _f32c(slot_valid), _f32c(slot_neg), _f32c(u)
+        _chk(w, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u)
+        assert gt_lab.dtype == torch.int64 and slot_src.dtype == torch.int64 and u.shape == slot_src.shape + (10,)
+        n, C = slot_src.numel(), w.shape[1]
+        kl = torch.empty(slot_src.shape, dtype=torch.int64, device=w.device)
+        q_label = torch.empty(slot_src.shape + (C,), dtype=torch.float32, device=w.device)
+        q_bbox = torch.empty(slot_src.shape + (4,), dtype=torch.float32, device=w.device)
+        lib.call('rscotr_cdn_queries', gt_lab.data_ptr(), gt_boxn.data_ptr(), slot_src.data_ptr(), slot_valid.data_ptr(),
+                 slot_neg.data_ptr(), u.data_ptr(), int(uniform), w.data_ptr(), float(label_thr), float(box_scale),
+                 int(num_classes), kl.data_ptr(), q_label.data_ptr(), q_bbox.data_ptr(), n, C, _stream())
+        ctx.save_for_backward(kl, slot_valid)
+        ctx.weight = weight
+        ctx.mark_non_differentiable(q_bbox)
+        return q_label, q_bbox
+
+    @staticmethod
+    def backward(ctx, g_label, g_bbox):
+        kl, slot_valid = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 11
+        g = _f32c(g_label)
+        rows, C = ctx.weight.shape
+        sk = _sink(ctx.weight)
+        dw = sk[1] if sk is not None else torch.empty((rows, C), dtype=torch.float32, device=g.device)
+        lib.call('rscotr_cdn_embed_grad', g.data_ptr(), kl.data_ptr(), slot_valid.data_ptr(), dw.data_ptr(), rows, kl.numel(), C,
+                 int(sk is not None), _stream())
+        if sk is not None:
+            GRAD_SINK.grad_written(sk[0])
+            return (None,) * 11
+        return (dw,) + (None,) * 10
+
+
+def cdn_queries(weight, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, label_noise_scale, box_noise_scale,
+                num_classes):
+    """-> (q_label (B,PC,C), q_bbox (B,PC,4)): see include/rscotr.h, rscotr_cdn_queries.  u (B,PC,10)."""
+    return _CdnQueries.apply(weight, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, bool(uniform),
+                             label_noise_scale * 0.5 if label_noise_scale > 0 else 0.0, max(box_noise_scale, 0.0), num_classes)
+
+
 def msda_prep(off, logit, reference_points, offset_norm, L, P):
     """off (B,Nq,H*L*P*2) raw sampling offsets, logit (B,Nq,H,L*P) raw attention logits, reference_points
     (B,Nq,L,2|4) (no gradient), offset_norm (L,2) = (W_l,H_l) -> (loc (B,Nq,H,L,P,2), attn (B,Nq,H,L,P))."""
@@ -1034,7 +1081,7 @@ class _GroupNormTokens(Function):
         lib.call('rscotr_groupnorm_tokens_fwd', x.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats.data_ptr(),
                  B, L, C, groups, float(eps), _WS.get(nws, x.device).data_ptr(), nws, _stream())
         ctx.save_for_backward(x, w, stats)
-        ctx.groups, ctx.has_b = groups, b is not None
+        ctx.groups, ctx.has_b, ctx.bias = groups, b is not None, b
         return y
 
     @staticmethod
@@ -1043,12 +1090,23 @@ class _GroupNormTokens(Function):
         B, L, C = x.shape
         dy = _f32c(dy)
         dx = torch.empty_like(x)
-        dwb = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        # dgamma / dbeta are ADDED by the kernel: straight into the gradient arena when both parameters are sunk (no
+        # zero-filled staging rows, no accumulate launches by autograd)
+        skw, skb = _sink(w), _sink(ctx.bias)
+        direct = w is not None and skw is not None and (skb is not None or not ctx.has_b)
+        dwb = None if direct else torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        dw_ptr = skw[1].data_ptr() if direct else dwb[0].data_ptr()
+        db_ptr = (skb[1].data_ptr() if ctx.has_b else 0) if direct else dwb[1].data_ptr()
         proj = torch.empty((B, ctx.groups, 2), dtype=torch.float32, device=x.device)
         nws = lib.rscotr_groupnorm_tokens_workspace(B, L, C, ctx.groups)
         lib.call('rscotr_groupnorm_tokens_bwd', dy.data_ptr(), x.data_ptr(), _ptr(w), stats.data_ptr(), dx.data_ptr(),
-                 dwb[0].data_ptr(), dwb[1].data_ptr(), proj.data_ptr(), B, L, C, ctx.groups,
+                 dw_ptr, db_ptr, proj.data_ptr(), B, L, C, ctx.groups,
                  _WS.get(nws, x.device).data_ptr(), nws, _stream())
+        if direct:
+            GRAD_SINK.grad_written(skw[0])
+            if ctx.has_b:
+                GRAD_SINK.grad_written(skb[0])
+            return dx, None, None, None, None
         return dx, dwb[0] if w is not None else None, dwb[1] if ctx.has_b else None, None, None
 
 

@@ -69,3 +69,39 @@ def test_pack4(cuda):
     lib.call('rscotr_pack4', parts[0].data_ptr(), 1000, parts[1].data_ptr(), 7, 0, 0, parts[3].data_ptr(), 333, out.data_ptr(),
              ops._stream())
     assert torch.equal(out, torch.cat(parts))
+
+
+@pytest.mark.parametrize('uniform', [True, False])
+def test_cdn_queries_kernel(cuda, uniform):
+    """ops.cdn_queries (one launch) against the op-by-op PyTorch form of the same slot arithmetic
+    (query_denoising.py:104-178) on the same random numbers; embedding gradient against autograd's, twice (bitwise)."""
+    from rscotr_amd import ops
+    from util import cdn_queries_ref
+    B, PC, G, C, NC = 2, 200, 32, 256, 20
+    g = torch.Generator(device='cpu').manual_seed(11)
+    w = torch.randn(NC, C, generator=g).to(cuda).requires_grad_(True)
+    gt_lab = torch.randint(0, NC, (B * G,), generator=g).to(cuda)
+    cxcy = torch.rand(B * G, 2, generator=g) * 0.8 + 0.1
+    wh = torch.rand(B * G, 2, generator=g) * 0.3 + 0.01
+    gt_boxn = torch.cat([cxcy, wh], -1).to(cuda)
+    slot_src = torch.randint(0, B * G, (B, PC), generator=g).to(cuda)
+    slot_valid = (torch.rand(B, PC, generator=g) < 0.7).float().to(cuda)
+    slot_neg = (torch.arange(PC) // 8 % 2).float()[None].expand(B, PC).contiguous().to(cuda)
+    u = torch.rand(B, PC, 10, generator=g)
+    if not uniform:
+        u[..., 1] = torch.randint(0, NC, (B, PC), generator=g).float()
+        u[..., 2:6] = torch.randint(0, 2, (B, PC, 4), generator=g).float()
+    u = u.to(cuda)
+    ql, qb = ops.cdn_queries(w, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, 0.5, 0.4, NC)
+    wr = w.detach().clone().requires_grad_(True)
+    rl, rb = cdn_queries_ref(wr, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, 0.5, 0.4, NC)
+    assert torch.equal(ql, rl)
+    assert float((qb - rb).abs().max()) <= 2e-6 * max(1.0, float(rb.abs().max()))
+    go = torch.randn(B, PC, C, generator=g).to(cuda)
+    ql.backward(go)
+    rl.backward(go)
+    assert float((w.grad - wr.grad).abs().max()) <= 1e-5 * float(wr.grad.abs().max())
+    first = w.grad.clone()
+    w.grad = None
+    ops.cdn_queries(w, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, 0.5, 0.4, NC)[0].backward(go)
+    assert torch.equal(first, w.grad)
