@@ -46,6 +46,88 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(float* __restrict
   for (int j = lane; j < Lk; j += 64) s[j] *= inv;
 }
 
+// Rows of Lk = 4 * 64 * NV keys at most (Lk a multiple of 4) stay in registers as NV float4 per lane: one read and one write
+// per element with 16-byte accesses instead of three scalar passes (the det decoder's 800-key rows: 22 -> ~10 us per call).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_mask_fwd_vec_kernel(float* __restrict__ S, const unsigned char* __restrict__ mask,
+                                                                   int mode, long rows, int Lq, int Lk, int heads, float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, Lk4 = Lk >> 2;
+  float4* s4 = reinterpret_cast<float4*>(S + row * Lk);
+  const unsigned char* m = mask_row(mask, mode, row, Lq, Lk, heads);
+  float4 v[NV];
+  unsigned long long blk = 0ull;  // bit 4 i + k: element k of vector i is blocked (or past the row)
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < Lk4) {
+      v[i] = s4[c];
+      unsigned b4 = 0u;
+      if (m) {
+        const uchar4 mm = reinterpret_cast<const uchar4*>(m)[c];
+        b4 = (mm.x ? 1u : 0u) | (mm.y ? 2u : 0u) | (mm.z ? 4u : 0u) | (mm.w ? 8u : 0u);
+      }
+      v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
+      if (!(b4 & 1u)) mx = fmaxf(mx, v[i].x);
+      if (!(b4 & 2u)) mx = fmaxf(mx, v[i].y);
+      if (!(b4 & 4u)) mx = fmaxf(mx, v[i].z);
+      if (!(b4 & 8u)) mx = fmaxf(mx, v[i].w);
+      blk |= (unsigned long long)b4 << (4 * i);
+    } else {
+      blk |= 15ull << (4 * i);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned b4 = (unsigned)(blk >> (4 * i)) & 15u;
+    v[i].x = (b4 & 1u) ? 0.f : expf(v[i].x - mx);
+    v[i].y = (b4 & 2u) ? 0.f : expf(v[i].y - mx);
+    v[i].z = (b4 & 4u) ? 0.f : expf(v[i].z - mx);
+    v[i].w = (b4 & 8u) ? 0.f : expf(v[i].w - mx);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < Lk4) s4[c] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
+                                                              int Lk, float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, Lk4 = Lk >> 2;
+  const float4* p4 = reinterpret_cast<const float4*>(P + row * Lk);
+  float4* d4 = reinterpret_cast<float4*>(dP + row * Lk);
+  float4 p[NV], d[NV];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < Lk4) {
+      p[i] = p4[c];
+      d[i] = d4[c];
+      dot += (p[i].x * d[i].x + p[i].y * d[i].y) + (p[i].z * d[i].z + p[i].w * d[i].w);
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < Lk4)
+      d4[c] = make_float4(scale * p[i].x * (d[i].x - dot), scale * p[i].y * (d[i].y - dot), scale * p[i].z * (d[i].z - dot),
+                          scale * p[i].w * (d[i].w - dot));
+  }
+}
+
 // dP <- scale * P * (dP - sum_k P_k dP_k)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
                                                           int Lk, float scale) {
@@ -223,7 +305,14 @@ extern "C" int rscotr_softmax_mask_fwd(float* S, const unsigned char* mask, int 
   const long rows = (long)B * heads * Lq;
   if (rows == 0) return RSCOTR_OK;
   if (!S) return fail(RSCOTR_E_ARG, "rscotr_softmax_mask_fwd: null pointer");
-  softmax_mask_fwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (Lk & 3) == 0 && Lk <= 4096 && aligned16(S) && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3u) == 0);
+  if (vec && Lk <= 256) softmax_mask_fwd_vec_kernel<1><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
+  else if (vec && Lk <= 1024) softmax_mask_fwd_vec_kernel<4><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
+  else if (vec && Lk <= 2048) softmax_mask_fwd_vec_kernel<8><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
+  else if (vec) softmax_mask_fwd_vec_kernel<16><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
+  else softmax_mask_fwd_kernel<<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
   return check_launch("rscotr_softmax_mask_fwd");
 }
 
@@ -231,6 +320,13 @@ extern "C" int rscotr_softmax_bwd(const float* P, float* dP, int64_t rows, int L
   if (rows < 0 || Lk <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_softmax_bwd: bad shape");
   if (rows == 0) return RSCOTR_OK;
   if (!P || !dP) return fail(RSCOTR_E_ARG, "rscotr_softmax_bwd: null pointer");
-  softmax_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(P, dP, rows, Lk, scale);
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (Lk & 3) == 0 && Lk <= 4096 && aligned16(P) && aligned16(dP);
+  if (vec && Lk <= 256) softmax_bwd_vec_kernel<1><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
+  else if (vec && Lk <= 1024) softmax_bwd_vec_kernel<4><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
+  else if (vec && Lk <= 2048) softmax_bwd_vec_kernel<8><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
+  else if (vec) softmax_bwd_vec_kernel<16><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
+  else softmax_bwd_kernel<<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
   return check_launch("rscotr_softmax_bwd");
 }

@@ -14,7 +14,8 @@ def _rel(a, ref):
 
 
 @pytest.mark.parametrize('B,Lq,Lk,mask_kind', [(2, 100, 100, None), (2, 100, 256, 'image'), (2, 830, 830, 'shared'),
-                                               (2, 37, 1024, 'head'), (1, 5, 64, 'image'), (2, 100, 4096, 'image')])
+                                               (2, 37, 1024, 'head'), (1, 5, 64, 'image'), (2, 100, 4096, 'image'),
+                                               (2, 800, 800, 'shared'), (1, 16, 2048, 'image')])
 def test_mha_matches_torch(cuda, B, Lq, Lk, mask_kind):
     from rscotr_amd import ops
     C, H = 256, 8
