@@ -2645,6 +2645,7 @@ extern "C" int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, i
   return check_launch("rscotr_splitk_flush");
 }
 
+namespace rscotr {
 // out[i] = sum_s slabs[s][i] (float4 lanes; n % 4 == 0)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float4* __restrict__ slabs, float4* __restrict__ out, long n4,
                                                        int splits) {
@@ -2657,6 +2658,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float4* __restrict_
     out[i] = a;
   }
 }
+}  // namespace rscotr
 
 // Batched form: nb0 * nb1 independent problems of one shape, problem (b0, b1) at element offsets
 // b0*s?0 + b1*s?1 of A, B, C (e.g. b0 = image, b1 = head: the per-head slices of (B, L, heads*32) tensors are
