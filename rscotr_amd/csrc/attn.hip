@@ -10,6 +10,7 @@
 // Mapping: one wavefront per row (rows are 64 ... 4096 keys: at most 16 KB, they stay in L1/L2 across the
 // passes), four rows per workgroup; max / sum by wave butterflies.
 #include "common.h"
+#include <stdlib.h>
 
 namespace rscotr {
 
@@ -307,7 +308,8 @@ extern "C" int rscotr_softmax_mask_fwd(float* S, const unsigned char* mask, int 
   if (!S) return fail(RSCOTR_E_ARG, "rscotr_softmax_mask_fwd: null pointer");
   const unsigned grid = (unsigned)((rows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = (Lk & 3) == 0 && Lk <= 4096 && aligned16(S) && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3u) == 0);
+  static const int vec_on = getenv("RSCOTR_SOFTMAX_VEC") ? atoi(getenv("RSCOTR_SOFTMAX_VEC")) : 3;  // (A/B switch: bit 0 forward, bit 1 backward, bits 4.. = smallest row length)
+  const bool vec = (vec_on & 1) && (Lk & 3) == 0 && Lk <= 4096 && Lk >= ((vec_on >> 4) & 0xffff) && aligned16(S) && (!mask || (reinterpret_cast<uintptr_t>(mask) & 3u) == 0);
   if (vec && Lk <= 256) softmax_mask_fwd_vec_kernel<1><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
   else if (vec && Lk <= 1024) softmax_mask_fwd_vec_kernel<4><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
   else if (vec && Lk <= 2048) softmax_mask_fwd_vec_kernel<8><<<grid, 256, 0, st>>>(S, mask, mask_mode, rows, Lq, Lk, heads, scale);
@@ -322,7 +324,8 @@ extern "C" int rscotr_softmax_bwd(const float* P, float* dP, int64_t rows, int L
   if (!P || !dP) return fail(RSCOTR_E_ARG, "rscotr_softmax_bwd: null pointer");
   const unsigned grid = (unsigned)((rows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = (Lk & 3) == 0 && Lk <= 4096 && aligned16(P) && aligned16(dP);
+  static const int vec_on = getenv("RSCOTR_SOFTMAX_VEC") ? atoi(getenv("RSCOTR_SOFTMAX_VEC")) : 3;
+  const bool vec = (vec_on & 2) && (Lk & 3) == 0 && Lk <= 4096 && Lk >= ((vec_on >> 4) & 0xffff) && aligned16(P) && aligned16(dP);
   if (vec && Lk <= 256) softmax_bwd_vec_kernel<1><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
   else if (vec && Lk <= 1024) softmax_bwd_vec_kernel<4><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);
   else if (vec && Lk <= 2048) softmax_bwd_vec_kernel<8><<<grid, 256, 0, st>>>(P, dP, rows, Lk, scale);

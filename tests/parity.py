@@ -79,10 +79,18 @@ def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2
         rnd_cpu = dict(rnd_cpu or {}, det_topk_idx=rec['topk_idx'].cpu())
     oout = OM.train_step(P, model_cfg, batch_cpu, rnd_cpu, orec)
     oout['loss'].backward()
-    if fp64:
+    def fp64_anchor():
         orec['P64'], orec['out64'] = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec)
         # the same step with every ReLU gate within RELU_BAND of zero flipped: how far coin-toss gates can move a gradient
         orec['P64b'], _ = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec, relu_band=RELU_BAND)
+
+    if fp64:
+        fp64_anchor()
+    else:
+        # (evaluated by check_step_pair only when the fp32 tiers fail: the fp32 ORACLE can itself sit on the other side of a
+        # coin-toss ReLU gate — measured at Swin-B 1024^2 seg: product within 5e-6 of fp64 on every tensor, fp32 oracle
+        # 7-14 % away on 559 of 615, the flipped-band evaluation moving by the same 7-14 %; scripts/seg_swinb_anchor.py)
+        orec['_fp64_anchor'] = fp64_anchor
     return out, oout, rec, orec, P
 
 
@@ -182,9 +190,15 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
     loose = [r for r in rows if r[1] > 1.0 and r[3] > RTOL]
     out['grad_report'] = dict(tensors=len(rows), over_tight=len(loose),
                               worst=sorted(loose, key=lambda r: -r[1])[:8])
-    assert len(rows) - len(loose) >= TIGHT_FRACTION * len(rows), out['grad_report']
     bad = [r for r in loose if r[3] > LOOSE_L2 or (loose_max is not None and r[1] > loose_max)]
-    assert not bad, bad[:5]
+    fp32_tiers_ok = len(rows) - len(loose) >= TIGHT_FRACTION * len(rows) and not bad
+    if not fp32_tiers_ok:
+        # product and fp32 oracle disagree beyond the two tiers: decided by the fp64 anchor below (which of the two fp32
+        # evaluations is away from the fp64 one under the same decisions, and can a coin-toss ReLU gate explain it?)
+        if 'P64' not in orec and '_fp64_anchor' in orec:
+            orec['_fp64_anchor']()
+        assert 'P64' in orec, (out['grad_report'], bad[:5])
+        out['grad_report']['decided_by_fp64_anchor'] = True
     if 'P64' in orec:
         rep = anchor_report(model, P, orec['P64'], orec.get('P64b'))
         ratio = sorted(((r['ep'] / max(r['eo'], r['amb'], ANCHOR_FLOOR), r['name']) for r in rep), reverse=True)
