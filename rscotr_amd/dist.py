@@ -22,6 +22,13 @@ import torch
 import torch.distributed as dist
 
 
+# RSCOTR_DIST_INLINE=1 (default): bucket all-reduces on the compute stream; =0: on RCCL's own stream, overlapping the rest of
+# backward.  On this runtime a captured iteration with a forked RCCL branch is replayed across several hardware queues and the
+# hand-overs cost more than the exchange they hide (one-rank group, per round: plain 40.6 ms, inline 41.7, overlapped 44.8;
+# DESIGN.md section 6)
+INLINE = os.environ.get('RSCOTR_DIST_INLINE', '1') == '1'
+
+
 def is_dist():
     """True when gradients have to be exchanged.  RSCOTR_DIST_SINGLE=1 takes the distributed code path with a
     one-rank group (exercises bucket plans, RCCL calls and the split graph/optimizer flow on a 1-GPU box)."""
@@ -109,7 +116,11 @@ class GradSync:
         if not is_dist():
             return
         view = self.opt.flat_g[b['lo']:b['hi']]
-        if dist.get_backend() == 'nccl':  # RCCL: mean in the collective
+        if dist.get_backend() == 'nccl' and INLINE:
+            # the collective on the COMPUTE stream, in launch order (c10d runs a synchronous collective on the current
+            # stream): no fork, so a captured iteration stays ONE chain on one hardware queue
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=False)
+        elif dist.get_backend() == 'nccl':  # RCCL: mean in the collective
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True))
         else:  # gloo (CPU tests) has no AVG
             view.div_(dist.get_world_size())

@@ -161,13 +161,23 @@ class GraphedTask:
                 ops.side_join()
                 ops.side_enable(False)
         ops.flush_deferred()  # one combine launch for every split-K weight gradient of this backward pass
+        log_work = None
         if sync is not None:
             sync.finish_step(self.task)  # leftover buckets in the fixed order, then the waits (event edges in the graph)
             import torch.distributed as dist
+            # rank-averaged log variables (multitask_learner.py:299-304): same place in the collective sequence as on every
+            # other path (after the buckets), but nothing on the compute queue depends on it — clip + AdamW are queued
+            # first and the wait comes last, so the queue hand-over to RCCL and back is off the critical path
             self.packed = self.packed / dist.get_world_size()
-            dist.all_reduce(self.packed)  # rank-averaged log variables (multitask_learner.py:299-304)
+            from .dist import INLINE
+            if INLINE:
+                dist.all_reduce(self.packed)  # (on the compute stream: the captured iteration stays one chain)
+            else:
+                log_work = dist.all_reduce(self.packed, async_op=True)
         if not self.split:
             self.opt.launch_step(self.table)
+        if log_work is not None:
+            log_work.wait()
 
     def _finish(self):
         if self.split:
@@ -217,7 +227,10 @@ class IterBasedRunner:
             self.lr_updater = StepLrUpdater(**{k: v for k, v in lr_config.items() if k != 'policy'})
         self.log_interval, self.logger = log_interval, logger
         if bucket_mb is None:  # gradient exchange granularity (MB of fp32 gradients per all-reduce)
-            bucket_mb = float(os.environ.get('RSCOTR_BUCKET_MB', 32.0))
+            from .dist import INLINE
+            # inline exchange: few large collectives (nothing overlaps them anyway, and a flush of the deferred work
+            # precedes every bucket); overlapped exchange: 32 MB so that the first buckets leave early in backward
+            bucket_mb = float(os.environ.get('RSCOTR_BUCKET_MB', 128.0 if INLINE else 32.0))
         self.sync = GradSync(optimizer, bucket_mb) if is_dist() else None
         self.rnd_fn = rnd_fn
         # tasks whose iteration is replayed from a hipGraph (RSCOTR_GRAPHS=0 disables)

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for m in 0 1; do
   rm -rf /tmp/prof_d$m
-  RSCOTR_DIST_SINGLE=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d$m -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /tmp/prof_d$m.log 2>&1
+  RSCOTR_DIST_SINGLE=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d$m -o p -- python $R/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-roofline > /tmp/prof_d$m.log 2>&1
   f=$(find /tmp/prof_d$m -name '*kernel_stats.csv' | head -1)
   cp "$f" $R/gpurun_out/r2_dist_prof_$m.csv
   echo "== DIST_SINGLE=$m"; grep -o '"ms_per_step": [0-9.]*' /tmp/prof_d$m.log
