@@ -207,7 +207,7 @@ class DetStatic:
     KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
             'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales')
 
-    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None):
+    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None):
         gen = head.dn_generator
         B = len(gt_bboxes)
         Q = head.num_query
@@ -228,16 +228,7 @@ class DetStatic:
         G, PC = self.gcap, self.padcap
         shapes = [tuple(m['img_shape'][:2]) for m in img_metas]
         self.img_shapes = shapes
-        # ground truth, padded with a harmless dummy box
-        gt_box = torch.zeros((B, G, 4), device=device)
-        gt_box[:, :, 2:] = 1.0
-        gt_lab = torch.zeros((B, G), dtype=torch.long, device=device)
-        for b in range(B):
-            if counts[b]:
-                gt_box[b, :counts[b]] = gt_bboxes[b]
-                gt_lab[b, :counts[b]] = gt_labels[b]
-        factors = torch.tensor([[w, h, w, h] for (h, w) in shapes], dtype=torch.float32)
-        self.t = dict(gt_box=gt_box, gt_lab=gt_lab)
+        factors_np = np.asarray([[w, h, w, h] for (h, w) in shapes], dtype=np.float32)
         # host-built layout
         goff = np.concatenate([[0], np.cumsum(counts)])[:-1]
         nb = int(sum(counts))
@@ -270,30 +261,63 @@ class DetStatic:
         npos_dn = ng * nb
         bgw = head.bg_cls_weight
         norms = np.array([num_pos * 1.0 + num_neg * bgw, num_pos, npos_dn * 1.0 + npos_dn * bgw, npos_dn], dtype=np.float32)
-        host = dict(gcount=np.asarray(counts, dtype=np.int32), factors=factors.numpy(), slot_src=slot_src,
+        host = dict(gcount=np.asarray(counts, dtype=np.int32), factors=factors_np, slot_src=slot_src,
                     slot_valid=slot_valid, slot_neg=slot_neg, slot_inpad=slot_inpad, slot_pos=slot_pos, slot_k=slot_k,
                     attn_mask=am, norms=norms)
-        for k, v in host.items():
-            self.t[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device, non_blocking=True)
-        f = self.t['factors']
-        self.t['gt_boxn'] = ops.bbox_xyxy_to_cxcywh(gt_box / f[:, None, :])
-        # every reduce_mean of the reference's det losses (detr_head.py:379-381,389-390; dino_head.py:266-268,
-        # 282-283) averages one of these four numbers over the ranks: one small all-reduce, here, outside
-        # any captured region
-        self.t['norms_r'] = ops.dist_mean_tensor(self.t['norms']).clone()
         # loss_weight / (max(normaliser, 1) + eps) of the three losses, for the matching part (row 0) and the denoising
         # part (row 1) (detr_head.py:379-396): six numbers known with the counts — on one rank they are computed on the
         # host with the fp32 operations torch would run (clamp, add, reciprocal, multiply) and ride the upload
         w3 = (head.loss_cls.loss_weight, head.loss_bbox.loss_weight, head.loss_iou.loss_weight)
-        if ops.dist_world() == 1:
+        one_rank = ops.dist_world() == 1
+        if one_rank:
             f32 = np.float32
             rows = []
             for ci, pi in ((0, 1), (2, 3)):
                 rc = f32(1.0) / (np.maximum(norms[ci], f32(1.0)) + f32(FP32_EPS))
                 rp = f32(1.0) / (np.maximum(norms[pi], f32(1.0)) + f32(FP32_EPS))
                 rows.append([rc * f32(w3[0]), rp * f32(w3[1]), rp * f32(w3[2])])
-            self.t['scales'] = torch.from_numpy(np.asarray(rows, dtype=np.float32)).to(device, non_blocking=True)
+            host['scales'] = np.asarray(rows, dtype=np.float32)
+            host['norms_r'] = norms.copy()  # (every reduce_mean of the det losses is the identity on one rank)
+        # ground truth, padded with a harmless dummy box.  When the loader left host copies on the gt tensors (`.host`:
+        # rscotr_amd.synth / rscotr_amd.pipeline build them on the host anyway) the padded tensors are laid out on the host
+        # too and EVERYTHING of this batch is one pinned block -> one upload (and one copy into a captured iteration's static
+        # block) instead of ~45 small launches per det iteration
+        hb = [getattr(x, 'host', None) for x in gt_bboxes]
+        hl = [getattr(x, 'host', None) for x in gt_labels]
+        self.blob = self.host_blob = None
+        if all(x is not None for x in hb + hl):
+            gt_box = np.zeros((B, G, 4), dtype=np.float32)
+            gt_box[:, :, 2:] = 1.0
+            gt_lab = np.zeros((B, G), dtype=np.int64)
+            for b in range(B):
+                if counts[b]:
+                    gt_box[b, :counts[b]] = np.asarray(hb[b], dtype=np.float32).reshape(-1, 4)
+                    gt_lab[b, :counts[b]] = np.asarray(hl[b], dtype=np.int64).reshape(-1)
+            q = gt_box / factors_np[:, None, :]  # bbox_xyxy_to_cxcywh(gt_box / factors) in fp32, as ops does it
+            x1, y1, x2, y2 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+            host.update(gt_box=gt_box, gt_lab=gt_lab,
+                        gt_boxn=np.stack([(x1 + x2) / np.float32(2), (y1 + y2) / np.float32(2), x2 - x1, y2 - y1], -1))
+            self._pack(host, device, pinned)
         else:
+            gt_box = torch.zeros((B, G, 4), device=device)
+            gt_box[:, :, 2:] = 1.0
+            gt_lab = torch.zeros((B, G), dtype=torch.long, device=device)
+            for b in range(B):
+                if counts[b]:
+                    gt_box[b, :counts[b]] = gt_bboxes[b]
+                    gt_lab[b, :counts[b]] = gt_labels[b]
+            self.t = dict(gt_box=gt_box, gt_lab=gt_lab)
+            for k, v in host.items():
+                self.t[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device, non_blocking=True)
+            f = self.t['factors']
+            self.t['gt_boxn'] = ops.bbox_xyxy_to_cxcywh(gt_box / f[:, None, :])
+        if not one_rank:
+            # every reduce_mean of the reference's det losses (detr_head.py:379-381,389-390; dino_head.py:266-268,
+            # 282-283) averages one of these four numbers over the ranks: one small all-reduce, here, outside
+            # any captured region
+            if 'norms' not in self.t:  # (staging-only block: the rank-local normalisers go up on their own)
+                self.t['norms'] = torch.from_numpy(norms).to(device, non_blocking=True)
+            self.t['norms_r'] = ops.dist_mean_tensor(self.t['norms']).clone()
             nr, nn_ = self.t['norms_r'], self.t['norms']
             rows = []
             for ci, pi in ((0, 1), (2, 3)):
@@ -303,14 +327,54 @@ class DetStatic:
                 rows.append(torch.stack([rc * w3[0], rp * w3[1], rp * w3[2]]))
             self.t['scales'] = torch.stack(rows)
 
+    def _pack(self, host, device, pinned=None):
+        """All host arrays of the batch in ONE byte block (16-byte aligned fields, KEYS order): `self.t` = typed views of
+        the device block.  `pinned`: a pinned staging buffer to fill instead of uploading (GraphedTask.run: the block is
+        then copied into the captured iteration's static block by update_into)."""
+        fields, off = [], 0
+        for k in self.KEYS:
+            if k in host:
+                a = np.ascontiguousarray(host[k])
+                fields.append((k, off, a))
+                off += (a.nbytes + 15) // 16 * 16
+        self.layout = tuple((k, o, a.dtype.str, a.shape) for k, o, a in fields)
+        if pinned is not None and pinned.numel() >= off:
+            stage = pinned[:off]
+        else:
+            stage = torch.empty(max(off, 16), dtype=torch.uint8)
+            if device.type == 'cuda':
+                stage = stage.pin_memory()
+            stage = stage[:off]
+        buf = stage.numpy()
+        for k, o, a in fields:
+            buf[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+        self.host_blob = stage
+        if pinned is not None and pinned.numel() >= off:
+            self.t = {}  # (staging only: the tensors of the captured iteration are refreshed by update_into)
+            return
+        self.blob = stage.to(device, non_blocking=True)
+        self.t = {}
+        for k, o, a in fields:
+            td = torch.bool if a.dtype == np.bool_ else getattr(torch, a.dtype.name)
+            self.t[k] = self.blob[o:o + a.nbytes].view(td).view(a.shape)
+
     def key(self):
         return (self.gcap, self.padcap, tuple(self.img_shapes))
 
     def update_into(self, static):
-        """Copy this batch's tensors into the static tensors of a captured iteration (same capacities)."""
+        """Copy this batch's tensors into the static tensors of a captured iteration (same capacities): one copy of the
+        packed block when both sides are packed the same way."""
         assert static.key() == self.key()
-        for k in self.KEYS:
-            static.t[k].copy_(self.t[k], non_blocking=True)
+        if self.host_blob is not None and static.blob is not None and self.layout == static.layout:
+            static.blob.copy_(self.host_blob, non_blocking=True)
+            static.host_keep = self.host_blob  # (the pinned source stays alive until the next refresh)
+            packed = {f[0] for f in self.layout}
+            for k in self.KEYS:                # tensors outside the block (several ranks: rank-averaged normalisers)
+                if k in self.t and k not in packed:
+                    static.t[k].copy_(self.t[k], non_blocking=True)
+        else:
+            for k in self.KEYS:
+                static.t[k].copy_(self.t[k], non_blocking=True)
         for a in ('counts', 'max_gt', 'ng', 'single_pad', 'pad_size'):
             setattr(static, a, getattr(self, a))
 

@@ -121,11 +121,13 @@ class DeviceCollate:
         elif self.task == 'det':
             boxes, labels = [], []
             for s, w, f in zip(samples, wins, flips):
-                bb = torch.as_tensor(np.asarray(s['gt_bboxes'], dtype=np.float32)).reshape(-1, 4).to(self.device)
-                if f:  # mmdet RandomFlip.bbox_flip, horizontal
-                    bb = torch.stack([w[2] - bb[:, 2], bb[:, 1], w[2] - bb[:, 0], bb[:, 3]], -1)
-                boxes.append(bb)
-                labels.append(torch.as_tensor(np.asarray(s['gt_labels'], dtype=np.int64)).to(self.device))
+                hb = np.asarray(s['gt_bboxes'], dtype=np.float32).reshape(-1, 4)
+                if f:  # mmdet RandomFlip.bbox_flip, horizontal (on the host: the boxes are a few dozen floats)
+                    hb = np.stack([np.float32(w[2]) - hb[:, 2], hb[:, 1], np.float32(w[2]) - hb[:, 0], hb[:, 3]], -1)
+                hl = np.asarray(s['gt_labels'], dtype=np.int64).reshape(-1)
+                boxes.append(torch.from_numpy(np.ascontiguousarray(hb)).to(self.device))
+                labels.append(torch.from_numpy(np.ascontiguousarray(hl)).to(self.device))
+                boxes[-1].host, labels[-1].host = hb, hl  # (host copies for the det head's packed batch layout)
             batch['gt_bboxes'], batch['gt_labels'] = boxes, labels
         else:
             lbuf, loffs = self._stage_bytes(segs)

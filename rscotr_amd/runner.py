@@ -51,6 +51,11 @@ class GraphedTask:
                 gcap = _round_up(max(int(need.item()), 32), 32)
             self.det_static = DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
                                         batch['img'].device, gcap=gcap)
+            # pinned staging block of the later batches (DetStatic packs a batch into one block when the loader left host
+            # copies of the ground truth: one upload per det iteration)
+            self.det_pinned = None
+            if self.det_static.host_blob is not None:
+                self.det_pinned = torch.empty(self.det_static.host_blob.numel(), dtype=torch.uint8).pin_memory()
         if task == 'cls':
             sp = self.model.cls_augments.static_params(self._draw(), batch['img'].shape[0])
             self.aug = {k: v.to(batch['img'].device) for k, v in sp.items()}
@@ -200,8 +205,8 @@ class GraphedTask:
         if self.det_static is not None:
             from .det_head import DetStatic
             DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
-                      batch['img'].device, gcap=self.det_static.gcap, padcap=self.det_static.padcap) \
-                .update_into(self.det_static)
+                      batch['img'].device, gcap=self.det_static.gcap, padcap=self.det_static.padcap,
+                      pinned=self.det_pinned).update_into(self.det_static)
         for k, t in self.static.items():
             t.copy_(batch[k], non_blocking=True)
         if self.aug is not None:

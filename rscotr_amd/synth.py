@@ -25,8 +25,11 @@ def make_batch(task, batch_size=2, size=512, seed=0, device='cpu', num_cls=45, n
             cxy = rs.uniform(0.1, 0.9, (G, 2)) * size
             wh = rs.uniform(16, min(200, size / 2), (G, 2))
             b = np.concatenate([cxy - wh / 2, cxy + wh / 2], 1).clip(0, size).astype(np.float32)
+            lab = rs.randint(0, num_det, G).astype(np.int64)
             boxes.append(torch.from_numpy(b).to(device))
-            labels.append(torch.from_numpy(rs.randint(0, num_det, G)).long().to(device))
+            labels.append(torch.from_numpy(lab).to(device))
+            # host copies ride on the tensors (the det head lays a batch out on the host when it finds them: DetStatic)
+            boxes[-1].host, labels[-1].host = b, lab
         batch['gt_bboxes'], batch['gt_labels'] = boxes, labels
     elif task == 'seg':
         blk = 32 if size >= 64 else 8
