@@ -149,6 +149,14 @@ class GradSync:
         if plan is None:
             self.fired, self._bucket_of = {}, None
             self.vfired, self._vpending = {}, None
+        elif INLINE and dist.is_initialized() and dist.get_backend() == 'nccl':
+            # inline exchange: nothing overlaps the collectives, so nothing is gained by launching a bucket early — and the
+            # bucket-aligned flushes would cut the grouped weight-gradient launch into pieces.  No hooks are armed: backward
+            # runs as on one GPU, finish_step() sends the buckets in the fixed order after the one flush of the deferred work
+            self.fired = self.vfired = None
+            self._bucket_of = self._vpending = None
+            self._order, self._next = list(reversed(plan)), 0
+            self._at_end = True
         else:
             vf = self.vfires.get(task, {})
             self.vfired = None
@@ -172,6 +180,11 @@ class GradSync:
             self._check_plan(task)
             for b in reversed(self.plans[task]):
                 self._launch(b)
+        elif getattr(self, '_at_end', False):
+            self._at_end = False
+            while self._next < len(self._order):
+                self._launch(self._order[self._next])
+                self._next += 1
         elif self._bucket_of is not None:
             # backward is over: whatever has not been launched (a parameter fired fewer times than in the discovery
             # step, so its bucket never counted down to zero) goes out now, in the same fixed order on every rank —
