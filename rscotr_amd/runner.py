@@ -18,6 +18,9 @@ from . import ops
 from .optim import StepLrUpdater, build_optimizer
 
 
+_HOST_TIMES = os.environ.get('RSCOTR_HOST_TIMES') == '1'
+
+
 class GraphedTask:
     """One task's whole iteration — forward, loss, zero_grad, backward, clip, AdamW — captured once
     into a hipGraph and replayed (the step is launch-bound: ~2-3k kernel launches per iteration).
@@ -215,7 +218,11 @@ class GraphedTask:
                 self.aug_host[k].copy_(sp[k])  # pinned staging: the upload below must not stall the host
                 t.copy_(self.aug_host[k], non_blocking=True)
         self.opt.prepare_step(self.table)
+        if _HOST_TIMES:
+            t0 = time.perf_counter()
         self.graph.replay()
+        if _HOST_TIMES:  # (diagnostic: host time of the graph launch alone)
+            print(f'[runner] {self.task}: graph launch {1e3 * (time.perf_counter() - t0):.2f} ms on the host', flush=True)
         self._finish()
         self.done = torch.cuda.Event()
         self.done.record()
