@@ -317,6 +317,15 @@ int rscotr_cdn_queries(const int64_t* gt_lab, const float* gt_boxn, const int64_
                        void* stream);
 int rscotr_cdn_embed_grad(const float* g, const int64_t* kl, const float* slot_valid, float* dw, int rows, int n_slots,
                           int C, int accumulate, void* stream);
+/* Classification head (models/multi/cls_head/slvl_cls_head.py:14-23; mmcls GlobalAveragePooling + LabelSmoothLoss 'original'):
+ * rscotr_gap_tokens_fwd: out (B, C) = mean over the T tokens of x (B, T, C); _bwd: dx (B, T, C) = g (B, C) / T, dense.
+ * rscotr_soft_ce: loss (1) = sum over rows and classes of -t * log_softmax(score) / avg_factor with
+ * t = label * (1 - smooth) + smooth / C (label (B, C): one-hot or mixed soft labels), and dscore (B, C) = d loss / d score
+ * in the same launch.  B <= 1024. */
+int rscotr_gap_tokens_fwd(const float* x, float* out, int B, int T, int C, void* stream);
+int rscotr_gap_tokens_bwd(const float* g, float* dx, int B, int T, int C, void* stream);
+int rscotr_soft_ce(const float* score, const float* label, float* loss, float* dscore, int B, int C, float smooth,
+                   float avg_factor, void* stream);
 /* out = [a | b | c | d]: flat concatenation of up to four fp32 arrays in one launch (packs the rows and biases of Linear
  * layers that read the same operand, e.g. mmcv MultiScaleDeformableAttention's sampling_offsets and attention_weights,
  * so that they run as one product). */

@@ -171,6 +171,75 @@ __global__ __launch_bounds__(256) void cdn_embed_grad_kernel(const float* __rest
   }
 }
 
+// ---- classification head pieces (models/multi/cls_head/slvl_cls_head.py:14-23: GlobalAveragePooling + LabelSmoothLoss) --------
+// mean over the T tokens of a (B, T, C) map, one thread per (b, float4 of channels); sequential over tokens (fixed order)
+__global__ __launch_bounds__(256) void gap_tokens_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out, int B, int T,
+                                                             int C4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C4) return;
+  const int b = i / C4, c = i - b * C4;
+  const float4* p = x + (long)b * T * C4 + c;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  int t = 0;
+  for (; t + 2 <= T; t += 2) {
+    const float4 u = p[(long)t * C4], v = p[(long)(t + 1) * C4];
+    a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+    a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+  }
+  if (t < T) { const float4 u = p[(long)t * C4]; a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w; }
+  const float inv = 1.f / (float)T;
+  out[i] = make_float4((a0.x + a1.x) * inv, (a0.y + a1.y) * inv, (a0.z + a1.z) * inv, (a0.w + a1.w) * inv);
+}
+
+// dx[b, t, :] = g[b, :] / T (dense, so that the consumer reads it without a copy)
+__global__ __launch_bounds__(256) void gap_tokens_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int T,
+                                                             int C4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)T * C4;
+  if (i >= per * B) return;
+  const int b = (int)(i / per), c = (int)(i % C4);
+  const float inv = 1.f / (float)T;
+  const float4 v = g[(long)b * C4 + c];
+  dx[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
+// loss = sum_b sum_c -t[b,c] * log_softmax(score[b])[c] / avg_factor with t = label * (1 - smooth) + smooth / C
+// (mmcls LabelSmoothLoss 'original' + soft cross-entropy); dscore[b,c] = (softmax[b,c] * sum_c t[b,c] - t[b,c]) / avg_factor.
+// One workgroup (rows are a few, C a few dozen): one wavefront per row, rows folded in order.
+__global__ __launch_bounds__(256) void soft_ce_kernel(const float* __restrict__ score, const float* __restrict__ label,
+                                                      float* __restrict__ loss, float* __restrict__ dscore, int B, int C,
+                                                      float smooth, float inv_avg) {
+  __shared__ float rowloss[1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int b = w; b < B; b += 4) {
+    const float* s = score + (long)b * C;
+    const float* l = label + (long)b * C;
+    float mx = -3.0e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
+    mx = wave_max(mx);
+    float se = 0.f, st = 0.f, dot = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float t = l[c] * (1.f - smooth) + smooth / (float)C;
+      se += expf(s[c] - mx);
+      st += t;
+      dot += t * (s[c] - mx);
+    }
+    se = wave_sum(se); st = wave_sum(st); dot = wave_sum(dot);
+    const float lse = logf(se);
+    if (lane == 0 && b < 1024) rowloss[b] = (st * lse - dot) * inv_avg;  // -sum t (s - mx - lse)
+    for (int c = lane; c < C; c += 64) {
+      const float t = l[c] * (1.f - smooth) + smooth / (float)C;
+      dscore[(long)b * C + c] = (expf(s[c] - mx) / se * st - t) * inv_avg;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += rowloss[b];
+    *loss = a;
+  }
+}
+
 static int level_starts(const char* who, const int* sizes, int L, int N, LevelStarts* ls) {
   if (L < 1 || L > 8) return fail(RSCOTR_E_SHAPE, "%s: 1..8 levels supported, got %d", who, L);
   if (!sizes) return fail(RSCOTR_E_ARG, "%s: null sizes", who);
@@ -253,4 +322,34 @@ extern "C" int rscotr_cdn_embed_grad(const float* g, const int64_t* kl, const fl
   if (!g || !kl || !slot_valid || !dw) return fail(RSCOTR_E_ARG, "rscotr_cdn_embed_grad: null pointer");
   cdn_embed_grad_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(g, kl, slot_valid, dw, n_slots, C, accumulate);
   return check_launch("rscotr_cdn_embed_grad");
+}
+
+extern "C" int rscotr_gap_tokens_fwd(const float* x, float* out, int B, int T, int C, void* stream) {
+  if (B < 0 || T <= 0 || C <= 0 || (C & 3)) return fail(RSCOTR_E_SHAPE, "rscotr_gap_tokens_fwd: bad shape (C a multiple of 4)");
+  if (B == 0) return RSCOTR_OK;
+  if (!x || !out) return fail(RSCOTR_E_ARG, "rscotr_gap_tokens_fwd: null pointer");
+  if (!aligned16(x) || !aligned16(out)) return fail(RSCOTR_E_ALIGN, "rscotr_gap_tokens_fwd: 16-byte aligned tensors required");
+  gap_tokens_fwd_kernel<<<(unsigned)((B * (C / 4) + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), B, T, C / 4);
+  return check_launch("rscotr_gap_tokens_fwd");
+}
+
+extern "C" int rscotr_gap_tokens_bwd(const float* g, float* dx, int B, int T, int C, void* stream) {
+  if (B < 0 || T <= 0 || C <= 0 || (C & 3)) return fail(RSCOTR_E_SHAPE, "rscotr_gap_tokens_bwd: bad shape (C a multiple of 4)");
+  if (B == 0) return RSCOTR_OK;
+  if (!g || !dx) return fail(RSCOTR_E_ARG, "rscotr_gap_tokens_bwd: null pointer");
+  if (!aligned16(g) || !aligned16(dx)) return fail(RSCOTR_E_ALIGN, "rscotr_gap_tokens_bwd: 16-byte aligned tensors required");
+  const long total = (long)B * T * (C / 4);
+  gap_tokens_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(dx), B, T, C / 4);
+  return check_launch("rscotr_gap_tokens_bwd");
+}
+
+extern "C" int rscotr_soft_ce(const float* score, const float* label, float* loss, float* dscore, int B, int C, float smooth,
+                              float avg_factor, void* stream) {
+  if (B <= 0 || B > 1024 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_soft_ce: 1 <= B <= 1024 rows, C >= 1");
+  if (!(avg_factor > 0.f)) return fail(RSCOTR_E_ARG, "rscotr_soft_ce: avg_factor must be positive");
+  if (!score || !label || !loss || !dscore) return fail(RSCOTR_E_ARG, "rscotr_soft_ce: null pointer");
+  soft_ce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(score, label, loss, dscore, B, C, smooth, 1.f / avg_factor);
+  return check_launch("rscotr_soft_ce");
 }

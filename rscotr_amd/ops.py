@@ -1690,12 +1690,60 @@ def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=Non
 # ------------------------------------------------------------------------------------------
 # classification / detection / segmentation loss pieces
 # ------------------------------------------------------------------------------------------
+class _GapTokens(Function):
+    @staticmethod
+    def forward(ctx, tok):
+        B, T, C = tok.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=tok.device)
+        lib.call('rscotr_gap_tokens_fwd', tok.data_ptr(), out.data_ptr(), B, T, C, _stream())
+        ctx.geom = (B, T, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, C = ctx.geom
+        g = _f32c(g)
+        dx = torch.empty((B, T, C), dtype=torch.float32, device=g.device)
+        lib.call('rscotr_gap_tokens_bwd', g.data_ptr(), dx.data_ptr(), B, T, C, _stream())
+        return dx
+
+
 def global_avg_pool(x):
+    """mmcls GlobalAveragePooling of a (B, C, H, W) map.  The maps of this path are channels-last views of token tensors
+    (tokens_to_map): pooled by one kernel over the tokens, with a dense gradient (the generic mean's expanded gradient costs
+    the consumer a copy); any other layout goes through the device library."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0:
+        tok = x.permute(0, 2, 3, 1)
+        if tok.is_contiguous():
+            B, H, W, C = tok.shape
+            return _GapTokens.apply(tok.reshape(B, H * W, C))
     return x.mean(dim=(2, 3))
 
 
+class _SoftCE(Function):
+    @staticmethod
+    def forward(ctx, score, soft_label, smooth, avg_factor):
+        score, soft_label = _f32c(score), _f32c(soft_label.detach())
+        _chk(score, soft_label)
+        B, C = score.shape
+        loss = torch.empty((), dtype=torch.float32, device=score.device)
+        dscore = torch.empty_like(score)
+        lib.call('rscotr_soft_ce', score.data_ptr(), soft_label.data_ptr(), loss.data_ptr(), dscore.data_ptr(), B, C,
+                 float(smooth), float(avg_factor), _stream())
+        ctx.save_for_backward(dscore)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dscore,) = ctx.saved_tensors
+        return dscore * g, None, None, None
+
+
 def soft_ce_label_smooth(score, soft_label, smooth, avg_factor):
-    """mmcls LabelSmoothLoss('original') + soft cross-entropy, sum / avg_factor."""
+    """mmcls LabelSmoothLoss('original') + soft cross-entropy, sum / avg_factor: loss and d(loss)/d(score) in one launch
+    (rscotr_soft_ce) instead of a smoothing / log-softmax / multiply / sum / divide chain and its five backward nodes."""
+    if score.is_cuda and score.dim() == 2 and score.shape[0] <= 1024 and not soft_label.requires_grad:
+        return _SoftCE.apply(score, soft_label, float(smooth), float(avg_factor))
     C = score.shape[-1]
     t = soft_label * (1 - smooth) + smooth / C
     return (-t * F.log_softmax(score, dim=-1)).sum() / avg_factor

@@ -105,3 +105,36 @@ def test_cdn_queries_kernel(cuda, uniform):
     w.grad = None
     ops.cdn_queries(w, gt_lab, gt_boxn, slot_src, slot_valid, slot_neg, u, uniform, 0.5, 0.4, NC)[0].backward(go)
     assert torch.equal(first, w.grad)
+
+
+def test_cls_head_kernels(cuda):
+    """ops.global_avg_pool on a channels-last map view and ops.soft_ce_label_smooth against the PyTorch lines they replace
+    (mmcls GlobalAveragePooling; LabelSmoothLoss 'original' + soft cross-entropy: slvl_cls_head.py:14-23), values and
+    gradients, one-hot and mixed labels."""
+    import torch.nn.functional as F
+    from rscotr_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(2)
+    B, H, W, C, K = 2, 16, 16, 768, 45
+    tok = torch.randn(B, H * W, C, generator=g).to(cuda).requires_grad_(True)
+    ref_tok = tok.detach().clone().requires_grad_(True)
+    pooled = ops.global_avg_pool(ops.tokens_to_map(tok, (H, W)))
+    ref = ops.tokens_to_map(ref_tok, (H, W)).mean(dim=(2, 3))
+    assert pooled.shape == (B, C) and float((pooled - ref).abs().max()) <= 1e-6
+    go = torch.randn(B, C, generator=g).to(cuda)
+    pooled.backward(go)
+    ref.backward(go)
+    assert float((tok.grad - ref_tok.grad).abs().max()) <= 1e-7 * float(ref_tok.grad.abs().max()) + 1e-12
+    for mixed in (False, True):
+        score = (torch.randn(B, K, generator=g) * 3).to(cuda).requires_grad_(True)
+        rs = score.detach().clone().requires_grad_(True)
+        lab = F.one_hot(torch.randint(0, K, (B,), generator=g), K).float()
+        if mixed:
+            lab = 0.7 * lab + 0.3 * F.one_hot(torch.randint(0, K, (B,), generator=g), K).float()
+        lab = lab.to(cuda)
+        loss = ops.soft_ce_label_smooth(score, lab, 0.1, float(B))
+        t = lab * 0.9 + 0.1 / K
+        rl = (-t * F.log_softmax(rs, dim=-1)).sum() / B
+        assert abs(float(loss) - float(rl)) <= 1e-6 * max(1.0, abs(float(rl)))
+        (loss * 1.7).backward()
+        (rl * 1.7).backward()
+        assert float((score.grad - rs.grad).abs().max()) <= 2e-6 * float(rs.grad.abs().max())
