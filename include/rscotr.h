@@ -326,6 +326,10 @@ int rscotr_gap_tokens_fwd(const float* x, float* out, int B, int T, int C, void*
 int rscotr_gap_tokens_bwd(const float* g, float* dx, int B, int T, int C, void* stream);
 int rscotr_soft_ce(const float* score, const float* label, float* loss, float* dscore, int B, int C, float smooth,
                    float avg_factor, void* stream);
+/* out = p0 + p1 + ... + p(n-1) (n <= 8 dense fp32 arrays of `count` elements, added left to right; out may be p0): the
+ * gradients that meet at a tensor with several consumers (torch autograd adds them pairwise, one launch per consumer). */
+int rscotr_sum8(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4, const float* p5,
+                const float* p6, const float* p7, int n, float* out, int64_t count, void* stream);
 /* out = [a | b | c | d]: flat concatenation of up to four fp32 arrays in one launch (packs the rows and biases of Linear
  * layers that read the same operand, e.g. mmcv MultiScaleDeformableAttention's sampling_offsets and attention_weights,
  * so that they run as one product). */

@@ -240,6 +240,22 @@ __global__ __launch_bounds__(256) void soft_ce_kernel(const float* __restrict__ 
   }
 }
 
+// out = p0 + p1 + ... + p(n-1), n <= 8, left to right (fixed order); out may be p0.  One thread per float4.
+struct SumPtrs { const float4* p[8]; };
+__global__ __launch_bounds__(256) void sum8_kernel(SumPtrs P, int n, float4* out, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = P.p[0][i];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    if (k < n) {
+      const float4 v = P.p[k][i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  out[i] = a;
+}
+
 static int level_starts(const char* who, const int* sizes, int L, int N, LevelStarts* ls) {
   if (L < 1 || L > 8) return fail(RSCOTR_E_SHAPE, "%s: 1..8 levels supported, got %d", who, L);
   if (!sizes) return fail(RSCOTR_E_ARG, "%s: null sizes", who);
@@ -352,4 +368,19 @@ extern "C" int rscotr_soft_ce(const float* score, const float* label, float* los
   if (!score || !label || !loss || !dscore) return fail(RSCOTR_E_ARG, "rscotr_soft_ce: null pointer");
   soft_ce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(score, label, loss, dscore, B, C, smooth, 1.f / avg_factor);
   return check_launch("rscotr_soft_ce");
+}
+
+extern "C" int rscotr_sum8(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4, const float* p5,
+                           const float* p6, const float* p7, int n, float* out, int64_t count, void* stream) {
+  if (n < 1 || n > 8 || count < 0 || (count & 3)) return fail(RSCOTR_E_SHAPE, "rscotr_sum8: 1..8 inputs, count a multiple of 4");
+  if (count == 0) return RSCOTR_OK;
+  const float* ps[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
+  SumPtrs P;
+  for (int k = 0; k < 8; ++k) {
+    if (k < n && (!ps[k] || !aligned16(ps[k]))) return fail(RSCOTR_E_ARG, "rscotr_sum8: null or unaligned input %d", k);
+    P.p[k] = reinterpret_cast<const float4*>(k < n ? ps[k] : ps[0]);
+  }
+  if (!out || !aligned16(out)) return fail(RSCOTR_E_ARG, "rscotr_sum8: null or unaligned output");
+  sum8_kernel<<<(unsigned)((count / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(P, n, reinterpret_cast<float4*>(out), count / 4);
+  return check_launch("rscotr_sum8");
 }

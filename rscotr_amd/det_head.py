@@ -419,6 +419,7 @@ class DinoTransformerDecoder(TransformerLayerSequence):
         full-size zero-fill + copy per use and an add per layer in backward (35 launches on 10 MB tensors per step)."""
         output = query
         inter, inter_ref = [], [reference_points]
+        values = value if isinstance(value, (list, tuple)) else [value] * len(self.layers)  # (one handle per layer: fan_out)
         vr4 = None if unit_ratios else torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         for lid, layer in enumerate(self.layers):
             assert reference_points.shape[-1] == 4
@@ -428,12 +429,15 @@ class DinoTransformerDecoder(TransformerLayerSequence):
             else:
                 rp_in = reference_points[:, :, None] * vr4
                 query_pos = _mlp(ops.sine_embed4(rp_in[:, :, 0, :]), self.ref_point_head)
-            output = layer(output, None, value, query_pos=query_pos, attn_masks=attn_mask,
+            output = layer(output, None, values[lid], query_pos=query_pos, attn_masks=attn_mask,
                            key_padding_mask=key_padding_mask, reference_points=rp_in, **geom.kwargs())
-            tmp = _mlp(output, reg_branches[lid])
+            # three consumers of a layer's output: the next layer, the box branch, the shared norm
+            last = lid == len(self.layers) - 1
+            output, o_reg, o_norm = ops.fan_out(output, 3) if not last else (output, output, output)
+            tmp = _mlp(o_reg, reg_branches[lid])
             new_ref = ops.refine_box(tmp, reference_points, eps=1e-3)
             reference_points = new_ref.detach()
-            inter.append(ops.layer_norm(output, self.norm.weight, self.norm.bias))
+            inter.append(ops.layer_norm(o_norm, self.norm.weight, self.norm.bias))
             inter_ref.append(new_ref)  # look-forward-twice: un-detached
         return inter, inter_ref
 
@@ -548,6 +552,9 @@ class DinoTransformer(nn.Module):
         memory = encoder(feat, None, None, query_pos=pos, query_key_padding_mask=kpm,
                          reference_points=reference_points, **geom.kwargs())
         B = memory.shape[0]
+        # the encoder memory feeds the proposal branch and the value projection of every decoder layer: one handle each
+        mems = ops.fan_out(memory, 1 + self.decoder.num_layers)
+        memory, mem_dec = mems[0], mems[1:]
         om = memory if unpadded else memory.masked_fill(mask_flat.unsqueeze(-1), 0.0)
         om = om.masked_fill(~valid, 0.0)
         om = ops.layer_norm(ops.linear(om, self.enc_output.weight, self.enc_output.bias),
@@ -568,7 +575,7 @@ class DinoTransformer(nn.Module):
             query = torch.cat([dn_label_query, query], dim=1)
         refp = torch.cat([dn_bbox_query, topk_unact], dim=1) if dn_bbox_query is not None else topk_unact
         refp = refp.sigmoid()
-        inter_states, inter_refs = self.decoder(query, memory, refp, valid_ratios, reg_branches, attn_mask,
+        inter_states, inter_refs = self.decoder(query, mem_dec, refp, valid_ratios, reg_branches, attn_mask,
                                                 kpm, geom, unit_ratios=unpadded)
         return inter_states, inter_refs, topk_score, topk_anchor
 

@@ -231,7 +231,12 @@ class BaseTransformerLayer(nn.Module):
             attn_masks = [None] * len(self.attentions)
         elif torch.is_tensor(attn_masks):
             attn_masks = [attn_masks for _ in self.attentions]
+        qp_all = query_pos
         for op in self.operation_order:
+            if op in ('self_attn', 'cross_attn'):
+                # a tuple / list of query_pos: one handle per attention of the layer (ops.fan_out: the gradients of all
+                # consumers of a shared positional embedding are then summed by one launch)
+                query_pos = qp_all[attn_i] if isinstance(qp_all, (tuple, list)) else qp_all
             if op == 'self_attn':
                 query = self.attentions[attn_i](query, query, query, None, query_pos=query_pos, key_pos=query_pos,
                                                 attn_mask=attn_masks[attn_i],
@@ -263,7 +268,12 @@ class TransformerLayerSequence(nn.Module):
         self.pre_norm = self.layers[0].pre_norm
 
     def forward(self, query, key=None, value=None, **kwargs):
-        for layer in self.layers:
+        # the positional embedding is shared by all layers: one handle per layer, so that its gradients meet in one launch
+        qp = kwargs.get('query_pos')
+        qps = ops.fan_out(qp, len(self.layers)) if torch.is_tensor(qp) else None
+        for i, layer in enumerate(self.layers):
+            if qps is not None:
+                kwargs['query_pos'] = qps[i]
             query = layer(query, key, value, **kwargs)
         return query
 

@@ -437,6 +437,51 @@ def level_embed_add(x, weight, sizes, const=None, batch=None, row0=0):
     return _LevelEmbedAdd.apply(x, weight, const, tuple(sizes), batch, row0)
 
 
+FAN_OUT = os.environ.get('RSCOTR_FAN_OUT', '1') != '0'  # (A/B switch)
+
+
+class _FanOut(Function):
+    """n handles of one tensor for n consumers: the gradients of all of them arrive in ONE backward call and are summed by
+    ONE launch per 8 of them (rscotr_sum8, fixed order) instead of by n - 1 pairwise adds of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        gs = [_f32c(g) for g in gs]
+        _chk(*gs)
+        count = gs[0].numel()
+        if count % 4 or any(g.shape != gs[0].shape for g in gs):
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(gs[0])
+        cur, rest = None, gs
+        while rest:
+            take = rest[:8] if cur is None else [cur] + rest[:7]
+            rest = rest[8:] if cur is None else rest[7:]
+            ptrs = [t.data_ptr() for t in take] + [0] * (8 - len(take))
+            lib.call('rscotr_sum8', *ptrs, len(take), out.data_ptr(), count, _stream())
+            cur = out
+        return out, None
+
+
+def fan_out(x, n):
+    """-> n handles of x, one per consumer (see _FanOut); x itself when nothing is to be gained (n <= 2, no gradient)."""
+    if n <= 2 or not FAN_OUT or not (torch.is_tensor(x) and x.requires_grad and x.is_cuda):
+        return [x] * n
+    return list(_FanOut.apply(x, n))
+
+
 class _CdnQueries(Function):
     """The denoising queries of a det batch in slot layout, one launch (rscotr_cdn_queries); the only gradient is the
     label embedding's (fixed-order scatter, straight into the arena when the parameter is sunk)."""

@@ -138,3 +138,24 @@ def test_cls_head_kernels(cuda):
         (loss * 1.7).backward()
         (rl * 1.7).backward()
         assert float((score.grad - rs.grad).abs().max()) <= 2e-6 * float(rs.grad.abs().max())
+
+
+@pytest.mark.parametrize('n,used', [(3, (0, 1, 2)), (18, tuple(range(18))), (9, (0, 3, 8)), (4, (2,))])
+def test_fan_out_sums_the_consumers_gradients(cuda, n, used):
+    """ops.fan_out: n handles of a tensor; the gradient that reaches the tensor is the sum of the consumers' gradients
+    (handles without a consumer contribute nothing), summed left to right — identical to autograd's pairwise adds in the
+    same order up to rounding, and bit-identical between two runs."""
+    from rscotr_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(4)
+    x = torch.randn(2, 100, 256, generator=g).to(cuda).requires_grad_(True)
+    ws = [torch.randn(2, 100, 256, generator=g).to(cuda) for _ in range(n)]
+    hs = ops.fan_out(x, n)
+    assert len(hs) == n
+    sum((hs[i] * ws[i]).sum() for i in used).backward()
+    ref = sum(ws[i].double() for i in used)
+    assert float((x.grad.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    first = x.grad.clone()
+    x.grad = None
+    hs = ops.fan_out(x, n)
+    sum((hs[i] * ws[i]).sum() for i in used).backward()
+    assert torch.equal(first, x.grad)
