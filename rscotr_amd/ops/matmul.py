@@ -1,0 +1,605 @@
+"""Matrix products of the step on the C ABI: `gemm` (rscotr_gemm_f32 and its split-product / weight-plane routes),
+`gemm_batched` (attention products addressed in place), the deferred split-K / grouped weight-gradient machinery (`DEFER`),
+the pre-split weight planes (`WPLANES`), and the Linear / MLP autograd nodes built on them."""
+import os
+
+import torch
+from torch.autograd import Function
+
+from .core import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_RELU_GRAD, _ACT, _WS, _Prof, _chk, _f32c, _gemm_ws_bytes,
+                   _off_path, _ptr, _sink, _stream, lib)
+from .state import STATE
+
+class _WeightPlanes:
+    """bf16 plane sets of the parameters that serve as the B operand of y = x W^T (and dx = dy W): rscotr_gemm_split_weights
+    writes them ONCE per optimizer step and rscotr_gemm_f32_wplanes multiplies fp32 activations with them (include/rscotr.h).
+    A parameter is recognised by its address inside the optimizer's flat arena (`STATE.grad_sink.is_param_ptr`); the sets a task
+    uses are remembered under the task's name (`begin`), and the first product of an iteration that finds them stale
+    re-splits ALL of them in one grouped launch (inside the per-task hipGraph when the iteration is replayed).  `bump()` =
+    "the parameters have changed" (optimizer step, checkpoint load, snapshot restore)."""
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_WPLANES', '1') != '0'
+        self.min_m = int(os.environ.get('RSCOTR_WPLANES_MIN_M', 4096))
+        self.min_k = int(os.environ.get('RSCOTR_WPLANES_MIN_K', 1024))
+        self.version = 1
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.current = None
+
+    def begin(self, group):
+        self.current = group
+
+    def reset(self):
+        """Forget every plane set (a new optimizer arena: addresses may be reused by other parameters)."""
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.version += 1
+
+    def bump(self):
+        self.version += 1
+
+    def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
+        if not self.enabled or a_kmajor or STATE.grad_sink is None or K % 16 or K < self.min_k or M < self.min_m or N < 64:
+            return False
+        if lda % 4 or A.data_ptr() % 16 or (b_kmajor and ldb % 4):
+            return False
+        if lib.rscotr_gemm_get_precision() != 3:
+            return False
+        return STATE.grad_sink.is_param_ptr(B.data_ptr())
+
+    def get(self, B, N, K, ldb, b_kmajor):
+        """-> (planes pointer, npad) of the weight behind operand B (N output rows, reduction K), fresh."""
+        key = (B.data_ptr(), N, K, ldb, int(b_kmajor))
+        e = self.entries.get(key)
+        if e is None:
+            npad = (N + 255) // 256 * 256
+            e = self.entries[key] = dict(planes=torch.empty(npad * K * 3, dtype=torch.int16, device=B.device), npad=npad,
+                                         version=0, blocks=(npad * (K // 16) + 255) // 256)
+        keys = self.groups.setdefault(self.current, [])
+        if key not in keys:
+            keys.append(key)
+        if e['version'] != self.version:
+            self._refresh(keys, B.device)
+        return e['planes'].data_ptr(), e['npad']
+
+    def _refresh(self, keys, dev):
+        stale = tuple(k for k in keys if self.entries[k]['version'] != self.version)
+        hit = self.tables.get(stale)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for (ptr, N, K, ldb, tr) in stale:
+                e = self.entries[(ptr, N, K, ldb, tr)]
+                # table row {W, planes, rows of W, cols of W, ldw, npad, first block, transposed}: operand B (N, K) row-major is
+                # W itself; operand B k-major is the (K, N) matrix W whose TRANSPOSE is multiplied (planes of W^T)
+                rows.append((ptr, e['planes'].data_ptr(), K if tr else N, N if tr else K, ldb, e['npad'], first, tr))
+                first += e['blocks']
+            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+        lib.call('rscotr_gemm_split_weights', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        for k in stale:
+            self.entries[k]['version'] = self.version
+
+
+WPLANES = _WeightPlanes()
+
+
+class _DeferredCombine:
+    """Split-K weight-gradient contractions whose result is ACCUMULATED into the gradient arena leave their slabs in a
+    private region and are combined by ONE launch at the end of the backward pass (`flush_deferred`, called by the
+    runner / optimizer before anything reads the arena) instead of one combine launch each: ~450 launches per
+    co-training round become ~10 (one per task, plus one per repeated use of a shared parameter).  The (slab, destination, shape) table of a pass is static across iterations (slab
+    regions are handed out in call order, destinations are arena addresses), so its device copy is cached by content
+    and a captured hipGraph replays the same flush."""
+
+    BLOCK = 256 << 20
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_DEFER_SPLITK', '1') != '0'
+        self.blocks, self.cur, self.off = [], 0, 0
+        self.entries, self.notify, self.cache = [], [], {}
+        self.ln_entries, self.ln_cache = [], {}
+        # flush tables are addressed by raw pointer from captured hipGraphs: a table that was looked up while a graph
+        # was being warmed up / captured (`pin = True`, set by runner.GraphedTask) is never evicted; the others are
+        # dropped oldest-first once more than MAX_TABLES signatures have been seen
+        self.pin = False
+        self.pinned = set()
+        # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
+        # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
+        self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
+        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '0'))  # 0: fp32 tiles only, 1: bf16x6 128 x 128 tiles for interior problems
+        self.group, self.group_keep, self.group_cache = [], [], {}
+        self.pinned_pool, self.pinned_live = [], []
+        self.wattn_entries, self.wattn_cache = [], {}
+
+    MAX_TABLES = 64
+    GROUP_MAX_OUT = int(os.environ.get('RSCOTR_DW_GROUP_MAX', 160000))     # M * N of a grouped problem
+    GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 3072))    # workgroups a grouped launch aims at
+
+    def _plan_group(self):
+        """Slices and slab regions of the pending grouped problems -> ([(device table, problems, workgroups, variant)],
+        combine entries).  Interior problems (M, N multiples of 128, aligned operands) go to the bf16x6 128 x 128 variant of
+        the grouped kernel, the rest to the fp32 64 x 64 variant: one launch each."""
+        import numpy as np
+        probs = self.group
+
+        def kind(p):
+            a, b, _, _, _, M, N, K, lda, ldb, _ = p
+            ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
+            if self.group_x6 == 3:  # bf16x6 on 64 x 64 tiles, 32 k per step
+                return 3 if ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512 else 0
+            return 2 if ok and M % 128 == 0 and N % 128 == 0 else 0
+        kinds = [kind(p) for p in probs]
+        tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else ((M + 63) // 64) * ((N + 63) // 64)
+                 for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
+        # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
+        work = sum(t * p[7] * (4 if k == 2 else 1) for t, k, p in zip(tiles, kinds, probs))
+        klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
+        dev = self.group_keep[0].device
+        launches, ents = [], []
+        for variant in (0, 2, 3):
+            rows = []
+            for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
+                if x6 != variant:
+                    continue
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
+                kq = 32 if x6 == 3 else 16
+                klen = -(-(-(-K // sp)) // kq) * kq
+                sp = -(-K // klen)
+                if sp == 1:
+                    klen = K
+                slab = self.reserve(sp * (M * N + M) * 4, dev)
+                rs_slab = slab + sp * M * N * 4 if rs else 0
+                rows.append([a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, 0, max(kper, 1), 0, t * sp])
+                ents.append((slab, rs_slab, out, rs, M, N, N, sp))
+            if rows:
+                # bundles of 8 problems of similar size, one problem per XCD (the kernel's id layout): largest first
+                rows.sort(key=lambda r: -r[15])
+                rows += [[0] * 16 for _ in range(-len(rows) % 8)]
+                first = 0
+                for b0 in range(0, len(rows), 8):
+                    for r in rows[b0:b0 + 8]:
+                        r[12] = first
+                    first += 8 * rows[b0][15]
+                launches.append((self._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first, variant))
+                if os.environ.get('RSCOTR_DW_GROUP_DUMP'):  # (tuning aid: the problems of one grouped launch)
+                    print(f'[dw group] variant {variant}: {len(rows)} problems, {first} workgroups, k-slice target {klen_t}')
+                    for r in rows:
+                        print(f'    M={r[5]} N={r[6]} K={r[7]} klen={r[10]} splits={r[11]} rowsum={int(r[3] != 0)}')
+        return launches, ents
+
+    def prepare_capture(self, n=4):
+        """Pinned staging buffers for tables that have to be built WHILE a hipGraph is being captured (the grouped launch's
+        table holds activation addresses, which differ between the warm-up iterations and the capture): a pageable
+        host-to-device copy is not capturable, a pinned one is — and the replayed copy node re-reads the pinned buffer,
+        which therefore lives as long as the cache entry."""
+        while len(self.pinned_pool) < n:
+            self.pinned_pool.append(torch.empty((4096, 16), dtype=torch.int64).pin_memory())
+
+    def _upload(self, arr, dev):
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            assert arr.shape[0] <= 4096 and self.pinned_pool, 'DEFER.prepare_capture() must run before a capture'
+            host = self.pinned_pool.pop()
+            host[:arr.shape[0]].copy_(torch.from_numpy(arr))
+            d = torch.empty(arr.shape, dtype=torch.int64, device=dev)
+            d.copy_(host[:arr.shape[0]], non_blocking=True)
+            self.pinned_live.append(host)
+            return d
+        return torch.from_numpy(arr).to(dev)
+
+    def _remember(self, cache, sig, hit):
+        if self.pin:
+            self.pinned.add(sig)
+        if sig not in cache:
+            cache[sig] = hit
+            if len(cache) > self.MAX_TABLES:
+                for k in list(cache):
+                    if len(cache) <= self.MAX_TABLES:
+                        break
+                    if k not in self.pinned and k != sig:
+                        del cache[k]
+
+    def reserve(self, nbytes, device):
+        nbytes = (nbytes + 255) // 256 * 256
+        while True:
+            if self.cur == len(self.blocks):
+                self.blocks.append(torch.empty(max(self.BLOCK, nbytes) // 4, dtype=torch.float32, device=device))
+            b = self.blocks[self.cur]
+            if self.off + nbytes <= b.numel() * 4:
+                ptr = b.data_ptr() + self.off
+                self.off += nbytes
+                return ptr
+            self.cur, self.off = self.cur + 1, 0
+
+    def pending(self):
+        return bool(self.entries or self.ln_entries or self.group or self.wattn_entries)
+
+    def drop(self):
+        self.entries, self.notify, self.ln_entries = [], [], []
+        self.group, self.group_keep = [], []
+        self.wattn_entries = []
+        self.cur = self.off = 0
+
+    @staticmethod
+    def _rounds(entries, dests):
+        """Entries that share a destination go to successive launches (the combine is a plain read-add-write)."""
+        seen, rounds = {}, []
+        for e in entries:
+            ds = [d for d in dests(e) if d]
+            k = max([seen.get(d, 0) for d in ds] or [0])
+            for d in ds:
+                seen[d] = k + 1
+            while len(rounds) <= k:
+                rounds.append([])
+            rounds[k].append(e)
+        return rounds
+
+    def _flush_ln(self):
+        sig = tuple(self.ln_entries)
+        hit = self.ln_cache.get(sig)
+        if hit is None:
+            import numpy as np
+            dev = self.blocks[0].device
+            hit = []
+            for ents in self._rounds(self.ln_entries, lambda e: (e[1], e[2])):
+                wg = [(r, c) for r, e in enumerate(ents) for c in range((2 * e[4] + 63) // 64)]
+                hit.append((torch.from_numpy(np.asarray(ents, dtype=np.int64)).to(dev),
+                            torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg)))
+        self._remember(self.ln_cache, sig, hit)
+        for tab, wg, nwg in hit:
+            lib.call('rscotr_layernorm_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
+        self.ln_entries = []
+
+    def _flush_group(self):
+        sig = (tuple(self.group), self.cur, self.off)  # (the slab regions continue where this pass's reserves stand)
+        hit = self.group_cache.get(sig)
+        if hit is None:
+            launches, ents = self._plan_group()
+            hit = (launches, ents, self.cur, self.off)
+        else:
+            self.cur, self.off = hit[2], hit[3]
+        self._remember(self.group_cache, sig, hit)
+        for table, n, total, variant in hit[0]:
+            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, _stream())
+        self.entries.extend(hit[1])
+        self.group, self.group_keep = [], []
+
+    def _flush_wattn(self):
+        """Partial rows of the window-attention backward passes (bias-table / pad-token gradients): one fold launch."""
+        sig = tuple(self.wattn_entries)
+        hit = self.wattn_cache.get(sig)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for part, dt, db, heads, C, nrows in self.wattn_entries:
+                rows.append((part, dt, db, heads, C, nrows, first) + (0,) * 9)
+                first += heads
+            hit = (self._upload(np.asarray(rows, dtype=np.int64), self.blocks[0].device), len(rows), first)
+        self._remember(self.wattn_cache, sig, hit)
+        lib.call('rscotr_swin_wattn_flush', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        self.wattn_entries = []
+
+    def flush(self):
+        if self.group:
+            self._flush_group()
+        if self.ln_entries:
+            self._flush_ln()
+        if self.wattn_entries:
+            self._flush_wattn()
+        if self.entries:
+            sig = tuple(self.entries)
+            hit = self.cache.get(sig)
+            if hit is None:
+                import numpy as np
+                # a parameter used several times in one pass (ref_point_head and the shared heads of the DINO decoder:
+                # 6-7 contractions into one destination) must not be combined by concurrent workgroups: entry k of a
+                # destination goes to launch k
+                seen_c, seen_r, rounds = {}, {}, []
+                for e in self.entries:
+                    k = max(seen_c.get(e[2], 0), seen_r.get(e[3], 0) if e[3] else 0)
+                    seen_c[e[2]] = k + 1
+                    if e[3]:
+                        seen_r[e[3]] = k + 1
+                    while len(rounds) <= k:
+                        rounds.append([])
+                    rounds[k].append(e)
+                dev = self.blocks[0].device
+                hit = []
+                for ents in rounds:
+                    tab = np.asarray(ents, dtype=np.int64)
+                    wg = []
+                    for r, e in enumerate(ents):
+                        M, N = e[4], e[5]
+                        wg.extend((r, c) for c in range((max(M * N // 4, M) + 255) // 256))
+                    hit.append((torch.from_numpy(tab).to(dev), torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg)))
+            self._remember(self.cache, sig, hit)
+            for tab, wg, nwg in hit:
+                lib.call('rscotr_splitk_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
+        notify, self.notify = self.notify, []
+        self.entries = []
+        self.cur = self.off = 0
+        if STATE.grad_sink is not None:
+            for i in notify:
+                STATE.grad_sink._on_ready(i)
+
+
+DEFER = _DeferredCombine()
+
+
+def flush_deferred():
+    """Compute the grouped weight gradients and combine the pending split-K weight gradients / LayerNorm parameter
+    gradients into the arena (no-op when nothing is pending)."""
+    if DEFER.pending() or DEFER.notify:
+        DEFER.flush()
+
+
+def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
+    """-> True if the contraction was issued as slabs for the deferred combine."""
+    sink = STATE.grad_sink
+    if sink is None or not DEFER.enabled or STATE.side is not None or N % 4 or out.data_ptr() % 16:
+        return False
+    fg = sink.flat_g
+    lo = fg.data_ptr()
+    if not (lo <= out.data_ptr() < lo + fg.numel() * 4):
+        return False
+    if DEFER.group_enabled and M * N <= DEFER.GROUP_MAX_OUT and K >= 16:
+        # small output: joins the grouped launch at the end of backward (operands stay alive until then)
+        DEFER.group.append((A.data_ptr(), B.data_ptr(), out.data_ptr(), _ptr(rowsum), _ptr(kscale), M, N, K, lda, ldb,
+                            int(krows_per)))
+        DEFER.group_keep.extend(t for t in (A, B, kscale) if t is not None)
+        return True
+    if nws == 0:
+        return False
+    import ctypes
+    ptr = DEFER.reserve(nws, A.device)
+    splits = ctypes.c_int32(1)
+    lib.call('rscotr_gemm_f32_dw_slabs', A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, _ptr(rowsum),
+             _ptr(kscale), int(krows_per), ptr, nws, ctypes.byref(splits), _stream())
+    sp = splits.value
+    if sp > 1:
+        DEFER.entries.append((ptr, ptr + sp * M * N * 4 if rowsum is not None else 0, out.data_ptr(), _ptr(rowsum), M, N, N, sp))
+    return True
+
+
+def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=ACT_NONE, aux=None, pre=None,
+         resid=None, accumulate=False, rowsum=None, rowsum_accumulate=False, rowscale=None, rows_per=0, kscale=None,
+         krows_per=0, out2=None):
+    """C[m,n] = epilogue(sum_k Aop[m,k] Bop[n,k]) on the fp32 matrix cores (include/rscotr.h,
+    rscotr_gemm_f32).  A, B, out are contiguous fp32 device tensors; out (M,N) is allocated here
+    unless given.  `rowsum` (M,) (+)= sum_k Aop[m,k] (k-major A only: the bias gradient riding the dW
+    contraction).  `out2` (M,N): second output out + resid, `out` itself then stays without the residual.
+    Returns out."""
+    _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if (rowsum is None and kscale is None and STATE.profile is None
+            and WPLANES.eligible(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor)):
+        # B is a parameter: multiply with its pre-split bf16 planes (written once per optimizer step)
+        planes, npad = WPLANES.get(B, N, K, ldb, b_kmajor)
+        nws = lib.rscotr_gemm_f32_wplanes_workspace(M, N, K)
+        ws = _WS.get(nws, A.device).data_ptr() if nws else 0
+        lib.call('rscotr_gemm_f32_wplanes', A.data_ptr(), planes, npad, out.data_ptr(), M, N, K, lda, N, _ptr(bias), int(act),
+                 _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowscale), int(rows_per), _ptr(out2), ws, nws,
+                 _stream())
+        return out
+    key = (M, N, K, lib.rscotr_gemm_get_precision())  # the workspace a shape wants depends on the precision mode
+    nws = _gemm_ws_bytes.get(key)
+    if nws is None:
+        nws = _gemm_ws_bytes[key] = lib.rscotr_gemm_f32_workspace(M, N, K)
+    if (accumulate and a_kmajor and b_kmajor and bias is None and act == ACT_NONE and resid is None and pre is None
+            and rowscale is None and (rowsum is None or rowsum_accumulate) and STATE.profile is None
+            and _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws)):
+        return out
+    ws = _WS.get(nws, A.device).data_ptr() if nws else 0
+    args = (A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, int(a_kmajor), int(b_kmajor),
+            _ptr(bias), int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowsum),
+            int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), _ptr(out2), ws, nws,
+            _stream())
+    if STATE.profile is None:
+        lib.call('rscotr_gemm_f32', *args)
+    else:
+        with _Prof('gemm', 2 * M * N * K, gemm_kernel_name(M, N, K, a_kmajor, b_kmajor),
+                   shape=(M, N, K, int(a_kmajor), int(b_kmajor))):
+            lib.call('rscotr_gemm_f32', *args)
+    return out
+
+
+def gemm_kernel_name(M, N, K, a_kmajor, b_kmajor):
+    """Name of the kernel instantiation rscotr_gemm_f32 launches for this problem (mirrors the tile
+    choice in csrc/gemm.hip; used to label roofline samples so they can be matched with rocprof)."""
+    if N <= 32:
+        bm, bn, wm, wn = 128, 32, 4, 1
+    elif N >= 1024 and M >= 4096 and M % 128 == 0:
+        bm, bn, wm, wn = 128, 64, 2, 2
+    else:
+        bm, bn, wm, wn = 64, 64, 2, 2
+    return f'rscotr::gemm_f32_kernel<{bm}, {bn}, {wm}, {wn}, {"true" if a_kmajor else "false"}, ' \
+           f'{"true" if b_kmajor else "false"}, *>'
+
+
+def colsum(X, M, N, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    nws = lib.rscotr_colsum_f32_workspace(M, N)
+    ws = _WS.get(nws, X.device)
+    lib.call('rscotr_colsum_f32', X.data_ptr(), out.data_ptr(), M, N, N, int(accumulate), ws.data_ptr(), nws,
+             _stream())
+    return out
+
+
+class _MLP(Function):
+    """y = L_n(act(L_{n-1}(... act(L_1(x))))) [+ identity], L_i(h) = h W_i^T + b_i: every Linear is
+    one MFMA GEMM with bias/activation/residual fused in its epilogue; backward folds act' into the
+    epilogue of the dX GEMM of the following layer (no separate element-wise passes).
+    `out_scale` (B,) or None: per-sample factor on the last layer's output before the identity is added (the
+    DropPath of a Swin block folded into its proj / fc2 Linear): forward rides the epilogue, backward the
+    epilogue of dH and the operand staging of dW / db.
+    args: x, identity (Tensor | None), act code, out_scale, then W_1, b_1, ..., W_n, b_n (b may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, identity, act, out_scale, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[0::2], wb[1::2]
+        K0 = x.shape[-1]
+        x2 = _f32c(x).reshape(-1, K0)
+        M = x2.shape[0]
+        id_is_x = identity is x  # mmcv FFN: identity defaults to the input itself
+        rows_per = 0
+        if out_scale is not None:
+            out_scale = _f32c(out_scale)
+            assert x.dim() == 3 and out_scale.numel() == x.shape[0]
+            rows_per = x.shape[1]
+        id2 = None if identity is None else (x2 if id_is_x else _f32c(identity).reshape(M, -1))
+        hs, auxs = [x2], []
+        h = x2
+        for i in range(n):
+            W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
+            N, K = W.shape
+            last = i == n - 1
+            pre = None
+            if not last and act == ACT_GELU:
+                pre = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+            sc = out_scale if last else None
+            h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else act, pre=pre,
+                     resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0)
+            if not last:
+                hs.append(h)
+                auxs.append(pre if act == ACT_GELU else h)
+        ctx.save_for_backward(*hs, *auxs, *ws)
+        ctx.out_scale, ctx.rows_per = out_scale, rows_per
+        ctx.n, ctx.act, ctx.has_id, ctx.id_is_x = n, act, identity is not None, id_is_x
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.biases = bs  # parameter handles only (for the gradient sink); not needed as saved tensors
+        ctx.x_shape = x.shape
+        ctx.id_shape = None if identity is None else identity.shape
+        return h.view(*x.shape[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, act = ctx.n, ctx.act
+        saved = ctx.saved_tensors
+        hs, auxs, ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
+        M = hs[0].shape[0]
+        g = _f32c(dy).reshape(M, -1)
+        g_out = g
+        d_id = g.view(ctx.id_shape) if ctx.has_id and not ctx.id_is_x and ctx.needs_input_grad[1] else None
+        grads_wb = [None] * (2 * n)
+        gact = ACT_RELU_GRAD if act == ACT_RELU else ACT_GELU_GRAD
+        dx = None
+        for i in range(n - 1, -1, -1):
+            W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
+            N, K = W.shape
+            want_w = ctx.needs_input_grad[4 + 2 * i]
+            want_b = ctx.has_bias[i] and ctx.needs_input_grad[5 + 2 * i]
+            # the last layer's upstream gradient is s_b * dy: folded into the three contractions that read it
+            sc = ctx.out_scale if i == n - 1 else None
+            sck = dict(kscale=sc, krows_per=ctx.rows_per) if sc is not None else {}
+            scr = dict(rowscale=sc, rows_per=ctx.rows_per) if sc is not None else {}
+            rs, rs_acc, skb = None, False, None
+            if want_b:
+                skb = _sink(ctx.biases[i])
+                if skb is None:
+                    rs = grads_wb[2 * i + 1] = torch.empty(N, dtype=torch.float32, device=g.device)
+                else:  # straight into the gradient arena
+                    rs, rs_acc = skb[1], True
+            if want_w:
+                # dW = g^T h; the bias gradient (column sums of g = row sums of the k-major A) rides along
+                sk = _sink(ws[i])
+                if sk is None:
+                    grads_wb[2 * i] = gemm(g, hs[i], N, K, M, N, K, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc, **sck)
+                elif skb is not None or not want_b:  # everything lands in the arena: off the critical path
+                    _off_path(lambda g=g, h=hs[i], o=sk[1], rs=rs: gemm(g, h, N, K, M, N, K, 1, 1, out=o, accumulate=True,
+                                                                        rowsum=rs, rowsum_accumulate=rs_acc, **sck),
+                              g, hs[i], sc)
+                    STATE.grad_sink.grad_written(sk[0])
+                else:
+                    gemm(g, hs[i], N, K, M, N, K, 1, 1, out=sk[1], accumulate=True, rowsum=rs,
+                         rowsum_accumulate=rs_acc, **sck)
+                    STATE.grad_sink.grad_written(sk[0])
+            elif want_b:
+                if sc is not None:
+                    raise RuntimeError('out_scale with a bias-only gradient is not supported')
+                colsum(g, M, N, out=rs, accumulate=rs_acc)
+            if skb is not None:
+                STATE.grad_sink.grad_written(skb[0])
+            if i > 0:
+                g = gemm(g, W, M, K, N, N, K, 0, 1, act=gact, aux=auxs[i - 1], **scr)  # dH = (g W) * act'
+            elif ctx.needs_input_grad[0]:
+                # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
+                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr).view(ctx.x_shape)
+        return (dx, d_id, None, None, *grads_wb)
+
+
+def mlp(x, layers, act='relu', identity=None, out_scale=None):
+    """layers: [(W, b), ...]; activation between layers, none after the last; `identity` (same shape
+    as the output) is added in the last epilogue (mmcv FFN add_identity); `out_scale` (B,) multiplies the
+    output per sample before that (DropPath)."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _MLP.apply(x, identity, _ACT[act], out_scale, *flat)
+
+
+def linear(x, w, b=None, act=None, resid=None, out_scale=None):
+    """F.linear(x, w, b) [* out_scale per sample] (+ resid) on the matrix cores.  Activations belong to `mlp`."""
+    if act is not None:
+        raise RuntimeError('ops.linear has no activation: use ops.mlp')
+    return _MLP.apply(x, resid, ACT_NONE, out_scale, w, b)
+
+
+def _attn_ksplits(M, N, K, nb):
+    """Slices of the key axis for an attention product with few output tiles (P v, dS k): aim at >= 512
+    workgroups, >= 128 keys per slice, K divisible."""
+    tiles = ((M + 127) // 128) * nb if N <= 32 else ((M + 63) // 64) * ((N + 63) // 64) * nb
+    sp = 1
+    while tiles * sp < 512 and K % (sp * 2) == 0 and K // (sp * 2) >= 128 and (K // (sp * 2)) % 16 == 0:
+        sp *= 2
+    return sp
+
+
+def gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, nb0, nb1, sA, sB, sC, offA=0, offB=0, offC=0,
+                 accumulate=False, ksplit=False):
+    """nb0*nb1 products of one shape addressed in place (rscotr_gemm_f32_batched); s? = (stride b0, stride b1)
+    and off? = element offset of the first problem inside the tensor."""
+    _chk(A, B, C)
+    flops = 2 * M * N * K * nb0 * nb1
+    sp = _attn_ksplits(M, N, K, nb0 * nb1) if (ksplit and not a_kmajor and b_kmajor and not accumulate and offC == 0) else 1
+    ws = _WS.get(sp * C.numel() * 4, C.device).data_ptr() if sp > 1 else 0
+    args = (A.data_ptr() + 4 * offA, B.data_ptr() + 4 * offB, C.data_ptr() + 4 * offC, M, N, K, lda, ldb, ldc,
+            int(a_kmajor), int(b_kmajor), nb0, nb1, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], int(accumulate), sp, ws,
+            C.numel(), _stream())
+    if STATE.profile is None:
+        lib.call('rscotr_gemm_f32_batched', *args)
+    else:
+        with _Prof('gemm_batched', flops, 'rscotr::gemm_f32_kernel (batched attention products)'):
+            lib.call('rscotr_gemm_f32_batched', *args)
+    return C
+
+
+def _linear_param_grad(A, Bm, M, N, K, w_handle, b_handle, row0, want_w, want_b, lda=None):
+    """Parameter gradients of y = x W^T + b from A = dy (K rows, M columns as the k-major operand) and Bm = x:
+    dW[row0:row0+M] (+)= A^T Bm, db[row0:row0+M] (+)= column sums of A (riding the dW contraction); straight into the
+    gradient arena when the parameter is sunk (then nothing is returned for it).  `lda`: row stride of A when it is a column
+    block of a wider tensor.  Returns (gw, gb, sink_w, sink_b)."""
+    dev = A.device
+    skw = _sink(w_handle) if want_w else None
+    skb = _sink(b_handle) if want_b else None
+    gw = gb = None
+    rs, rs_acc = None, False
+    if want_b:
+        if skb is not None:
+            rs, rs_acc = skb[1][row0:row0 + M], True
+        else:
+            rs = gb = torch.empty(M, dtype=torch.float32, device=dev)
+    if want_w:
+        if skw is not None and (skb is not None or not want_b):
+            _off_path(lambda: gemm(A, Bm, M, N, K, lda or M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True,
+                                   rowsum=rs, rowsum_accumulate=rs_acc), A, Bm)
+        elif skw is not None:
+            gemm(A, Bm, M, N, K, lda or M, N, 1, 1, out=skw[1][row0:row0 + M], accumulate=True, rowsum=rs,
+                 rowsum_accumulate=rs_acc)
+        else:
+            gw = gemm(A, Bm, M, N, K, lda or M, N, 1, 1, rowsum=rs, rowsum_accumulate=rs_acc)
+    elif want_b:
+        assert lda is None or lda == M
+        colsum(A, K, M, out=rs, accumulate=rs_acc)
+    return gw, gb, skw, skb
+

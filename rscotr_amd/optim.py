@@ -146,7 +146,7 @@ class FlatAdamW:
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                        for i, p in enumerate(params) if p.requires_grad]
         self._by_ptr = {p.data_ptr(): i for i, p in enumerate(params) if p.requires_grad and p.numel() > 0}
-        ops.GRAD_SINK = self
+        ops.STATE.grad_sink = self
 
     def _make_hook(self, i):
         def hook(param):
@@ -188,8 +188,8 @@ class FlatAdamW:
             cb(i)
 
     def close(self):
-        if ops.GRAD_SINK is self:
-            ops.GRAD_SINK = None
+        if ops.STATE.grad_sink is self:
+            ops.STATE.grad_sink = None
 
     def mark_live(self, names):
         name2i = {g['name']: i for i, g in enumerate(self.groups)}

@@ -23,3 +23,59 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The parity suite must test what ships (a test that left the MSDA backward strategy changed made
+# every later whole-step test run a non-default kernel).  Before EVERY test — ahead of the test's own fixtures, which may
+# then select another setting for the test's duration — the process-wide product state must equal what the process started
+# with: the operator switches (ops.STATE), the GEMM precision mode, the deferred-work / weight-plane toggles, the RSCOTR_*
+# environment.  A leak fails the NEXT test with the name of what leaked instead of silently changing what it measures.
+# ----------------------------------------------------------------------------------------------------------------------
+_BASE = {}
+
+
+def _product_state():
+    from rscotr_amd import ops
+    from rscotr_amd._lib import LIB_PATH, lib
+    st = dict(switches=tuple(sorted(ops.STATE.changed().items())),
+              hooks=(ops.STATE.side is None, ops.STATE.profile is None),
+              defer=(ops.DEFER.enabled, ops.DEFER.group_enabled, ops.DEFER.group_x6, ops.DEFER.pin),
+              wplanes=(ops.WPLANES.enabled, ops.WPLANES.min_m, ops.WPLANES.min_k),
+              env=tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('RSCOTR_'))))
+    if os.path.exists(LIB_PATH):
+        st['gemm_precision'] = int(lib.rscotr_gemm_get_precision())
+    return st
+
+
+def pytest_runtest_setup(item):
+    cur = _product_state()
+    if not _BASE:
+        assert cur['switches'] == (), cur['switches']
+        _BASE.update(cur)
+        return
+    leaked = {k: (cur[k], _BASE[k]) for k in _BASE if cur.get(k) != _BASE[k]}
+    assert not leaked, f'product state changed by an earlier test and not restored (now, at start): {leaked}'
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _BASE:
+        # one line in the log of every run: what the whole-step tests ran with
+        from rscotr_amd import ops
+        print(f"\n[conftest] product state held for the whole session: switches {ops.STATE.defaults()}, "
+              f"gemm precision mode {_BASE.get('gemm_precision')}")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Which whole-step parity checks needed the fp64 judge, and the product's distance from it (tests/parity.py)."""
+    parity = sys.modules.get('parity')
+    if parity is None or not parity.PARITY_LOG:
+        return
+    tr = terminalreporter
+    tr.write_sep('-', 'whole-step parity: fp32 tiers / fp64 anchor')
+    for r in parity.PARITY_LOG:
+        a = r['anchor']
+        tr.write_line(f"{r['test']}: {r['tensors'] - r['over_tight']}/{r['tensors']} tensors within 1e-3 of the fp32 oracle; "
+                      f"decided_by_fp64_anchor={r['decided_by_fp64_anchor']}"
+                      + ('' if a is None else f"; anchor {a['within']}/{a['of']} within bound, worst ratio {a['worst_ratio']} "
+                                               f"({a['worst_tensor']}), median ep {a['ep_med']} / eo {a['eo_med']}"))

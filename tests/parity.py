@@ -161,6 +161,19 @@ ANCHOR_K = 4.0          # ep <= ANCHOR_K * max(eo, amb, ANCHOR_FLOOR) for at lea
 ANCHOR_FRACTION = 0.97
 ANCHOR_K_ALL = 150.0    # ... and within this factor for every tensor
 ANCHOR_FLOOR = 2e-7
+ANCHOR_EP_MEDIAN = 1e-4  # absolute: the median tensor of the product is within 1e-4 of the fp64 evaluation (measured ~5e-6)
+
+# When the fp32 tiers FAIL and the anchor decides (the gate must not loosen exactly where it is consulted), the
+# fp32 oracle's own distance eo is no yardstick any more — it is the suspect — so the product is held to the fp64 evaluation
+# ABSOLUTELY: >= ANCHOR_FRACTION of the tensors within RTOL (1e-3, the north star's tolerance) of fp64, median within
+# ANCHOR_EP_MEDIAN; the remaining tensors within ANCHOR_K_ALL x the coin-toss ambiguity amb of that tensor, or — only where
+# the band does NOT explain the oracle's distance (eo > 10 amb: an ill-conditioned sum, e.g. a bias whose exact gradient
+# nearly cancels, where both fp32 evaluations carry the same relative noise) — within ANCHOR_K x eo.
+ANCHOR_EO_CLEAN = 10.0
+
+# one record per checked step, printed by tests/conftest.py in the terminal summary (so the log of a run shows which tests
+# needed the fp64 judge and how far the product was from it)
+PARITY_LOG = []
 
 
 def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LOOSE_MAX):
@@ -199,15 +212,34 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
             orec['_fp64_anchor']()
         assert 'P64' in orec, (out['grad_report'], bad[:5])
         out['grad_report']['decided_by_fp64_anchor'] = True
+    decided = bool(out['grad_report'].get('decided_by_fp64_anchor'))
     if 'P64' in orec:
         rep = anchor_report(model, P, orec['P64'], orec.get('P64b'))
-        ratio = sorted(((r['ep'] / max(r['eo'], r['amb'], ANCHOR_FLOOR), r['name']) for r in rep), reverse=True)
-        within = sum(1 for x, _ in ratio if x <= ANCHOR_K)
-        out['anchor_report'] = dict(tensors=len(rep), within_k=within, worst=ratio[:5],
-                                    ep_med=sorted(r['ep'] for r in rep)[len(rep) // 2],
-                                    eo_med=sorted(r['eo'] for r in rep)[len(rep) // 2])
+        ep_med = sorted(r['ep'] for r in rep)[len(rep) // 2]
+        eo_med = sorted(r['eo'] for r in rep)[len(rep) // 2]
+        if decided:
+            def allowance(r):
+                a = max(RTOL, ANCHOR_K_ALL * max(r['amb'], ANCHOR_FLOOR))
+                return max(a, ANCHOR_K * r['eo']) if r['eo'] > ANCHOR_EO_CLEAN * r['amb'] else a
+            ratio = sorted(((r['ep'] / allowance(r), r['name']) for r in rep), reverse=True)
+            within = sum(1 for r in rep if r['ep'] <= RTOL)
+        else:
+            ratio = sorted(((r['ep'] / max(r['eo'], r['amb'], ANCHOR_FLOOR), r['name']) for r in rep), reverse=True)
+            within = sum(1 for x, _ in ratio if x <= ANCHOR_K)
+        out['anchor_report'] = dict(tensors=len(rep), within_k=within, worst=ratio[:5], ep_med=ep_med, eo_med=eo_med,
+                                    decided=decided)
         assert within >= ANCHOR_FRACTION * len(rep), out['anchor_report']
-        assert ratio[0][0] <= ANCHOR_K_ALL, out['anchor_report']
+        assert ratio[0][0] <= (1.0 if decided else ANCHOR_K_ALL), out['anchor_report']
+        assert ep_med <= ANCHOR_EP_MEDIAN, out['anchor_report']
+    import os
+    PARITY_LOG.append(dict(test=os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], tensors=len(rows),
+                           over_tight=len(loose), decided_by_fp64_anchor=decided,
+                           anchor=None if 'anchor_report' not in out else dict(
+                               within=out['anchor_report']['within_k'], of=out['anchor_report']['tensors'],
+                               worst_ratio=round(out['anchor_report']['worst'][0][0], 3),
+                               worst_tensor=out['anchor_report']['worst'][0][1],
+                               ep_med=float(f"{out['anchor_report']['ep_med']:.3g}"),
+                               eo_med=float(f"{out['anchor_report']['eo_med']:.3g}"))))
     if 'attn_masks' in rec and 'attn_masks' in orec:
         # masked-attention decisions: the oracle's own masks vs the product's, bit for bit; a logit
         # within fp32 rounding of 0 may land on either side, nothing else may differ

@@ -77,7 +77,7 @@ def test_step_is_bitwise_reproducible(task, prec, cuda):
 def test_step_is_bitwise_reproducible_512(task, msda, cuda, monkeypatch):
     """BASELINE configs[1] size (N = 5440 tokens): the size at which round 1 saw run-to-run gradient states."""
     from rscotr_amd import ops
-    monkeypatch.setattr(ops, 'MSDA_BWD_STRATEGY', msda)
+    monkeypatch.setattr(ops.STATE, 'msda_bwd', msda)
     cfg, mcfg = load_model_cfg(tiny=False)
     model = build_model(mcfg, seed=4).to(cuda)
     a = run_once(model, task, 512, 17, cuda)
@@ -116,20 +116,20 @@ def test_step_is_bitwise_reproducible_across_processes(cuda):
 
 @pytest.mark.parametrize('strategy', ['scatter'])
 def test_scatter_strategy_is_order_dependent_by_design(strategy, cuda):
-    """The atomic-scatter fallback of the MSDA backward (ops.MSDA_BWD_STRATEGY = 'scatter'; used when no workspace is
+    """The atomic-scatter fallback of the MSDA backward (ops.STATE.msda_bwd = 'scatter'; used when no workspace is
     given) accumulates with fp32 atomics whose order varies from run to run: the one documented order-dependent op.
     This test pins that statement — its gradients agree to rounding (1e-5 of the tensor's maximum), not bitwise; the
     forward pass is bitwise in every mode."""
     from rscotr_amd import ops
     cfg, mcfg = load_model_cfg(tiny=False)
     model = build_model(mcfg, seed=1).to(cuda)
-    old = ops.MSDA_BWD_STRATEGY
-    ops.MSDA_BWD_STRATEGY = strategy
+    old = ops.STATE.msda_bwd
+    ops.STATE.msda_bwd = strategy
     try:
         a = run_once(model, 'seg', 256, 11, cuda)
         b = run_once(model, 'seg', 256, 11, cuda)
     finally:
-        ops.MSDA_BWD_STRATEGY = old
+        ops.STATE.msda_bwd = old
     assert first_difference(a[0], b[0]) is None  # the forward pass has no atomics
     for n in a[1]:
         d = float((a[1][n] - b[1][n]).abs().max())

@@ -41,14 +41,11 @@ def test_msda_kernels_match_grid_sample_golden(cuda):
     z = _load('msda_gridsample.npz')
     shapes = torch.from_numpy(z['shapes']).long()
     starts = torch.cat([torch.zeros(1, dtype=torch.long), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
-    for strategy in ('sorted', 'scatter'):
-        ops.MSDA_BWD_STRATEGY = strategy
-        try:
+    for strategy in ('tiled', 'sorted', 'scatter'):   # 'tiled' is the shipped default
+        with ops.STATE.override(msda_bwd=strategy):
             value, loc, attn = (torch.from_numpy(z[k]).to(cuda).requires_grad_(True) for k in ('value', 'loc', 'attn'))
             out = ops.msda(value, shapes.to(cuda), starts.to(cuda), loc, attn)
             out.backward(torch.from_numpy(z['gout']).to(cuda))
-        finally:
-            ops.MSDA_BWD_STRATEGY = 'sorted'
         assert _rel(out.detach().cpu().numpy(), z['out']) < 1e-5
         assert _rel(value.grad.cpu().numpy(), z['gvalue']) < 1e-5
         assert _rel(loc.grad.cpu().numpy(), z['gloc']) < 1e-4

@@ -11,10 +11,8 @@ pytestmark = pytest.mark.gpu
 def bwd_strategy(request):
     """Both grad_value strategies of rscotr_msda_bwd run every test (include/rscotr.h)."""
     from rscotr_amd import ops
-    old = ops.MSDA_BWD_STRATEGY
-    ops.MSDA_BWD_STRATEGY = request.param
-    yield request.param
-    ops.MSDA_BWD_STRATEGY = old
+    with ops.STATE.override(msda_bwd=request.param):
+        yield request.param
 
 SHAPES_512 = [(64, 64), (32, 32), (16, 16), (8, 8)]
 
@@ -191,33 +189,22 @@ def test_sine_embed4_matches_reference_formula(cuda):
     assert out.shape == ref.shape and float((out - ref).abs().max()) < 2e-4  # fp32 sin/cos of arguments up to 2*pi
 
 
-@pytest.mark.parametrize('shapes,expect', [
-    ([(128, 128), (64, 64), (32, 32), (16, 16)], 'sorted'),   # BASELINE configs[4] (Swin-B 1024^2): N = 21760
-    ([(1, 30000), (2, 2)], 'scatter'),                          # degenerate pyramid: 60 011 bins exceed the LDS histogram
+@pytest.mark.parametrize('shapes,Nq', [
+    ([(100, 100), (50, 50), (25, 25), (13, 13)], 13294),     # BASELINE configs[3] (det 800^2): the encoder call, Nq = Nk
+    ([(128, 128), (64, 64), (32, 32), (16, 16)], 21760),     # BASELINE configs[4] (Swin-B 1024^2): Nq = Nk = 21760
+    ([(1, 30000), (2, 2)], 4000),                             # degenerate pyramid: 60 011 bins exceed the LDS histogram
 ])
-def test_msda_large_pyramids(cuda, bwd_strategy, shapes, expect):
-    """Pyramids whose host-side bin bound (2 Nk + 2 L + 2) exceeds the LDS histogram: the kernels decide on the
-    device from the level shapes whether the sorted path runs or stands down for the atomic scatter (csrc/msda.hip,
-    MSDA_LDS_WORDS); either way the result equals the caller-selected scatter strategy's."""
-    if bwd_strategy == 'scatter':
-        pytest.skip('compares the workspace strategies against the scatter entry itself')
-    from rscotr_amd import ops
-    Nk = sum(h * w for h, w in shapes)
-    Nq = 4000
+def test_msda_large_pyramids(cuda, bwd_strategy, shapes, Nq):
+    """The pyramids of BASELINE configs[3] / configs[4] at their full token counts, and one whose host-side bin bound
+    (2 Nk + 2 L + 2) exceeds the LDS histogram of the sorted strategy (the kernels decide on the device from the level
+    shapes whether that path runs or stands down for the atomic scatter: csrc/msda.hip, MSDA_LDS_WORDS): every strategy
+    against the ORACLE (seg_head/pixel_decoder.py:134-146, bbox_head/transformer.py:211-221 reach the op at these shapes)."""
+    L = len(shapes)
     value, ss, lsi, loc, attn = _inputs(1, shapes, Nq, 8, 32, 4, seed=11, spread=0.05)
-    go = torch.randn(1, Nq, 256, generator=torch.Generator().manual_seed(3)).to(cuda)
-    res = {}
-    for strat in (bwd_strategy, 'scatter'):
-        ops.MSDA_BWD_STRATEGY = strat
-        v, l, a = (t.clone().to(cuda).requires_grad_(True) for t in (value, loc, attn))
-        out = ops.msda(v, ss.to(cuda), lsi.to(cuda), l, a)
-        out.backward(go)
-        res[strat] = (out.detach(), v.grad, l.grad, a.grad)
-    ops.MSDA_BWD_STRATEGY = bwd_strategy
-    assert Nk * 2 + 2 * len(shapes) + 2 > (156 * 1024) // 4  # the regime under test
-    for s_, c_ in zip(res[bwd_strategy], res['scatter']):
-        assert torch.isfinite(s_).all()
-        _close(c_.cpu(), s_.cpu(), rtol=1e-4, atol=1e-4 * float(c_.abs().max()) + 1e-7)
+    ref, got = _run_pair(value, ss, lsi, loc, attn, cuda)
+    for r, g in zip(ref, got):
+        assert torch.isfinite(g).all()
+        _close(r, g)
 
 
 @pytest.mark.parametrize('kind', ['encoder', 'decoder', 'decoder_const_pos', 'plain'])

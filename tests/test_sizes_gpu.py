@@ -34,10 +34,11 @@ def test_det_step_800_bs4_matches_oracle(cuda):
 
 
 @pytest.mark.timeout(2400)
-@pytest.mark.parametrize('task', ['seg', 'det'])
+@pytest.mark.parametrize('task', ['cls', 'seg', 'det'])
 def test_swin_b_1024_step_matches_oracle(task, cuda):
     """configs[4]: Swin-B backbone (embed 128, depths 2-2-18-2, heads 4-8-16-32), 1024x1024, bs=1: the MSDA LDS-histogram
-    limit, split-K sizing and 32-head windows at their largest."""
+    limit, split-K sizing and 32-head windows at their largest; all three iterations of the round (cls: backbone + pooled
+    head on 256^2 stage-1 tokens)."""
     cfg, mcfg = swin_b_cfg()
     model = build_model(mcfg, seed=7).to(cuda)
     out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 1024, seed=31, device=cuda, batch_size=1)

@@ -51,6 +51,15 @@ def patch_ops_with_oracle(monkeypatch):
 
     import torch.nn.functional as F
 
+    def _set(name, fn):
+        # the package re-exports its submodules' names: patch the name wherever it is bound, so that composite ops calling a
+        # primitive through their own module (ops.patch_embed -> linear) take the patched one too
+        import types
+        monkeypatch.setattr(ops, name, fn)
+        for sub in vars(ops).values():
+            if isinstance(sub, types.ModuleType) and sub.__name__.startswith('rscotr_amd.ops.') and hasattr(sub, name):
+                monkeypatch.setattr(sub, name, fn)
+
     def msda(value, ss, lsi, loc, attn):
         return O.msda_sample(value, ss, lsi, loc, attn)
 
@@ -166,7 +175,7 @@ def patch_ops_with_oracle(monkeypatch):
         y = F.linear(out.reshape(B, Nq, C), w_o, b_o)
         return y if identity is None else identity + y
 
-    monkeypatch.setattr(ops, 'msda_attention', msda_attention)
+    _set('msda_attention', msda_attention)
 
     def level_embed_add(x, weight, sizes, const=None, batch=None, row0=0):
         rows = torch.cat([weight[row0 + l].view(1, -1).expand(int(n), -1) for l, n in enumerate(sizes)], 0)[None]
@@ -176,8 +185,8 @@ def patch_ops_with_oracle(monkeypatch):
         B = x.shape[0] if x is not None else (batch or const.shape[0])
         return out.expand(B, -1, -1) if out.shape[0] != B else out
 
-    monkeypatch.setattr(ops, 'level_embed_add', level_embed_add)
-    monkeypatch.setattr(ops, 'cdn_queries', cdn_queries_ref)
+    _set('level_embed_add', level_embed_add)
+    _set('cdn_queries', cdn_queries_ref)
 
     def match_cost_batched(cls_score, bbox_pred, gt_bboxes, gt_labels, factors, w_cls, w_l1, w_iou, alpha, gamma, eps):
         S, B, Q, C = cls_score.shape
@@ -215,35 +224,35 @@ def patch_ops_with_oracle(monkeypatch):
     def mask_logits(e, mask_tokens):
         return torch.einsum('bqd,bpd->bqp', e, mask_tokens)
 
-    monkeypatch.setattr(ops, 'mask_logits', mask_logits)
+    _set('mask_logits', mask_logits)
 
     def refine_box(delta, ref, eps=1e-3):
         from rscotr_amd.layers import inverse_sigmoid
         return (delta + inverse_sigmoid(ref, eps=eps)).sigmoid()
 
-    monkeypatch.setattr(ops, 'refine_box', refine_box)
-    monkeypatch.setattr(ops, 'match_cost_batched', match_cost_batched)
-    monkeypatch.setattr(ops, 'sigmoid_focal_loss_sum', sigmoid_focal_loss_sum)
-    monkeypatch.setattr(ops, 'box_loss_sums', box_loss_sums)
+    _set('refine_box', refine_box)
+    _set('match_cost_batched', match_cost_batched)
+    _set('sigmoid_focal_loss_sum', sigmoid_focal_loss_sum)
+    _set('box_loss_sums', box_loss_sums)
 
     def sine_embed4(pos):
         from rscotr_amd.det_head import DinoTransformerDecoder
         return DinoTransformerDecoder.gen_sineembed_for_position(pos)
 
-    monkeypatch.setattr(ops, 'sine_embed4', sine_embed4)
-    monkeypatch.setattr(ops, 'msda_prep', msda_prep)
-    monkeypatch.setattr(ops, 'seg_attn_mask', seg_attn_mask)
-    monkeypatch.setattr(ops, 'mha', mha)
-    monkeypatch.setattr(ops, 'lsap_device', lsap_device)
-    monkeypatch.setattr(ops, 'upsample_ce', upsample_ce)
-    monkeypatch.setattr(ops, 'group_norm_tokens', group_norm_tokens)
-    monkeypatch.setattr(ops, 'conv3x3s2_tokens', conv3x3s2_tokens)
-    monkeypatch.setattr(ops, 'swin_window_attention', swin_window_attention)
-    monkeypatch.setattr(ops, 'msda', msda)
-    monkeypatch.setattr(ops, 'linear', linear)
-    monkeypatch.setattr(ops, 'mlp', mlp)
-    monkeypatch.setattr(ops, 'layer_norm', layer_norm)
-    monkeypatch.setattr(ops, 'layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
+    _set('sine_embed4', sine_embed4)
+    _set('msda_prep', msda_prep)
+    _set('seg_attn_mask', seg_attn_mask)
+    _set('mha', mha)
+    _set('lsap_device', lsap_device)
+    _set('upsample_ce', upsample_ce)
+    _set('group_norm_tokens', group_norm_tokens)
+    _set('conv3x3s2_tokens', conv3x3s2_tokens)
+    _set('swin_window_attention', swin_window_attention)
+    _set('msda', msda)
+    _set('linear', linear)
+    _set('mlp', mlp)
+    _set('layer_norm', layer_norm)
+    _set('layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
 
 
 def rel_err(a, b):
