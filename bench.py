@@ -186,7 +186,7 @@ def main():
     model.to(dev).train()
     loader = build_synthetic_multidataloader(cfg, dev, size=a.size, batch_size=a.batch, rank=rank, tasks=wl['tasks'],
                                              max_gt=wl['max_gt'])
-    runner = build_runner(model, cfg, loader)
+    runner = build_runner(model, cfg, loader, logger=lambda m: print(m, file=sys.stderr, flush=True))  # (stdout carries ONE JSON line)
 
     hold = dict(cycles=0)  # > 0: park the stream this many spin cycles before every iteration (roofline rounds)
     marks = []  # timed region only: (task, HIP event recorded after the iteration) -> per-task step times

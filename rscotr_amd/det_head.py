@@ -14,6 +14,7 @@ names.  Differences that do not change results:
     (mmdet_detr_head/detr_head.py:379-381,389-390; dino_head.py:266-268,282-283).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -189,6 +190,9 @@ def _round_up(x, m):
     return (max(int(x), 1) + m - 1) // m * m
 
 
+_DEBUG_GT = os.environ.get('RSCOTR_DEBUG_GT') == '1'
+
+
 class DetStatic:
     """Everything of a det batch whose SHAPE follows the ground-truth count in the reference
     (query_denoising.py:55-201 pads to 2*groups*max_gt queries; detr_head.py:475-543 matches (Q, G_i)
@@ -207,7 +211,7 @@ class DetStatic:
     KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
             'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales')
 
-    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None):
+    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None, gt_host=None):
         gen = head.dn_generator
         B = len(gt_bboxes)
         Q = head.num_query
@@ -278,12 +282,24 @@ class DetStatic:
                 rows.append([rc * f32(w3[0]), rp * f32(w3[1]), rp * f32(w3[2])])
             host['scales'] = np.asarray(rows, dtype=np.float32)
             host['norms_r'] = norms.copy()  # (every reduce_mean of the det losses is the identity on one rank)
-        # ground truth, padded with a harmless dummy box.  When the loader left host copies on the gt tensors (`.host`:
-        # rscotr_amd.synth / rscotr_amd.pipeline build them on the host anyway) the padded tensors are laid out on the host
-        # too and EVERYTHING of this batch is one pinned block -> one upload (and one copy into a captured iteration's static
-        # block) instead of ~45 small launches per det iteration
-        hb = [getattr(x, 'host', None) for x in gt_bboxes]
-        hl = [getattr(x, 'host', None) for x in gt_labels]
+        # ground truth, padded with a harmless dummy box.  When the caller hands over host copies of the ground truth
+        # (`gt_host` = (boxes, labels) as lists of NumPy arrays: batch['gt_bboxes_host'] / ['gt_labels_host'] of
+        # rscotr_amd.synth / rscotr_amd.pipeline, which build them on the host anyway) the padded tensors are laid out on the
+        # host too and EVERYTHING of this batch is one pinned block -> one upload (and one copy into a captured iteration's
+        # static block) instead of ~45 small launches per det iteration.  The host copies must describe the device tensors:
+        # counts and shapes are checked here, the values too under RSCOTR_DEBUG_GT=1 (a device read-back per image)
+        hb = hl = [None]
+        if gt_host is not None:
+            hb, hl = [np.asarray(x) for x in gt_host[0]], [np.asarray(x) for x in gt_host[1]]
+            assert len(hb) == len(hl) == B, ('host ground truth of another batch', len(hb), len(hl), B)
+            for b in range(B):
+                assert hb[b].reshape(-1, 4).shape[0] == counts[b] == hl[b].reshape(-1).shape[0] and \
+                    tuple(gt_bboxes[b].shape) == (counts[b], 4), \
+                    f'image {b}: host ground truth ({hb[b].shape}, {hl[b].shape}) does not describe the device tensors ' \
+                    f'({tuple(gt_bboxes[b].shape)}, {tuple(gt_labels[b].shape)})'
+                if _DEBUG_GT:
+                    assert np.array_equal(hb[b].reshape(-1, 4).astype(np.float32), gt_bboxes[b].detach().cpu().numpy()) and \
+                        np.array_equal(hl[b].reshape(-1), gt_labels[b].detach().cpu().numpy()), f'image {b}: host / device GT differ'
         self.blob = self.host_blob = None
         if all(x is not None for x in hb + hl):
             gt_box = np.zeros((B, G, 4), dtype=np.float32)
@@ -715,11 +731,11 @@ class DINOHead(nn.Module):
         return d
 
     def forward_train(self, mlvl_feats, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
-                      shared_encoder=None, proposal_cfg=None, rnd=None, record=None, static=None, **kwargs):
+                      shared_encoder=None, proposal_cfg=None, rnd=None, record=None, static=None, gt_host=None, **kwargs):
         assert proposal_cfg is None, '"proposal_cfg" must be None'
         assert self.dn_generator is not None, '"dn_cfg" must be set'
         if static is None and self.static_path and max([int(l.shape[0]) for l in gt_labels] + [0]) <= min(self.num_query, 256):
-            static = DetStatic(self, gt_bboxes, gt_labels, img_metas, mlvl_feats[0].device)
+            static = DetStatic(self, gt_bboxes, gt_labels, img_metas, mlvl_feats[0].device, gt_host=gt_host)
         if static is not None:
             return self.forward_train_static(mlvl_feats, img_metas, static, shared_encoder, rnd=rnd, record=record)
         dn_label_query, dn_bbox_query, attn_mask, dn_meta = self.dn_generator(

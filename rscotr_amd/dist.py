@@ -49,6 +49,7 @@ class GradSync:
         self._bucket_of = None
         self.fires = {}       # task -> {param index: gradient-ready notifications per step}
         self._order, self._next, self._warned = [], 0, False
+        self._at_end = False
         optimizer.ready_callbacks.append(self._on_ready)
         # Overlap needs the gradients to LAND while backward is still running, but the direct-write path defers them
         # (split-K combines, LayerNorm folds and the grouped weight gradients wait for ops.flush_deferred()).  The
@@ -170,6 +171,14 @@ class GradSync:
                     self._bucket_of[i] = b
             self._order, self._next = list(reversed(plan)), 0
 
+    def reset_step(self):
+        """Forget a step that was begun and never finished (a failed graph capture): no armed hooks, no pending handles."""
+        self.handles = []
+        self.fired = self.vfired = None
+        self._bucket_of = self._vpending = None
+        self._order, self._next = [], 0
+        self._at_end = False
+
     def finish_step(self, task):
         """Call after backward, before the optimizer step: waits for the exchange."""
         if self.fired is not None:  # discovery step: plan from what fired, reduce everything now
@@ -180,7 +189,7 @@ class GradSync:
             self._check_plan(task)
             for b in reversed(self.plans[task]):
                 self._launch(b)
-        elif getattr(self, '_at_end', False):
+        elif self._at_end:
             self._at_end = False
             while self._next < len(self._order):
                 self._launch(self._order[self._next])

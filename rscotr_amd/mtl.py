@@ -123,32 +123,7 @@ class MTL(nn.Module):
                 if isinstance(attn, MultiScaleDeformableAttention):
                     attn.init_weights()
 
-    # ---- hipGraph'd trunk for the eager (det) iteration ---------------------------------------------
-    class _Trunk(nn.Module):
-        """backbone + neck as a tensors-in / tensors-out callable for torch.cuda.make_graphed_callables."""
-
-        def __init__(self, backbone, neck):
-            super().__init__()
-            self.backbone, self.neck = backbone, neck
-
-        def forward(self, img, drop_keep):
-            return tuple(self.neck(self.backbone(img, drop_keep)[-3:]))
-
-    def enable_graphed_trunk(self, img, drop_keep):
-        """Capture backbone + neck (forward graph and backward graph, static shapes) for inputs shaped
-        like `img`; later extract_feat calls with that shape replay them.  The det iteration as a whole
-        cannot be captured (its shapes follow the ground-truth count and the Hungarian matching runs on
-        the host), but its trunk — about half of its ~3k kernel launches — can."""
-        trunk = MTL._Trunk(self.backbone, self.neck)
-        fn = torch.cuda.make_graphed_callables(trunk, (img.detach().clone(), drop_keep.detach().clone()),
-                                               allow_unused_input=True)
-        self._trunk_graph = (tuple(img.shape), fn)
-
-    def extract_feat(self, img, drop_keep=None, with_neck=True, graphed=False):
-        tg = getattr(self, '_trunk_graph', None) if graphed else None
-        if tg is not None and with_neck and drop_keep is not None and self.training and tuple(img.shape) == tg[0] \
-                and torch.is_grad_enabled():
-            return list(tg[1](img, drop_keep)), None
+    def extract_feat(self, img, drop_keep=None, with_neck=True):
         backbone_feature = self.backbone(img, drop_keep)
         neck_feature = self.neck(backbone_feature[-3:]) if with_neck else None
         return neck_feature, backbone_feature
@@ -190,15 +165,17 @@ class MTL(nn.Module):
         return losses
 
     def forward_train_det(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, rnd=None, record=None,
-                          static=None):
+                          static=None, gt_bboxes_host=None, gt_labels_host=None):
         batch_input_shape = tuple(img[0].size()[-2:])
         for img_meta in img_metas:
             img_meta['batch_input_shape'] = batch_input_shape
-        x, bf = self.extract_feat(img, self._drop_keep(img.shape[0], img.device, rnd), graphed=record is None)
+        x, bf = self.extract_feat(img, self._drop_keep(img.shape[0], img.device, rnd))
         if record is not None:
             record['backbone_feats'], record['neck_feats'] = bf, x
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, self.shared_encoder,
-                                            rnd=None if rnd is None else rnd.get('cdn'), record=record, static=static)
+                                            rnd=None if rnd is None else rnd.get('cdn'), record=record, static=static,
+                                            gt_host=None if gt_bboxes_host is None or gt_labels_host is None
+                                            else (gt_bboxes_host, gt_labels_host))
 
     def forward_train_seg(self, img, img_metas, gt_semantic_seg, rnd=None, record=None):
         neck_feature, backbone_feature = self.extract_feat(img, self._drop_keep(img.shape[0], img.device, rnd))

@@ -15,23 +15,38 @@ from .state import STATE
 # (order-dependent).  Tests run all three.
 # STATE.msda_bwd selects (RSCOTR_MSDA_BWD).
 
-# host copies of the level-shape tensors (the mmcv contract keeps spatial_shapes on the device; the tile-accumulation
-# backward sizes its launches from the shapes): data_ptr -> int64 numpy array, registered by whoever builds the device
-# tensor (layers.LevelGeometry); an unregistered tensor is read back once (a device sync, eager callers only)
-_MSDA_HOST_SHAPES = {}
+# Host copies of the level-shape tensors.  The mmcv contract keeps spatial_shapes on the device; the tile-accumulation
+# backward sizes its launches from the shapes, so whoever builds the device tensor registers its host twin
+# (layers.LevelGeometry, which also keeps the tensor alive).  An entry is trusted only while the registered tensor object is
+# ALIVE (its address cannot have been handed to another tensor) and UNMODIFIED (same autograd version counter: an in-place
+# edit bumps it); anything else — an unregistered tensor, a dead owner whose address the caching allocator reused, an edited
+# one — is read back from the device on every call (a sync: eager callers only; inside a hipGraph capture it is an error).
+_MSDA_HOST_SHAPES = {}  # data_ptr -> (weakref to the registered tensor, its version, int64 (L, 2) array)
 
 
 def msda_register_shapes(spatial_shapes, shapes):
+    import weakref
     import numpy as np
-    _MSDA_HOST_SHAPES[spatial_shapes.data_ptr()] = np.ascontiguousarray(np.asarray(shapes, dtype=np.int64).reshape(-1, 2))
+    _MSDA_HOST_SHAPES[spatial_shapes.data_ptr()] = (
+        weakref.ref(spatial_shapes), spatial_shapes._version,
+        np.ascontiguousarray(np.asarray(shapes, dtype=np.int64).reshape(-1, 2)))
+    if len(_MSDA_HOST_SHAPES) > 256:  # (dead owners: forget them)
+        for k in [k for k, e in _MSDA_HOST_SHAPES.items() if e[0]() is None]:
+            del _MSDA_HOST_SHAPES[k]
 
 
 def _msda_host_shapes(spatial_shapes):
-    a = _MSDA_HOST_SHAPES.get(spatial_shapes.data_ptr())
-    if a is None:
-        msda_register_shapes(spatial_shapes, spatial_shapes.detach().cpu().numpy())
-        a = _MSDA_HOST_SHAPES[spatial_shapes.data_ptr()]
-    return a
+    e = _MSDA_HOST_SHAPES.get(spatial_shapes.data_ptr())
+    if e is not None:
+        owner = e[0]()
+        if (owner is not None and owner._version == e[1] and spatial_shapes._version == e[1]
+                and owner.shape == spatial_shapes.shape):
+            return e[2]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('rscotr_msda_bwd (tiled): the level shapes of this spatial_shapes tensor are not known on the host; '
+                           'register them (ops.msda_register_shapes) before the iteration is captured')
+    import numpy as np
+    return np.ascontiguousarray(spatial_shapes.detach().cpu().numpy().astype(np.int64).reshape(-1, 2))
 
 
 def _msda_fwd_raw(value, spatial_shapes, level_start_index, loc, attn):

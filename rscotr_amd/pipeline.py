@@ -119,7 +119,7 @@ class DeviceCollate:
         if self.task == 'cls':
             batch['gt_label'] = torch.tensor([int(s['gt_label']) for s in samples], dtype=torch.int64, device=self.device)
         elif self.task == 'det':
-            boxes, labels = [], []
+            boxes, labels, hboxes, hlabels = [], [], [], []
             for s, w, f in zip(samples, wins, flips):
                 hb = np.asarray(s['gt_bboxes'], dtype=np.float32).reshape(-1, 4)
                 if f:  # mmdet RandomFlip.bbox_flip, horizontal (on the host: the boxes are a few dozen floats)
@@ -127,8 +127,10 @@ class DeviceCollate:
                 hl = np.asarray(s['gt_labels'], dtype=np.int64).reshape(-1)
                 boxes.append(torch.from_numpy(np.ascontiguousarray(hb)).to(self.device))
                 labels.append(torch.from_numpy(np.ascontiguousarray(hl)).to(self.device))
-                boxes[-1].host, labels[-1].host = hb, hl  # (host copies for the det head's packed batch layout)
+                hboxes.append(np.ascontiguousarray(hb))
+                hlabels.append(np.ascontiguousarray(hl))
             batch['gt_bboxes'], batch['gt_labels'] = boxes, labels
+            batch['gt_bboxes_host'], batch['gt_labels_host'] = hboxes, hlabels  # (for the det head's packed batch layout)
         else:
             lbuf, loffs = self._stage_bytes(segs)
             lmeta = meta.clone()

@@ -21,6 +21,38 @@ from .optim import StepLrUpdater, build_optimizer
 _HOST_TIMES = os.environ.get('RSCOTR_HOST_TIMES') == '1'
 
 
+def _gt_host(batch):
+    hb, hl = batch.get('gt_bboxes_host'), batch.get('gt_labels_host')
+    return None if hb is None or hl is None else (hb, hl)
+
+
+def _wait_watchdog_idle(limit=2.0):
+    """Block until the RCCL process group's watchdog has RETIRED every collective issued so far (call after a device
+    synchronise, before a stream goes into capture).  The watchdog polls the end events of its pending works, and HIP refuses
+    an event query ("operation not permitted on an event last recorded in a capturing stream") while the stream the event
+    was recorded on is capturing — which aborts the process from the watchdog thread.  The works are complete after the
+    synchronise, but the watchdog drops them only on its next pass; c10d's flight recorder marks an entry retired in that
+    same pass, so "no active entries" = "the watchdog holds no event of ours".  -> ('recorder', seconds waited).  Where the
+    recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0) or its dump is not readable this falls back to waiting three
+    watchdog periods (3 x 100 ms + margin) -> ('sleep', 0.35)."""
+    import pickle
+    dump = getattr(torch._C._distributed_c10d, '_dump_nccl_trace', None)
+    t0 = time.perf_counter()
+    try:
+        if dump is not None:
+            full = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False))
+            if full and full.get('entries'):  # the recorder is on: it has seen the warm-up iterations' collectives
+                while time.perf_counter() - t0 < limit:
+                    act = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+                    if not (act and act.get('entries')):
+                        return 'recorder', time.perf_counter() - t0
+                    time.sleep(0.01)
+    except Exception:  # noqa: BLE001 — a diagnostic API: any surprise means "use the fixed wait"
+        pass
+    time.sleep(0.35)
+    return 'sleep', 0.35
+
+
 class GraphedTask:
     """One task's whole iteration — forward, loss, zero_grad, backward, clip, AdamW — captured once
     into a hipGraph and replayed (the step is launch-bound: ~2-3k kernel launches per iteration).
@@ -38,7 +70,7 @@ class GraphedTask:
         self.runner, self.task = runner, task
         self.model, self.opt = runner.model, runner.optimizer
         self.static = {k: batch[k].clone() for k in self.TENSOR_KEYS if k in batch}
-        self.meta = {k: v for k, v in batch.items() if k not in self.static}
+        self.meta = {k: v for k, v in batch.items() if k not in self.static and not k.endswith('_host')}
         self.aug = None
         self.det_static = None
         if task == 'det':
@@ -53,7 +85,7 @@ class GraphedTask:
                 dist.all_reduce(need, op=dist.ReduceOp.MAX)
                 gcap = _round_up(max(int(need.item()), 32), 32)
             self.det_static = DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
-                                        batch['img'].device, gcap=gcap)
+                                        batch['img'].device, gcap=gcap, gt_host=_gt_host(batch))
             # pinned staging block of the later batches (DetStatic packs a batch into one block when the loader left host
             # copies of the ground truth: one upload per det iteration)
             self.det_pinned = None
@@ -76,23 +108,56 @@ class GraphedTask:
         # holds forward + backward only; buckets, log vector and optimizer are issued eagerly after each replay.
         self.exchange_in_graph = runner.sync is not None and os.environ.get('RSCOTR_DIST_CAPTURE', '1') != '0'
         self.split = runner.sync is not None and not self.exchange_in_graph
-        try:
-            self._warm_and_capture()
-        except Exception as e:  # noqa: BLE001 — any failure of the collective capture: fall back to the split form
-            if not self.exchange_in_graph:
-                raise
-            import warnings
-            warnings.warn(f'capturing the RCCL collectives of task {task!r} failed ({type(e).__name__}: {e}); '
-                          'falling back to graph(forward + backward) + eager exchange')
-            torch.cuda.synchronize()
-            self.exchange_in_graph, self.split = False, True
-            self._warm_and_capture()
-        self.graph.replay()  # capture only records: this replay is the iteration prepare_step() announced
-        self._finish()
+        self._capture_agreed()
+        self._replay()  # capture only records: this replay is the iteration prepare_step() announced
         self.done = torch.cuda.Event()
         self.done.record()
         self.warm_iters = 1  # iterations applied to the weights on this batch (the warm-ups were rolled back)
         self.first_out = self._output(batch)
+
+    def _capture_agreed(self):
+        """Warm up and capture; with more than one rank the FORM of the captured iteration is one decision of all ranks.
+        A capture of the RCCL collectives that fails on one rank only must not leave that rank re-running its warm-ups in
+        the split form (two more iterations of bucket and log all-reduces) while the others go straight to their replay:
+        the collective sequences would diverge and the job would hang.  Every rank therefore reports success (1) or the
+        failure (0) of its attempt, MIN over ranks decides, and on 0 EVERY rank — also those whose capture succeeded —
+        drops its graph, resets the exchange state and captures again in the split form.  Only errors of the capture
+        itself are caught (RuntimeError from HIP / RCCL / torch's graph machinery); anything else propagates."""
+        err = None
+        try:
+            self._warm_and_capture()
+        except RuntimeError as e:
+            if not self.exchange_in_graph:
+                raise
+            err = e
+        if not self.exchange_in_graph:
+            return
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.static['img'].device)
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return
+        import warnings
+        warnings.warn(f'capturing the RCCL collectives of task {self.task!r} failed on at least one rank'
+                      + (f' (here: {type(err).__name__}: {err})' if err is not None else ' (not here)')
+                      + '; every rank falls back to graph(forward + backward) + eager exchange')
+        torch.cuda.synchronize()
+        self.graph = None
+        self.runner.sync.reset_step()
+        ops.DEFER.drop()
+        self.exchange_in_graph, self.split = False, True
+        self._warm_and_capture()
+
+    def _replay(self):
+        self.graph.replay()
+        if not self.split:
+            # the replayed graph holds the optimizer step: the parameters have changed, and nothing on the host has said
+            # so (WPLANES.bump() in launch_step ran at capture time only).  Without this, a non-captured forward after
+            # replays — the evaluation hook, an eager det iteration whose batch exceeds the captured capacities — would find
+            # its weight planes "fresh" and multiply with weights at least one step old (ADVICE r2, high)
+            ops.WPLANES.bump()
+        self._finish()
 
     def _warm_and_capture(self):
         # warm-up (allocator, workspaces, lazy inits), then capture — both on the runner's stream, which is
@@ -111,11 +176,7 @@ class GraphedTask:
                 side.synchronize()  # the pinned optimizer table is refilled by the next prepare_step()
             torch.cuda.synchronize()
             if self.runner.sync is not None:
-                # Let the process group's watchdog retire every collective issued so far before a stream goes into
-                # capture: it polls the end events of its pending works every 100 ms, and HIP refuses an event query
-                # ("operation not permitted on an event last recorded in a capturing stream") when the stream the event
-                # was recorded on is capturing at that moment — which aborts the process from the watchdog thread.
-                time.sleep(0.35)
+                self.watchdog_wait = _wait_watchdog_idle()
             self.opt.restore(snap)
             self.graph = torch.cuda.CUDAGraph()
             self.opt.prepare_step(self.table)
@@ -209,7 +270,7 @@ class GraphedTask:
             from .det_head import DetStatic
             DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
                       batch['img'].device, gcap=self.det_static.gcap, padcap=self.det_static.padcap,
-                      pinned=self.det_pinned).update_into(self.det_static)
+                      pinned=self.det_pinned, gt_host=_gt_host(batch)).update_into(self.det_static)
         for k, t in self.static.items():
             t.copy_(batch[k], non_blocking=True)
         if self.aug is not None:
@@ -220,10 +281,9 @@ class GraphedTask:
         self.opt.prepare_step(self.table)
         if _HOST_TIMES:
             t0 = time.perf_counter()
-        self.graph.replay()
-        if _HOST_TIMES:  # (diagnostic: host time of the graph launch alone)
+        self._replay()
+        if _HOST_TIMES:  # (diagnostic: host time of the graph launch (+ the split form's eager tail))
             print(f'[runner] {self.task}: graph launch {1e3 * (time.perf_counter() - t0):.2f} ms on the host', flush=True)
-        self._finish()
         self.done = torch.cuda.Event()
         self.done.record()
         return self._output(batch)
@@ -244,6 +304,14 @@ class IterBasedRunner:
             # precedes every bucket); overlapped exchange: 32 MB so that the first buckets leave early in backward
             bucket_mb = float(os.environ.get('RSCOTR_BUCKET_MB', 128.0 if INLINE else 32.0))
         self.sync = GradSync(optimizer, bucket_mb) if is_dist() else None
+        # host-side control group (gloo): batch-dependent decisions that every rank must take alike (replay the det graph or
+        # run this batch eagerly) are agreed on WITHOUT touching the device queue — the data they depend on (ground-truth
+        # counts, image shapes) is on the host already
+        self.ctrl = None
+        if self.sync is not None:
+            import torch.distributed as dist
+            if dist.get_world_size() > 1:
+                self.ctrl = dist.new_group(backend='gloo')
         self.rnd_fn = rnd_fn
         # tasks whose iteration is replayed from a hipGraph (RSCOTR_GRAPHS=0 disables)
         if graph_tasks is None:
@@ -264,6 +332,7 @@ class IterBasedRunner:
         # hook surface of mmcv's runner that rscotr_amd.engine.MultiDatasetsEvalHook uses
         self.hooks, self.epoch, self.meta, self.work_dir = [], 0, {}, None
         self.log_buffer_output, self.log_buffer_ready = OrderedDict(), False
+        self.outputs, self.max_iters, self.timestamp = None, None, None
 
     def register_hook(self, hook):
         self.hooks.append(hook)
@@ -281,6 +350,7 @@ class IterBasedRunner:
             with torch.cuda.stream(self.stream):
                 out = self._train_iter()
             torch.cuda.current_stream().wait_stream(self.stream)
+        self.outputs = out
         for h in self.hooks:
             if hasattr(h, 'after_train_iter'):
                 h.after_train_iter(self)
@@ -306,22 +376,16 @@ class IterBasedRunner:
                 out, g.first_out = g.first_out, None
                 self.log_buffer = out['log_vars']
                 return out
-            if g is not None and g.accepts(batch):
+            g = self._graph_for(task, batch)
+            if g is not None:
                 out = g.run(batch)
                 self.iter += 1
                 self.log_buffer = out['log_vars']
                 return out
-        if task == 'det' and 'det_trunk' in self.graph_tasks and batch['img'].is_cuda:
-            self._seen[task] = self._seen.get(task, 0) + 1
-            if self._seen[task] == 2 and getattr(self.model, '_trunk_graph', None) is None:
-                keep = self.model._drop_keep(batch['img'].shape[0], batch['img'].device, None)
-                if keep is not None:
-                    self.model.enable_graphed_trunk(batch['img'], keep)
-        # Distributed: every path of a task must issue the SAME collective sequence on every rank, whichever path each rank
-        # takes for this batch (a rank whose det batch exceeds the captured capacities runs eagerly while the others replay
-        # their graph): [det: normalisers, in forward] -> gradient buckets in arena order after backward -> packed log
-        # vector (n floats).  Tasks that are never graphed keep the overlapped exchange (buckets launched from backward
-        # hooks, back to front) — there all ranks run eagerly, always.
+        # Distributed: the ranks take the same path for every batch (_graph_for agrees on it), and the eager path of a graphed
+        # task issues the collective sequence of its graph anyway: [det: normalisers, in forward] -> gradient buckets in
+        # arena order after backward -> packed log vector (n floats).  Tasks that are never graphed keep the overlapped
+        # exchange (buckets launched from backward hooks, back to front).
         graphed_task = self.sync is not None and task in self.graph_tasks and not self.force_eager
         if self.sync is not None:
             self.model.defer_log_allreduce = True  # the packed log vector is exchanged here, after the buckets
@@ -348,6 +412,28 @@ class IterBasedRunner:
                                                        if k.endswith('.loss')))
         return out
 
+    def _agree(self, ok):
+        """MIN over ranks of a local yes / no (one tiny gloo all-reduce on the host; identity in a single process)."""
+        if self.ctrl is None:
+            return bool(ok)
+        import torch.distributed as dist
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.ctrl)
+        return bool(int(t[0]))
+
+    def _graph_for(self, task, batch):
+        """-> the GraphedTask that replays this batch, or None (run it eagerly): the SAME answer on every rank.  Only the det
+        graph's answer depends on the batch (it must fit the captured ground-truth / denoising capacities); a rank whose
+        batch does not fit pulls every rank to the eager path for this iteration, so graph and eager iterations never meet
+        in one collective sequence."""
+        g = self.graphed.get(task)
+        if g is None:
+            return None
+        ok = g.accepts(batch)
+        if g.det_static is not None:
+            ok = self._agree(ok)
+        return g if ok else None
+
     @contextlib.contextmanager
     def on_stream(self):
         """Make the runner's stream the current stream for a whole loop.  A train_iter() called from another stream hands
@@ -365,12 +451,87 @@ class IterBasedRunner:
         finally:
             outer.wait_stream(self.stream)
 
-    def run(self, max_iters):
+    def run(self, max_iters=None):
+        """Train until `max_iters` iterations are done (default: the `runner.max_iters` of the config)."""
+        if max_iters is None:
+            max_iters = self.max_iters
+        assert max_iters is not None, 'no iteration count: pass max_iters or build the runner from a config with `runner`'
+        if self.max_iters is None:
+            self.max_iters = max_iters
         with self.on_stream():
             while self.iter < max_iters:
                 self.train_iter()
+        for h in self.hooks:
+            if hasattr(h, 'after_run'):
+                h.after_run(self)
+
+    # ---- mmcv BaseRunner.load_checkpoint / resume (mtl/apis/train.py:115-118) --------------------------------------
+    def load_checkpoint(self, path, map_location='cpu', strict=False):
+        from .checkpoint import load_checkpoint
+        self.logger(f'load checkpoint from {path}')
+        return load_checkpoint(self.model, path, strict=strict, map_location=map_location)[0]
+
+    def resume(self, path, map_location='cpu'):
+        from .checkpoint import resume
+        ckpt = resume(self, path, map_location=map_location)
+        self.epoch = int(ckpt.get('meta', {}).get('epoch', 0))
+        if 'hook_msgs' in ckpt.get('meta', {}):
+            self.meta = dict(self.meta or {}, hook_msgs=ckpt['meta']['hook_msgs'])
+        # graphs captured before the resume replay the OLD step counts' bias corrections only through the per-iteration
+        # table (prepare_step), so they stay valid; the captured det capacities do too
+        self.logger(f'resumed from {path}: iter {self.iter}')
+        return ckpt
 
 
-def build_runner(model, cfg, data_loader, **kwargs):
-    optimizer = build_optimizer(model, cfg['optimizer'], cfg.get('optimizer_config'))
-    return IterBasedRunner(model, optimizer, data_loader, lr_config=cfg.get('lr_config'), **kwargs)
+def build_runner(model, cfg, data_loader, val_dataloaders=None, validate=None, work_dir=None, meta=None, timestamp=None,
+                 **kwargs):
+    """What `mtl/apis/train.py:24-118::train_model` does between building the model and `runner.run`: optimizer
+    (`build_optimizer(model, cfg.optimizer)`), runner (`cfg.runner`), `register_training_hooks(lr_config, optimizer_config,
+    checkpoint_config, log_config)` (:77-83), the evaluation hook from `cfg.evaluation` when validating (:89-107), then
+    `auto_resume` / `resume_from` / `load_from` (:109-118).  `val_dataloaders`: {dataset name: loader} for the evaluation
+    hook (`validate` defaults to "loaders were given"); `work_dir` defaults to `cfg.work_dir`.  LR schedule and optimizer
+    hook are built into the runner (`lr_config`, `optimizer_config`); checkpoint / logger hooks come from
+    rscotr_amd.hooks under the reference's type strings."""
+    from .hooks import CheckpointHook, build_hook, find_latest_checkpoint
+    get = cfg.get if hasattr(cfg, 'get') else (lambda k, d=None: getattr(cfg, k, d))
+    optimizer = build_optimizer(model, cfg['optimizer'], get('optimizer_config'))
+    log_cfg = dict(get('log_config') or {})
+    runner = IterBasedRunner(model, optimizer, data_loader, lr_config=get('lr_config'), **kwargs)
+    rcfg = dict(get('runner') or {})
+    if rcfg.get('type', 'IterBasedRunner') != 'IterBasedRunner':
+        raise NotImplementedError(f"runner type {rcfg.get('type')!r}: the MTL configs train with IterBasedRunner")
+    runner.max_iters = rcfg.get('max_iters')
+    runner.work_dir = work_dir if work_dir is not None else get('work_dir')
+    runner.meta = dict(meta or {})
+    runner.timestamp = timestamp
+    # register_training_hooks: checkpoint (priority NORMAL), then the logger hooks (VERY_LOW); the evaluation hook (LOW)
+    # runs between them in mmcv's priority order — after the checkpoint hook, before the loggers, which then report its
+    # metrics in the same iteration
+    ck = get('checkpoint_config')
+    if ck is not None:
+        ck = dict(ck)
+        ck.setdefault('by_epoch', False)  # mmcv IterBasedRunner.register_training_hooks
+        runner.register_hook(CheckpointHook(**{k: v for k, v in ck.items() if k != 'type'}))
+    validate = (val_dataloaders is not None) if validate is None else validate
+    if validate:
+        if val_dataloaders is None:
+            raise ValueError('validate=True needs val_dataloaders ({dataset name: loader})')
+        from .engine import MultiDatasetsEvalHook
+        eval_cfg = dict(get('evaluation') or {})
+        eval_cfg['by_epoch'] = False  # `eval_cfg['by_epoch'] = cfg.runner['type'] != 'IterBasedRunner'` (:97)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError('distributed validation (mtl/apis/train.py:98-99 raises the same)')
+        runner.register_hook(MultiDatasetsEvalHook(val_dataloaders, **eval_cfg))
+    interval = log_cfg.get('interval', 10)
+    for h in log_cfg.get('hooks', [dict(type='TextLoggerHook')] if log_cfg else []):
+        runner.register_hook(build_hook(h, interval=interval, by_epoch=False))
+    # resume / load (train.py:109-118)
+    resume_from = get('resume_from')
+    if resume_from is None and get('auto_resume'):
+        resume_from = find_latest_checkpoint(runner.work_dir)
+    if resume_from:
+        runner.resume(resume_from)
+    elif get('load_from'):
+        runner.load_checkpoint(get('load_from'))
+    return runner

@@ -19,7 +19,7 @@ def make_batch(task, batch_size=2, size=512, seed=0, device='cpu', num_cls=45, n
     if task == 'cls':
         batch['gt_label'] = torch.from_numpy(rs.randint(0, num_cls, batch_size)).long().to(device)
     elif task == 'det':
-        boxes, labels = [], []
+        boxes, labels, hboxes, hlabels = [], [], [], []
         for _ in range(batch_size):
             G = int(rs.randint(1, max_gt + 1))
             cxy = rs.uniform(0.1, 0.9, (G, 2)) * size
@@ -28,9 +28,12 @@ def make_batch(task, batch_size=2, size=512, seed=0, device='cpu', num_cls=45, n
             lab = rs.randint(0, num_det, G).astype(np.int64)
             boxes.append(torch.from_numpy(b).to(device))
             labels.append(torch.from_numpy(lab).to(device))
-            # host copies ride on the tensors (the det head lays a batch out on the host when it finds them: DetStatic)
-            boxes[-1].host, labels[-1].host = b, lab
+            hboxes.append(b)
+            hlabels.append(lab)
         batch['gt_bboxes'], batch['gt_labels'] = boxes, labels
+        # host copies of the ground truth, explicitly in the batch (the det head lays a batch out on the host when it gets
+        # them: DetStatic checks them against the device tensors' shapes)
+        batch['gt_bboxes_host'], batch['gt_labels_host'] = hboxes, hlabels
     elif task == 'seg':
         blk = 32 if size >= 64 else 8
         coarse = rs.randint(0, num_seg, (batch_size, 1, (size + blk - 1) // blk, (size + blk - 1) // blk))

@@ -154,6 +154,31 @@ def _worker(rank, world, port, q):
         loss, logs = MTL._parse_losses(None, losses)
         assert abs(logs['loss_x'] - 1.5) < 1e-6 and abs(logs['acc'] - 15.0) < 1e-6 and abs(logs['loss'] - 1.5) < 1e-6
         assert float(loss) == float(rank + 1)  # the differentiable loss stays local
+        # The graph-or-eager decision of a det iteration is ONE decision of all ranks (runner._graph_for): rank 1's batch
+        # "exceeds the captured capacities" -> no rank replays its graph; both fit -> both replay.  The decision travels over
+        # the host-side control group, so the collective sequences of the two paths never meet.
+        from rscotr_amd.runner import IterBasedRunner
+        runner = IterBasedRunner(model, opt, data_loader=None, graph_tasks=())
+        assert runner.sync is not None and runner.ctrl is not None
+
+        class FakeGraph:
+            det_static = object()
+
+            def __init__(self, fits):
+                self.fits, self.asked = fits, 0
+
+            def accepts(self, batch):
+                self.asked += 1
+                return self.fits
+        for fits_here, want in (((rank == 0), False), (True, True), (False, False)):
+            runner.graphed['det'] = FakeGraph(fits_here)
+            got = runner._graph_for('det', {})
+            assert (got is not None) == want and runner.graphed['det'].asked == 1, (rank, fits_here, want)
+        shape_static = FakeGraph(rank == 0)
+        shape_static.det_static = None          # cls / seg graphs accept every batch of their shape: no exchange needed
+        runner.graphed['seg'] = shape_static
+        assert (runner._graph_for('seg', {}) is not None) == (rank == 0)
+        assert runner._graph_for('cls', {}) is None
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         import traceback
