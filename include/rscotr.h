@@ -123,8 +123,10 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * 0 = fp32 matrix pipe (v_mfma_f32_32x32x2_f32); 1 = "bf16x3": fp32 operands split into hi + lo bf16 halves while they are
  * staged, three v_mfma_f32_32x32x16_bf16 per k-step (lo*hi + hi*lo + hi*hi), fp32 accumulate -- error ~5e-6 of max|C|
  * against ~1e-6 for fp32 FMA, inside the 1e-3 gate of the path; 2 = bf16x3 only on the large row-major x row-major products
- * (128x128x32 tiles, gemm_bf16x3_big_kernel), fp32 pipe elsewhere.  Process-wide; start value 0, or from
- * RSCOTR_GEMM_PREC=fp32|bf16x3|bf16x3-big. */
+ * (128x128x32 tiles, gemm_bf16x3_big_kernel), fp32 pipe elsewhere; 3 = "bf16x6" (THE START VALUE): the large products as SIX
+ * bf16 MFMAs on three-plane splits (h + m + l carry all 24 significand bits) with fp32 accumulation -- 3e-7 of max|C|, the
+ * error class of an fp32 FMA chain (gemm_bf16x6_kernel; ragged M / N take its edge instantiations), fp32 pipe for the small
+ * ones.  Process-wide; start value 3, or from RSCOTR_GEMM_PREC=fp32|bf16x3|bf16x3-big|bf16x6. */
 /* The same product with PRE-SPLIT WEIGHTS.  In y = x W^T and dx = dy W of a Linear layer (torch F.linear behind mmcv's FFN,
  * MultiheadAttention, MultiScaleDeformableAttention, mmdet's WindowMSA / FFN) the B operand is a parameter that changes once
  * per optimizer step; rscotr_gemm_split_weights writes its three bf16 planes once (layout [K/16][npad][3][16], npad = rows
