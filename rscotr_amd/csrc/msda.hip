@@ -177,20 +177,18 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) {
 struct MsdaMaskGeom {
   float itx[8], ity[8];
   int ntx[8];
-  // owned-tile backward (TILE == 2): tokens per tile edge and tile counts; a bin belongs to the tile that owns its own
-  // cell AND to the left / upper neighbour when it sits on that tile's last bin column / row (the one-bin halo)
-  int tx[8], ty[8], nty[8];
 };
 
 // SCATTER: 0 = grad_loc / grad_attn only (grad_value comes from the pull kernel), 1 = also scatter grad_value with
 // atomics, 2 = scatter iff the level pyramid has more than `bins_cap` extended bins (the sorted path stood down).
-template <int D, int P, int SCATTER, int TILE = 0>
+// TILE: also leave what the tile-accumulation backward needs (see that section): one bin word per sample + the block masks.
+template <int D, int P, int SCATTER, bool TILE = false>
 __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attn, const float* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int4* __restrict__ rec, int* __restrict__ binw, unsigned long long* __restrict__ mask, MsdaMaskGeom MG, int Nk, int Nq,
+    int* __restrict__ binw, unsigned long long* __restrict__ mask, MsdaMaskGeom MG, int Nk, int Nq,
     int H, int L, int ntiles, int bins_cap) {
   constexpr int G = D / 4;
   constexpr int QW = kWave / G;
@@ -207,14 +205,11 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
   float* s_attn = smem + QB * LP * 2;        // [QB][LP]    in: weights
   float* s_gattn = smem + QB * LP * 3;       // [QB][LP]    out: grad_attn
   float* s_gloc = smem + QB * LP * 4;        // [QB][LP*2]  out: grad_loc
-  // rec != nullptr (tile-accumulation backward): one record {bin of the top-left tap on the extended grid | -1, attention
-  // weight, lw, lh} per sample, laid out (b h, level, q, p); staged [L][QB][P] for a coalesced store (the launch then
-  // brings QB * LP * 16 more bytes of LDS)
-  // TILE == 2 (owned-tile backward): only the bin word per sample, staged the same way (QB * LP * 4 more bytes of LDS)
-  int4* s_rec = reinterpret_cast<int4*>(smem + QB * LP * 6);
+  // TILE (tile-accumulation backward): one 4-byte bin word per sample (bin of the top-left tap on the extended grid | -1),
+  // laid out (b h, level, q, p), staged [L][QB][P] for a coalesced store (the launch then brings QB * LP * 4 more bytes of LDS)
   int* s_bin = reinterpret_cast<int*>(smem + QB * LP * 6);
-  unsigned* s_mask = reinterpret_cast<unsigned*>(smem + QB * LP * (TILE == 2 ? 7 : 10));  // [L][2] (TILE != 0 only)
-  if (TILE != 0 && threadIdx.x < 2 * L) s_mask[threadIdx.x] = 0u;  // (ordered before the atomics by the barrier below)
+  unsigned* s_mask = reinterpret_cast<unsigned*>(smem + QB * LP * 7);  // [L][2] (TILE only)
+  if (TILE && threadIdx.x < 2 * L) s_mask[threadIdx.x] = 0u;  // (ordered before the atomics by the barrier below)
 
   const int bid = blockIdx.x;
   const int h = bid % H;
@@ -235,6 +230,22 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
     s_attn[i] = (q < Nq) ? attn[(((long)b * Nq + q) * H + h) * LP + c] : 0.f;
   }
   __syncthreads();
+
+  if (TILE) {
+    // bin word of every sample and the tile it falls in, in a pass of its own over the staged locations (two samples per
+    // thread): inside the gather loop below the same code (round 2: plus a 16-byte record per sample) pushed the kernel over
+    // the 128-register cap it runs under — 32 bytes of scratch per lane, +17 us per launch
+    for (int i = tid; i < QB * LP; i += 256) {
+      const int rr = i / LP, c = i - rr * LP, l = c / P, pp = c - l * P;
+      const Bilinear gg = bilinear_setup(s_loc[2 * i], s_loc[2 * i + 1], (int)shapes[2 * l], (int)shapes[2 * l + 1]);
+      const bool in = gg.in && q0 + rr < Nq;
+      s_bin[(l * QB + rr) * P + pp] = in ? ((gg.h_low + 1) << 16) | (gg.w_low + 1) : -1;
+      if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
+        const int t = (int)(((float)(gg.h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(gg.w_low + 1) + 0.5f) * MG.itx[l]);
+        atomicOr(&s_mask[2 * l + ((t >> 5) & 1)], 1u << (t & 31));
+      }
+    }
+  }
 
   const int lane = tid & 63, w = tid >> 6;
   const int r = w * QW + lane / G;
@@ -260,41 +271,12 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
     Bilinear g[P];
     float aw[P];
     float4 v1[P], v2[P], v3[P], v4[P];
-    unsigned mlo = 0u, mhi = 0u;  // tiles of this level this lane's samples fall in (rec != nullptr)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float2 xy = *reinterpret_cast<const float2*>(my_loc + (l * P + p) * 2);
       aw[p] = my_attn[l * P + p];
       g[p] = bilinear_setup(xy.x, xy.y, Hl, Wl);
       if (!qok) g[p].in = g[p].ok1 = g[p].ok2 = g[p].ok3 = g[p].ok4 = false;
-      if (TILE == 1 && sub == 0) {  // (here, before the gathers: the top-left tap need not stay in registers)
-        const bool in = g[p].in;
-        s_rec[(l * QB + r) * P + p] = make_int4(in ? ((g[p].h_low + 1) << 16) | (g[p].w_low + 1) : -1, __float_as_int(aw[p]),
-                                                __float_as_int(g[p].lw), __float_as_int(g[p].lh));
-        if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
-          const int t = (int)(((float)(g[p].h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(g[p].w_low + 1) + 0.5f) * MG.itx[l]);
-          if (t & 32) mhi |= 1u << (t & 31); else mlo |= 1u << (t & 31);
-        }
-      }
-      if (TILE == 2 && sub == 0) {
-        const bool in = g[p].in;
-        const int bx = g[p].w_low + 1, by = g[p].h_low + 1;
-        s_bin[(l * QB + r) * P + p] = in ? (by << 16) | bx : -1;
-        if (in) {
-          const int ntx = MG.ntx[l], nty = MG.nty[l];
-          const int ix = (int)(((float)bx + 0.5f) * MG.itx[l]), iy = (int)(((float)by + 0.5f) * MG.ity[l]);
-          const bool xl = ix > 0 && bx == ix * MG.tx[l], yu = iy > 0 && by == iy * MG.ty[l];  // on the neighbour's halo bins
-          const bool xo = ix < ntx, yo = iy < nty;
-          auto mark = [&](int tyy, int txx) {
-            const int t = tyy * ntx + txx;
-            if (t & 32) mhi |= 1u << (t & 31); else mlo |= 1u << (t & 31);
-          };
-          if (xo && yo) mark(iy, ix);
-          if (xl && yo) mark(iy, ix - 1);
-          if (xo && yu) mark(iy - 1, ix);
-          if (xl && yu) mark(iy - 1, ix - 1);
-        }
-      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -331,17 +313,6 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
         s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
       }
     }
-    if (TILE != 0) {  // the wavefront's tiles of this level: one LDS atomic per word and wavefront
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        mlo |= (unsigned)__shfl_xor((int)mlo, o, 64);
-        mhi |= (unsigned)__shfl_xor((int)mhi, o, 64);
-      }
-      if (lane == 0) {
-        if (mlo) atomicOr(&s_mask[2 * l], mlo);
-        if (mhi) atomicOr(&s_mask[2 * l + 1], mhi);
-      }
-    }
   }
   __syncthreads();
   for (int i = tid; i < QB * LP * 2; i += 256) {
@@ -354,14 +325,11 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
     const int qq = q0 + rr;
     if (qq < Nq) grad_attn[(((long)b * Nq + qq) * H + h) * LP + c] = s_gattn[i];
   }
-  if (TILE != 0) {
+  if (TILE) {
     const long SP = (long)Nq * P;
     for (int i = tid; i < L * QB * P; i += 256) {
       const int l = i / (QB * P), rem = i - l * (QB * P);
-      if (q0 + rem / P < Nq) {
-        if (TILE == 1) rec[((long)(b * H + h) * L + l) * SP + (long)q0 * P + rem] = s_rec[i];
-        binw[((long)(b * H + h) * L + l) * ((SP + 3) & ~3L) + (long)q0 * P + rem] = TILE == 1 ? s_rec[i].x : s_bin[i];  // (the scan reads these only)
-      }
+      if (q0 + rem / P < Nq) binw[((long)(b * H + h) * L + l) * ((SP + 3) & ~3L) + (long)q0 * P + rem] = s_bin[i];
     }
     if (tid < L) mask[((long)(b * H + h) * L + tid) * ntiles + tile] = (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
   }
@@ -804,9 +772,10 @@ __global__ __launch_bounds__(256) void msda_chunk_combine_kernel(const int64_t* 
 // level; its four taps land on the cells (bin, bin + 1 right, bin + 1 down, both).  The bins of a level are cut into tiles of
 // at most 16 x 16 bins (17 x 17 cells with the one-cell halo to the right / bottom), and the samples of a level — in sample
 // order — into `nch` chunks; one 256-thread workgroup per (b, h, level, tile, chunk):
-//   0. the sample kernel (msda_bwd_kernel, which has every bilinear set-up in registers anyway) leaves one 16-byte record
-//      {bin | -1, attention weight, lw, lh} per sample, laid out (b h, level, q, p);
-//   1. SCAN: the workgroup reads the records of its chunk (coalesced, L2-resident: all workgroups of a (b, h) run on one
+//   0. the sample kernel (msda_bwd_kernel<.., TILE = true>) leaves one 4-byte bin word {bin | -1} per sample, laid out
+//      (b h, level, q, p), and one 64-bit tile mask per block of its queries and level (a pass of its own over the staged
+//      locations);
+//   1. SCAN: the workgroup reads the bin words of its chunk (coalesced, L2-resident: all workgroups of a (b, h) run on one
 //      XCD) and keeps those whose bin lies in its tile — ballot compaction, so the kept list is in sample order.  No sort of
 //      the whole sample set: filtering 16 x redundantly costs less than the counting sort did (5 launches, ~110 us);
 //   2. every MSDA_T_CAP kept records (and at the end): stable counting sort of the list by bin inside LDS (one wavefront
@@ -871,14 +840,13 @@ static bool msda_tiles_build(MsdaTiles* T, const int64_t* shapes_host, int L, in
 }
 
 struct MsdaTileWs {
-  long rec, binw, mask, part, total;  // byte offsets
+  long binw, mask, part, total;  // byte offsets
 };
 
 static MsdaTileWs msda_tile_ws(const MsdaTiles& T, int BH, int Nq, int P, int D) {
   MsdaTileWs w;
   const long SP = (long)Nq * P;
   long o = 0;
-  w.rec = o; o += (long)BH * T.L * SP * 16;
   w.binw = o; o += (long)BH * T.L * ((SP + 3) & ~3L) * 4;  // (rows padded to whole 16-byte loads)
   const int QB = 4 * (kWave / (D / 4));  // queries per workgroup of the sample kernel
   const long nqt = (Nq + QB - 1) / QB;
@@ -927,11 +895,13 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int
 // rows of ITS bin (its CH channels) in registers for the whole life of the workgroup: the walk over the sorted list needs
 // no barrier and no LDS accumulator — a thread reads the records of its bin in order, gathers each sample's grad_out row
 // (its part) once and feeds the four accumulators; the rows meet in the tile's cells only at the very end.
-template <int D>
-__global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const float* __restrict__ go, const int4* __restrict__ rec,
+template <int D, int P>
+__global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const float* __restrict__ go, const float* __restrict__ loc,
+                                                        const float* __restrict__ attn,
                                                         const int* __restrict__ binw, const unsigned long long* __restrict__ mask,
-                                                        float* __restrict__ part, MsdaTiles T, int Nq, int pshift, int bshift,
+                                                        float* __restrict__ part, MsdaTiles T, int Nq, int bshift,
                                                         int nqt, int H, int BH) {
+  constexpr int pshift = P == 1 ? 0 : P == 2 ? 1 : P == 4 ? 2 : 3;
   using Gm = MsdaTileGeom<D>;
   constexpr int TB = Gm::TB, CH = Gm::CH, V = Gm::V, U = Gm::U, NBIN = Gm::NBIN, NCELL = Gm::NCELL;
   constexpr int R = 4;  // consecutive records per thread and scan round (one 16-byte load of bin words)
@@ -963,7 +933,6 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   // chunk bounds on whole blocks of the sample kernel (BS = 1 << bshift records, >= 16: 16-byte loads of bin words)
   const int BS = 1 << bshift;
   const int c0 = (int)((long)SP * chunk / nch) & ~(BS - 1), c1 = chunk + 1 == nch ? SP : (int)((long)SP * (chunk + 1) / nch) & ~(BS - 1);
-  const int4* src = rec + ((long)bh * T.L + l) * SP;
   const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
 
   // this thread's bin, channel part, and — tiles with few bins (the coarse levels, whose bins hold long runs) — its share of
@@ -976,6 +945,14 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   const int bin = (bidx / tsx) * MSDA_T_TS + bidx % tsx;
   const float* gob = go + ((long)b * Nq * H + h) * D + sub * CH;  // + q * H * D
   const int qstride = H * D;
+  // the walk re-derives a sample's tap weights from its sampling location and attention weight (12 algorithmic bytes per
+  // sample, L2-resident) with the sample kernel's arithmetic, hence the same floats — round 2 read a 16-byte record per
+  // sample that the sample kernel had written: 45 MB of HBM traffic per launch at the encoder shape of configs[1]
+  const int Hl = T.Hl[l], Wl = T.Wl[l];
+  const int LP = T.L << pshift;
+  const float* locb = loc + (((long)b * Nq * H + h) * T.L + l) * (2 << pshift);   // + q * H * LP * 2 + p * 2
+  const float* attb = attn + (((long)b * Nq * H + h) * T.L + l) * (1 << pshift);  // + q * H * LP + p
+  const long lstride = (long)H * LP * 2, astride = (long)H * LP;
   typedef float v2f __attribute__((ext_vector_type(2)));  // (pairs: v_pk_fma_f32 does two channels per instruction)
   v2f a1[2 * V], a2[2 * V], a3[2 * V], a4[2 * V];  // the bin's four tap rows (this thread's channels)
 #pragma unroll
@@ -1012,20 +989,25 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
     }
 #pragma unroll 1
     for (int i = s0; i < s1; i += U) {  // U samples in flight per thread, applied in list (= sample) order
-      int4 rr[U];
+      float2 xy[U];
+      float aws[U];
       float4 g[U][V];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int sidx = lrec[order[min(i + u, s1 - 1)]] >> 8;
-        rr[u] = src[sidx];  // (re-read: L2-hot, the sample kernel has just written it)
-        const float4* row = reinterpret_cast<const float4*>(gob + (long)(sidx >> pshift) * qstride);
+        const int q = sidx >> pshift, pp = sidx & (P - 1);
+        xy[u] = *reinterpret_cast<const float2*>(locb + q * lstride + pp * 2);
+        aws[u] = attb[q * astride + pp];
+        const float4* row = reinterpret_cast<const float4*>(gob + (long)q * qstride);
 #pragma unroll
         for (int v = 0; v < V; ++v) g[u][v] = row[v];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (i + u < s1) {
-          const float aw = __int_as_float(rr[u].y), lw = __int_as_float(rr[u].z), lh = __int_as_float(rr[u].w);
+          const float aw = aws[u];  // (bilinear_setup's arithmetic)
+          const float h_im = xy[u].y * (float)Hl - 0.5f, w_im = xy[u].x * (float)Wl - 0.5f;
+          const float lh = h_im - floorf(h_im), lw = w_im - floorf(w_im);
           const float hw = 1.f - lw, hh = 1.f - lh;
           const float ah = aw * hh, al = aw * lh;  // the tap weights carry the attention weight
           const float w1 = ah * hw, w2 = ah * lw, w3 = al * hw, w4 = al * lw;
@@ -1203,386 +1185,29 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
                              const MsdaTiles& T, char* ws, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 10 * sizeof(float) + 64;  // + 16-byte records staged for a coalesced store, + masks
+  const size_t shm = (size_t)QB * L * P * 7 * sizeof(float) + 64;  // + bin words staged for a coalesced store, + masks
   const int BH = B * H;
   const MsdaTileWs W = msda_tile_ws(T, BH, Nq, P, D);
-  int4* rec = reinterpret_cast<int4*>(ws + W.rec);
   int* binw = reinterpret_cast<int*>(ws + W.binw);
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + W.mask);
   float* part = reinterpret_cast<float*>(ws + W.part);
   MsdaMaskGeom MG;
   for (int l = 0; l < 8; ++l) { MG.itx[l] = 1.f / (float)T.tsx[l]; MG.ity[l] = 1.f / (float)T.tsy[l]; MG.ntx[l] = T.ntx[l]; }
-  // grad_loc / grad_attn by sample + one record and one bin word per sample + one tile mask per block of QB queries
-  msda_bwd_kernel<D, P, 0, 1><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, rec, binw, mask, MG, Nk, Nq, H, L, ntiles, 0);
-  constexpr size_t lds = MsdaTileGeom<D>::lds_bytes();
-  static const bool attr_set = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return true;
-  }();
-  (void)attr_set;
-  const unsigned bh8 = (unsigned)((BH + 7) / 8) * 8;
-  int pshift = 0, bshift = 0;
-  while ((1 << pshift) < P) ++pshift;
-  while ((1 << bshift) < QB * P) ++bshift;
-  msda_tile_kernel<D><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, rec, binw, mask, part, T, Nq, pshift, bshift, ntiles, H, BH);
-  const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
-  msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// backward, grad_value by OWNED TILES — deterministic, no records, no partial tiles, no combine (round 3; the default)
-// ---------------------------------------------------------------------------------------------
-// The tile-accumulation design above moved 2.7x the algorithmic bytes: 16-byte records per sample (written and read:
-// 45 MB at the encoder shape of configs[1]) and one partial 17 x 9 cell block per (tile, sample chunk) (80 MB written and
-// read), folded by a third launch.  Here a tile OWNS a rectangle of tokens and nobody else writes them:
-//   * a tile of tx x ty tokens takes every sample whose top-left tap lies in the (tx + 1) x (ty + 1) bins that can reach its
-//     tokens — its own bins plus one halo column to the left and one halo row above; a sample on a tile border is visited by
-//     the 2 (4 at a corner) tiles it touches, each keeping only the taps that land on ITS tokens.  (tx + 1)/tx * (ty + 1)/ty
-//     = 1.2x the sample visits buy the absence of every cross-workgroup sum: grad_value rows are written once, coalesced,
-//     straight from the tile's LDS cells (fully overwritten: tokens nobody samples get zeros);
-//   * the sample kernel leaves ONE 4-byte bin word per sample (5.6 MB) and the per-block tile masks; the walk re-derives the
-//     tap weights from the sampling location and the attention weight (12 algorithmic bytes per sample, L2-resident: every
-//     workgroup of a (b, h) runs on one XCD) with the same arithmetic, hence the same floats, as the sample kernel;
-//   * no sample chunks: levels whose bins hold long runs (the coarse levels receive as many samples as the fine ones on a
-//     fraction of the bins) get SMALLER tiles and up to 8 threads (pairs) per bin that take consecutive parts of a bin's run,
-//     their rows added in part order — every float sum still runs in an order fixed by the data layout alone.
-// Scan / LDS counting sort / register accumulation are those of the tile kernel above.
-constexpr int MSDA_O_CHAIN = 64;  // samples per thread (pair) and bin the tile sizes aim at (RSCOTR_MSDA_OWN_CHAIN)
-constexpr int MSDA_O_MAXSF = 8;
-
-struct MsdaOwn {
-  int L, NW;                                        // levels, workgroups (= tiles) per (b, h)
-  int Hl[MSDA_T_MAXL], Wl[MSDA_T_MAXL], lsi[MSDA_T_MAXL];
-  int tx[MSDA_T_MAXL], ty[MSDA_T_MAXL];            // tokens per tile along x / y (bins: + 1)
-  int ntx[MSDA_T_MAXL], nty[MSDA_T_MAXL];
-  int sf[MSDA_T_MAXL];                              // thread pairs per bin
-  int wbase[MSDA_T_MAXL];
-};
-
-static bool msda_own_build(MsdaOwn* T, const int64_t* shapes_host, int L, int Nk, long SP, int D) {
-  const int npair = D >= 32 ? 128 : 256;           // MsdaTileGeom<D>: 256 / TB bins-with-threads per workgroup
-  const int ty_max = (D >= 32 ? 8 : 16) - 1, tx_max = MSDA_T_TS - 1;
-  if (!shapes_host || L < 1 || L > MSDA_T_MAXL) return false;
-  static const int chain = [] { const char* e = getenv("RSCOTR_MSDA_OWN_CHAIN"); const int v = e ? atoi(e) : MSDA_O_CHAIN; return v > 0 ? v : MSDA_O_CHAIN; }();
-  T->L = L;
-  int nw = 0, tok = 0;
-  for (int l = 0; l < L; ++l) {
-    const int Hh = (int)shapes_host[2 * l], Ww = (int)shapes_host[2 * l + 1];
-    if (Hh < 1 || Ww < 1 || Hh > 32766 || Ww > 32766) return false;
-    T->Hl[l] = Hh; T->Wl[l] = Ww; T->lsi[l] = tok;
-    int tx = std::min(Ww, tx_max), ty = std::min(Hh, ty_max);
-    const double per_bin = (double)SP / ((double)(Hh + 1) * (Ww + 1));
-    for (;;) {  // shrink the tile until a thread's share of a bin's run is short (or the tile is 1 x 1)
-      const int sf = std::max(1, std::min(MSDA_O_MAXSF, npair / ((tx + 1) * (ty + 1))));
-      if (per_bin / sf <= chain || (tx == 1 && ty == 1)) break;
-      if (tx >= ty && tx > 1) tx = (tx + 1) / 2; else if (ty > 1) ty = (ty + 1) / 2; else tx = (tx + 1) / 2;
-    }
-    T->ntx[l] = (Ww + tx - 1) / tx; T->nty[l] = (Hh + ty - 1) / ty;
-    T->tx[l] = (Ww + T->ntx[l] - 1) / T->ntx[l]; T->ty[l] = (Hh + T->nty[l] - 1) / T->nty[l];  // (even tiles)
-    T->ntx[l] = (Ww + T->tx[l] - 1) / T->tx[l]; T->nty[l] = (Hh + T->ty[l] - 1) / T->ty[l];
-    T->sf[l] = std::max(1, std::min(MSDA_O_MAXSF, npair / ((T->tx[l] + 1) * (T->ty[l] + 1))));
-    const long tiles = (long)T->ntx[l] * T->nty[l];
-    T->wbase[l] = nw;
-    if (tiles > (1 << 20)) return false;
-    nw += (int)tiles;
-    tok += Hh * Ww;
-  }
-  for (int l = L; l < MSDA_T_MAXL; ++l) {
-    T->Hl[l] = T->Wl[l] = 1; T->lsi[l] = tok; T->tx[l] = T->ty[l] = 1; T->ntx[l] = T->nty[l] = 1; T->sf[l] = 1; T->wbase[l] = nw;
-  }
-  T->NW = nw;
-  return tok == Nk && nw <= (1 << 20);
-}
-
-struct MsdaOwnWs {
-  long binw, mask, total;  // byte offsets
-};
-
-static MsdaOwnWs msda_own_ws(const MsdaOwn& T, int BH, int Nq, int P, int D) {
-  MsdaOwnWs w;
-  const long SP = (long)Nq * P;
-  long o = 0;
-  w.binw = o; o += (long)BH * T.L * ((SP + 3) & ~3L) * 4;  // (rows padded to whole 16-byte loads)
-  const int QB = 4 * (kWave / (D / 4));
-  const long nqt = (Nq + QB - 1) / QB;
-  w.mask = o; o += (((long)BH * T.L * nqt * 8) + 15) & ~15L;
-  w.total = o + 1024;  // (the scan's 16-byte loads of the last, partial block of a row may run past the row's end)
-  return w;
-}
-
-// One 256-thread workgroup per (b, h, level, tile).  See the header of this section; structure of msda_tile_kernel.
-template <int D, int P>
-__global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_own_kernel(const float* __restrict__ go, const float* __restrict__ loc,
-                                                                      const float* __restrict__ attn, const int* __restrict__ binw,
-                                                                      const unsigned long long* __restrict__ mask,
-                                                                      float* __restrict__ grad_value, MsdaOwn T, int Nk, int Nq,
-                                                                      int bshift, int nqt, int H, int BH) {
-  using Gm = MsdaTileGeom<D>;
-  constexpr int TB = Gm::TB, CH = Gm::CH, V = Gm::V, U = Gm::U, NBIN = Gm::NBIN, NCELL = Gm::NCELL;
-  constexpr int R = 4;
-  constexpr int pshift = P == 1 ? 0 : P == 2 ? 1 : P == 4 ? 2 : 3;
-  extern __shared__ __attribute__((aligned(16))) float t_lds[];
-  float* acc = t_lds;                                                   // [NCELL][D] (filled at the very end)
-  int* lrec = reinterpret_cast<int*>(acc + NCELL * D);                  // [CAP] sample index << 8 | local bin (kept list)
-  unsigned short* order = reinterpret_cast<unsigned short*>(lrec + MSDA_T_CAP);
-  unsigned short* rank = order + MSDA_T_CAP;
-  int* hist = reinterpret_cast<int*>(rank + MSDA_T_CAP);                // [4][NBIN]
-  int* binstart = hist + 4 * NBIN;                                      // [NBIN + 1]
-  int* wtot = binstart + NBIN + 4;
-  int* scratch = wtot + 8;
-  unsigned short* blist = reinterpret_cast<unsigned short*>(scratch + 4);
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int x8 = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int bh = x8 + 8 * (j / T.NW), e = j % T.NW;
-  if (bh >= BH) return;
-  const int b = bh / H, h = bh - b * H;
-  int l = 0;
-  while (l + 1 < T.L && e >= T.wbase[l + 1]) ++l;
-  const int tile = e - T.wbase[l];
-  const int Hl = T.Hl[l], Wl = T.Wl[l];
-  const int tyi = tile / T.ntx[l], txi = tile - tyi * T.ntx[l];
-  const int x0 = txi * T.tx[l], y0 = tyi * T.ty[l];                    // first owned token = first (halo) bin
-  const int x1 = min(x0 + T.tx[l], Wl), y1 = min(y0 + T.ty[l], Hl);    // one past the last owned token = last bin
-  const int SP = Nq << pshift;
-  const int BS = 1 << bshift;
-  const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
-
-  const int nbx = T.tx[l] + 1, nbt = nbx * (T.ty[l] + 1);              // bins of a tile (nominal: the last tiles use fewer)
-  const int SF = T.sf[l];
-  const int pair = tid / TB, sub = tid % TB;
-  const bool active = pair < nbt * SF;
-  const int bidx = active ? pair / SF : 0, seg = pair % SF;
-  const int bin = (bidx / nbx) * MSDA_T_TS + bidx % nbx;
-  const float* gob = go + ((long)b * Nq * H + h) * D + sub * CH;       // + q * H * D
-  const int qstride = H * D;
-  const int LP = T.L << pshift;
-  const float* locb = loc + (((long)b * Nq * H + h) * T.L + l) * (2 << pshift);   // + q * H * LP * 2 + p * 2
-  const float* attb = attn + (((long)b * Nq * H + h) * T.L + l) * (1 << pshift);  // + q * H * LP + p
-  const long lstride = (long)H * LP * 2, astride = (long)H * LP;
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  v2f a1[2 * V], a2[2 * V], a3[2 * V], a4[2 * V];
-#pragma unroll
-  for (int v = 0; v < 2 * V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = v2f{0.f, 0.f};
-
-  auto flush = [&](int n) {
-    for (int i = tid; i < 4 * NBIN; i += 256) hist[i] = 0;
-    __syncthreads();
-    const int nw = ((n + 3) / 4 + 63) & ~63;
-    const int i0 = w * nw, i1 = min(n, i0 + nw);
-    for (int i = i0 + lane; i < i1; i += 64) rank[i] = (unsigned short)atomicAdd(&hist[w * NBIN + (lrec[i] & 255)], 1);
-    __syncthreads();
-    {
-      int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-      if (tid < NBIN) { h0 = hist[tid]; h1 = hist[NBIN + tid]; h2 = hist[2 * NBIN + tid]; h3 = hist[3 * NBIN + tid]; }
-      int total;
-      const int start = block_exclusive_scan_256(h0 + h1 + h2 + h3, scratch, &total);
-      if (tid < NBIN) {
-        binstart[tid] = start;
-        hist[tid] = start; hist[NBIN + tid] = start + h0; hist[2 * NBIN + tid] = start + h0 + h1; hist[3 * NBIN + tid] = start + h0 + h1 + h2;
-      }
-      if (tid == 0) binstart[NBIN] = total;
-    }
-    __syncthreads();
-    for (int i = i0 + lane; i < i1; i += 64) order[hist[w * NBIN + (lrec[i] & 255)] + rank[i]] = (unsigned short)i;
-    __syncthreads();
-    int s0 = binstart[bin], s1 = binstart[bin + 1];
-    {
-      const int per = (s1 - s0 + SF - 1) / SF;
-      s0 = active ? s0 + seg * per : s1;
-      s1 = min(s1, s0 + per);
-    }
-#pragma unroll 1
-    for (int i = s0; i < s1; i += U) {  // U samples in flight per thread, applied in list (= sample) order
-      float2 xy[U];
-      float aw[U];
-      float4 g[U][V];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int sidx = lrec[order[min(i + u, s1 - 1)]] >> 8;
-        const int q = sidx >> pshift, pp = sidx & (P - 1);
-        xy[u] = *reinterpret_cast<const float2*>(locb + q * lstride + pp * 2);
-        aw[u] = attb[q * astride + pp];
-        const float4* row = reinterpret_cast<const float4*>(gob + (long)q * qstride);
-#pragma unroll
-        for (int v = 0; v < V; ++v) g[u][v] = row[v];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (i + u < s1) {
-          // (the sample kernel's arithmetic: bilinear_setup)
-          const float h_im = xy[u].y * (float)Hl - 0.5f, w_im = xy[u].x * (float)Wl - 0.5f;
-          const float lh = h_im - floorf(h_im), lw = w_im - floorf(w_im);
-          const float hw = 1.f - lw, hh = 1.f - lh;
-          const float ah = aw[u] * hh, al = aw[u] * lh;  // the tap weights carry the attention weight
-          const float w1 = ah * hw, w2 = ah * lw, w3 = al * hw, w4 = al * lw;
-          const v2f W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3}, W4 = {w4, w4};
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const v2f lo = {g[u][v].x, g[u][v].y}, hi = {g[u][v].z, g[u][v].w};
-            a1[2 * v] += lo * W1; a1[2 * v + 1] += hi * W1;
-            a2[2 * v] += lo * W2; a2[2 * v + 1] += hi * W2;
-            a3[2 * v] += lo * W3; a3[2 * v + 1] += hi * W3;
-            a4[2 * v] += lo * W4; a4[2 * v + 1] += hi * W4;
-          }
-        }
-      }
-    }
-    __syncthreads();  // (the lists are rewritten by the scan that follows)
-  };
-
-  // scan the bin words of the blocks whose mask names this tile (msda_tile_kernel's scan over the whole level: no chunks)
-  int n = 0, it = 0;
-  const int4 none = make_int4(-1, -1, -1, -1);
-  const unsigned long long* msrc = mask + ((long)bh * T.L + l) * nqt;
-  const int mbit = tile & 63;
-  const int nblk = (SP + BS - 1) >> bshift;
-  const int slot = (tid * R) >> bshift, off = (tid * R) & (BS - 1), BPR = (256 * R) >> bshift;  // blocks per round
-  for (int sg0 = 0; sg0 < nblk; sg0 += MSDA_T_SEGB) {
-    const int segn = min(nblk - sg0, MSDA_T_SEGB);
-    int cnt = 0;
-    for (int j0 = 0; j0 < segn; j0 += 256, ++it) {
-      const int jj = j0 + tid;
-      const bool keep = jj < segn && ((msrc[sg0 + jj] >> mbit) & 1ull) != 0ull;
-      const unsigned long long m = __ballot(keep);
-      int* wt = wtot + (it & 1) * 4;
-      if (lane == 0) wt[w] = __popcll(m);
-      __syncthreads();
-      const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
-      if (keep) blist[cnt + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0) + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)jj;
-      cnt += t0 + t1 + t2 + t3;
-    }
-    __syncthreads();
-    auto index = [&](int rb) {
-      const int k = rb + slot;
-      return k < cnt ? ((sg0 + (int)blist[k]) << bshift) + off : -1;
-    };
-    auto fetch = [&](int i) { return i >= 0 ? *reinterpret_cast<const int4*>(bsrc + i) : none; };
-    int i0 = index(0), i1 = index(BPR);
-    int4 nx0 = fetch(i0), nx1 = fetch(i1);
-    for (int rb = 0; rb < cnt; rb += BPR, ++it) {
-      const int4 c4 = nx0;
-      const int ib = i0;
-      nx0 = nx1; i0 = i1;
-      i1 = index(rb + 2 * BPR);
-      nx1 = fetch(i1);
-      const int cur[R] = {c4.x, c4.y, c4.z, c4.w};
-      bool sel[R];
-      int before = 0, wsum = 0;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int bx = cur[k] & 0xffff, by = cur[k] >> 16;  // (-1: by = -1: outside every tile)
-        sel[k] = ib >= 0 && cur[k] >= 0 && bx >= x0 && bx <= x1 && by >= y0 && by <= y1 && ib + k < SP;
-        const unsigned long long m = __ballot(sel[k]);
-        before += __popcll(m & ((1ull << lane) - 1ull));
-        wsum += __popcll(m);
-      }
-      int* wt = wtot + (it & 1) * 4;
-      if (lane == 0) wt[w] = wsum;
-      __syncthreads();
-      const int t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
-      int pos = n + before + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        if (sel[k]) {
-          const int bx = cur[k] & 0xffff, by = cur[k] >> 16;
-          lrec[pos++] = ((ib + k) << 8) | ((by - y0) * MSDA_T_TS + (bx - x0));
-        }
-      }
-      n += t0 + t1 + t2 + t3;
-      if (n > MSDA_T_CAP - 256 * R) {
-        __syncthreads();
-        flush(n);
-        n = 0;
-      }
-    }
-    __syncthreads();  // (blist is rebuilt)
-  }
-  __syncthreads();
-  if (n > 0) flush(n);
-  // the bins' tap rows meet in the tile's cells: tap k of local bin (x, y) belongs to cell (x + (k & 1), y + (k >> 1)); cell
-  // (cx, cy) is token (x0 + cx - 1, y0 + cy - 1), so column / row 0 hold what belongs to the left / upper neighbour (or lies
-  // outside the map) and is dropped.  One tap and one part at a time: no two threads touch a cell together and every cell
-  // sums its rows in (tap, part) order
-  for (int i = tid; i < NCELL * D / 4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  {
-    const int lbx = bin & (MSDA_T_TS - 1), lby = bin / MSDA_T_TS;
-    float4* c = reinterpret_cast<float4*>(acc + (lby * MSDA_T_CW + lbx) * D + sub * CH);
-    constexpr int CS = D / 4;  // float4 per cell
-    auto add = [](float4* p, const float4& v) { float4 o = *p; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *p = o; };
-    for (int sg = 0; sg < SF; ++sg) {
-      if (active && seg == sg) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + v, make_float4(a1[2 * v].x, a1[2 * v].y, a1[2 * v + 1].x, a1[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      if (active && seg == sg) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + CS + v, make_float4(a2[2 * v].x, a2[2 * v].y, a2[2 * v + 1].x, a2[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      if (active && seg == sg) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, make_float4(a3[2 * v].x, a3[2 * v].y, a3[2 * v + 1].x, a3[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      if (active && seg == sg) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, make_float4(a4[2 * v].x, a4[2 * v].y, a4[2 * v + 1].x, a4[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-  }
-  // the owned tokens' rows: D / 4 lanes per token, whole 128-byte (D = 32) lines
-  {
-    constexpr int G = D / 4;
-    const int tw = x1 - x0, th = y1 - y0;
-    for (int i = tid; i < tw * th * G; i += 256) {
-      const int c4 = i % G, tk = i / G, ly = tk / tw, lx = tk - ly * tw;
-      const float4 v = *reinterpret_cast<const float4*>(acc + ((ly + 1) * MSDA_T_CW + lx + 1) * D + c4 * 4);
-      *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + T.lsi[l] + (long)(y0 + ly) * Wl + x0 + lx) * H + h) * D + c4 * 4) = v;
-    }
-  }
-}
-
-template <int D, int P>
-static void launch_bwd_owned(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
-                             const float* go, float* gv, float* gl, float* ga, int B, int Nk, int Nq, int H, int L,
-                             const MsdaOwn& T, char* ws, hipStream_t s) {
-  constexpr int QB = 4 * (kWave / (D / 4));
-  const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 7 * sizeof(float) + 64;  // + 4-byte bin words staged for a coalesced store, + masks
-  const int BH = B * H;
-  const MsdaOwnWs W = msda_own_ws(T, BH, Nq, P, D);
-  int* binw = reinterpret_cast<int*>(ws + W.binw);
-  unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + W.mask);
-  MsdaMaskGeom MG;
-  for (int l = 0; l < 8; ++l) {
-    MG.itx[l] = 1.f / (float)T.tx[l]; MG.ity[l] = 1.f / (float)T.ty[l]; MG.ntx[l] = T.ntx[l]; MG.nty[l] = T.nty[l];
-    MG.tx[l] = T.tx[l]; MG.ty[l] = T.ty[l];
-  }
   // grad_loc / grad_attn by sample + one bin word per sample + one tile mask per block of QB queries
-  msda_bwd_kernel<D, P, 0, 2><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, binw, mask, MG, Nk, Nq, H, L, ntiles, 0);
+  msda_bwd_kernel<D, P, 0, true><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, binw, mask, MG, Nk, Nq, H, L, ntiles, 0);
   constexpr size_t lds = MsdaTileGeom<D>::lds_bytes();
   static const bool attr_set = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_own_kernel<D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_tile_kernel<D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return true;
   }();
   (void)attr_set;
   const unsigned bh8 = (unsigned)((BH + 7) / 8) * 8;
   int bshift = 0;
   while ((1 << bshift) < QB * P) ++bshift;
-  msda_own_kernel<D, P><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, loc, attn, binw, mask, gv, T, Nk, Nq, bshift, ntiles, H, BH);
+  msda_tile_kernel<D, P><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, loc, attn, binw, mask, part, T, Nq, bshift, ntiles, H, BH);
+  const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
+  msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1619,7 +1244,7 @@ static void launch_bwd(const float* value, const int64_t* shapes, const int64_t*
   const int ntiles = (Nq + QB - 1) / QB;
   const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
   msda_bwd_kernel<D, P, 1><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
+      value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
 }
 
 // sorted / pull strategy: grad_loc + grad_attn by sample, grad_value by destination token
@@ -1646,10 +1271,10 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
     // grad_value zeroed for the scatter the sample kernel falls back to; on the sorted path the pull kernel overwrites it
     hipMemsetAsync(gv, 0, (size_t)B * Nk * H * D * sizeof(float), s);
     msda_bwd_kernel<D, P, 2><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, W.lds_words);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, W.lds_words);
   } else {
     msda_bwd_kernel<D, P, 0><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
-        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
+        value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
   }
   msda_binsum_kernel<<<dim3((W.NEmax + 255) / 256, BH), 256, 0, s>>>(shapes, ws, W, L);
   msda_plan_kernel<D><<<BH, 1024, hist_lds, s>>>(shapes, lsi, ws, W, gv, Nk, H, L);
@@ -1714,22 +1339,10 @@ extern "C" int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L
   return (int64_t)(W.body + (long)B * H * W.per_bh) * 4;
 }
 
-// 2 (default): owned tiles (round 3); 1: partial tiles + combine (round 2), kept as the A/B reference (RSCOTR_MSDA_TILE_VARIANT)
-static int msda_tile_variant() {
-  static const int v = [] { const char* e = getenv("RSCOTR_MSDA_TILE_VARIANT"); const int x = e ? atoi(e) : 2; return x == 1 ? 1 : 2; }();
-  return v;
-}
-
 extern "C" int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L,
                                                    int P) {
-  if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || Nq >= (1 << 20)) return 0;
-  if (msda_tile_variant() == 2) {
-    MsdaOwn T;
-    if (!msda_own_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) return 0;
-    return msda_own_ws(T, B * H, Nq, P, D).total;
-  }
   MsdaTiles T;
-  if (!msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) return 0;
+  if (B <= 0 || Nq <= 0 || H <= 0 || P <= 0 || Nq >= (1 << 20) || !msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) return 0;
   return msda_tile_ws(T, B * H, Nq, P, D).total;
 }
 
@@ -1749,20 +1362,8 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: read value, read-modify-write grad_value, read loc/attn/grad_out, write grad_loc/grad_attn
   ProfScope prof(PROF_MSDA_BWD, 4.0 * B * (3.0 * Nk * H * D + (double)Nq * H * L * P * 6 + (double)Nq * H * D), s,
-                 "rscotr_msda_bwd<%d, %d> (sample + tile kernels)", D, P);
-  if (workspace && shapes_host && Nk > 0 && msda_tile_variant() == 2) {
-    MsdaOwn T;
-    const int64_t need_t = rscotr_msda_bwd_tiled_workspace(shapes_host, B, Nk, Nq, H, D, L, P);
-    if (need_t > 0 && workspace_bytes >= need_t && msda_own_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) {
-      if (!aligned16(workspace)) return fail(RSCOTR_E_ALIGN, "rscotr_msda_bwd: workspace must be 16-byte aligned");
-#define CALL(DD, PP)                                                                                    \
-  launch_bwd_owned<DD, PP>(value, spatial_shapes, level_start_index, loc, attn, grad_out, grad_value, \
-                           grad_loc, grad_attn, B, Nk, Nq, H, L, T, (char*)workspace, s)
-      RSCOTR_DISPATCH_DP(D, P, CALL)
-#undef CALL
-      return check_launch("rscotr_msda_bwd (owned tiles)");
-    }
-  } else if (workspace && shapes_host && Nk > 0) {
+                 "rscotr_msda_bwd<%d, %d> (sample + tile + combine kernels)", D, P);
+  if (workspace && shapes_host && Nk > 0) {
     MsdaTiles T;
     const int64_t need_t = rscotr_msda_bwd_tiled_workspace(shapes_host, B, Nk, Nq, H, D, L, P);
     if (need_t > 0 && workspace_bytes >= need_t && msda_tiles_build(&T, shapes_host, L, Nk, (long)Nq * P, D)) {
