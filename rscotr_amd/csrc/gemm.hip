@@ -966,30 +966,46 @@ struct SplitOperand {
   static constexpr int NV = (ITEMS + 255) / 256;
   float4 v[NV], w[NV];  // row-major: v; k-major: v = even k row, w = odd k row of a pair
 
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid) {
+  // EDGE instantiations (ragged M / N / K).  rlast: the last row a load may touch — rows - 1 of a row-major operand, rows - 4
+  // of a k-major one (whose rows are read four at a time; rows % 4 == 0, host-checked): rows past it are CLAMPED reads, and
+  // what they bring is multiplied into accumulator rows / columns that are never stored.  klim: the end of the reduction
+  // (K % 4 == 0, host-checked): k positions past it are clamped reads replaced by ZEROS (they do enter the sums).
+  template <bool EDGE = false>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid, int rlast = 0, int klim = 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       if (ITEMS % 256 == 0 || idx < ITEMS) {
         if (!KM) {
-          v[i] = *reinterpret_cast<const float4*>(P + (long)(row0 + idx / Q) * ld + k0 + (idx % Q) * 4);
+          const int row = EDGE ? min(row0 + idx / Q, rlast) : row0 + idx / Q;
+          const int kk = k0 + (idx % Q) * 4;
+          v[i] = *reinterpret_cast<const float4*>(P + (long)row * ld + (EDGE ? min(kk, klim - 4) : kk));
+          if (EDGE && kk >= klim) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
-          const float* src = P + (long)(k0 + 2 * kp) * ld + row0 + r4;
-          v[i] = *reinterpret_cast<const float4*>(src);
-          w[i] = *reinterpret_cast<const float4*>(src + ld);
+          const int ka = k0 + 2 * kp, col = EDGE ? min(row0 + r4, rlast) : row0 + r4;
+          if (!EDGE) {
+            const float* src = P + (long)ka * ld + col;
+            v[i] = *reinterpret_cast<const float4*>(src);
+            w[i] = *reinterpret_cast<const float4*>(src + ld);
+          } else {
+            v[i] = *reinterpret_cast<const float4*>(P + (long)min(ka, klim - 1) * ld + col);
+            w[i] = *reinterpret_cast<const float4*>(P + (long)min(ka + 1, klim - 1) * ld + col);
+            if (ka >= klim) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ka + 1 >= klim) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
       }
     }
   }
   // k-major only: row k of the staged tile times ks[k / per]
-  __device__ __forceinline__ void scale_k(const float* __restrict__ ks, int per, int k0, int tid) {
+  __device__ __forceinline__ void scale_k(const float* __restrict__ ks, int per, int k0, int tid, int klast = 0x7ffffffe) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       if (ITEMS % 256 == 0 || idx < ITEMS) {
         const int k = k0 + 2 * (idx / (R / 4));
-        const float f0 = ks[k / per], f1 = ks[(k + 1) / per];
+        const float f0 = ks[min(k, klast) / per], f1 = ks[min(k + 1, klast) / per];  // (rows past K hold zeros: any factor)
         v[i].x *= f0; v[i].y *= f0; v[i].z *= f0; v[i].w *= f0;
         w[i].x *= f1; w[i].y *= f1; w[i].z *= f1; w[i].w *= f1;
       }
@@ -1076,7 +1092,7 @@ constexpr int bf16x6_lds_words() {
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
   constexpr int NPL = 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
@@ -1087,7 +1103,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = p.N / BN;
+  const int tiles_n = EDGE ? (p.N + BN - 1) / BN : p.N / BN;
+  const int alast = EDGE ? (AKM ? p.M - 4 : p.M - 1) : 0, blast = EDGE ? (BKM ? p.N - 4 : p.N - 1) : 0;
   int tile, split = 0;
   if (p.splits == 1) {
     tile = xcd_swizzle(bx, gx);
@@ -1103,7 +1120,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = split * p.ksplit_len;
   const int kend = min(p.K, kbeg + p.ksplit_len);
-  const int nk = (kend - kbeg) / SBK;
+  const int nk = EDGE ? (kend - kbeg + SBK - 1) / SBK : (kend - kbeg) / SBK;
+  const int klast = EDGE ? p.K - 1 : 0x7ffffffe;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -1120,9 +1138,9 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
   const int fr = lane & 31, g = lane >> 5;
   auto fetch = [&](int t) {
-    la.load(p.A, p.lda, m0, kbeg + t * SBK, tid);
-    lb.load(p.B, p.ldb, n0, kbeg + t * SBK, tid);
-    if (AKM && p.kscale) la.scale_k(p.kscale, p.krows_per, kbeg + t * SBK, tid);
+    la.template load<EDGE>(p.A, p.lda, m0, kbeg + t * SBK, tid, alast, p.K);
+    lb.template load<EDGE>(p.B, p.ldb, n0, kbeg + t * SBK, tid, blast, p.K);
+    if (AKM && p.kscale) la.scale_k(p.kscale, p.krows_per, kbeg + t * SBK, tid, klast);
   };
   auto stage = [&](unsigned* a_s, unsigned* b_s) {
     if (AKM && do_rs) la.accum(rs, tid);
@@ -1162,10 +1180,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int tt = min(d, nk - 1);
-      las[d].load(p.A, p.lda, m0, kbeg + tt * SBK, tid);
-      lbs[d].load(p.B, p.ldb, n0, kbeg + tt * SBK, tid);
+      las[d].template load<EDGE>(p.A, p.lda, m0, kbeg + tt * SBK, tid, alast, p.K);
+      lbs[d].template load<EDGE>(p.B, p.ldb, n0, kbeg + tt * SBK, tid, blast, p.K);
     }
-    if (AKM) las[0].scale_k(ksp, ksper, kbeg, tid);
+    if (AKM) las[0].scale_k(ksp, ksper, kbeg, tid, klast);
     if (AKM) las[0].accum(rs, tid);
     las[0].store(sA[0], tid);
     lbs[0].store(sB[0], tid);
@@ -1177,11 +1195,11 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
         if (t < nk) {
           {  // tile t + D into the set tile t left (staged during step t - 1 / the prologue)
             const int tt = min(t + D, nk - 1);
-            las[s % D].load(p.A, p.lda, m0, kbeg + tt * SBK, tid);
-            lbs[s % D].load(p.B, p.ldb, n0, kbeg + tt * SBK, tid);
+            las[s % D].template load<EDGE>(p.A, p.lda, m0, kbeg + tt * SBK, tid, alast, p.K);
+            lbs[s % D].template load<EDGE>(p.B, p.ldb, n0, kbeg + tt * SBK, tid, blast, p.K);
           }
           mma(sA[s & 1], sB[s & 1]);
-          if (AKM) las[(s + 1) % D].scale_k(ksp, ksper, kbeg + min(t + 1, nk - 1) * SBK, tid);
+          if (AKM) las[(s + 1) % D].scale_k(ksp, ksper, kbeg + min(t + 1, nk - 1) * SBK, tid, klast);
           if (AKM) las[(s + 1) % D].accum(rs, tid, t + 1 < nk ? 1.f : 0.f);
           las[(s + 1) % D].store(sA[(s + 1) & 1], tid);
           lbs[(s + 1) % D].store(sB[(s + 1) & 1], tid);
@@ -1232,8 +1250,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
 #pragma unroll
       for (int k = 0; k < KL; ++k) v += rf[k * BM + tid];
       const int m = m0 + tid;
-      if (p.splits > 1 || SLAB) p.rs_slabs[(long)split * p.M + m] = v;
-      else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
+      if (!EDGE || m < p.M) {
+        if (p.splits > 1 || SLAB) p.rs_slabs[(long)split * p.M + m] = v;
+        else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
+      }
     }
   }
 
@@ -1247,7 +1267,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          slab[(long)m * p.N + n] = acc[i][j][r];
+          if (!EDGE || (m < p.M && n < p.N)) slab[(long)m * p.N + n] = acc[i][j][r];
         }
       }
     return;
@@ -1258,29 +1278,31 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+      if (EDGE && n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
       const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * g;
       float* crow = p.C + (long)mb * p.ldc + n;
       if (plain) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
+        for (int r = 0; r < 16; ++r)
+          if (!EDGE || mb + (r & 3) + 8 * (r >> 2) < p.M) crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
       } else {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           float v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          epilogue_rows4<false>(p, v, mb + 8 * g4, n);
+          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE>()];
-  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false>(p, blockIdx.x, gridDim.x, lds);
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1590,12 +1612,20 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   // gradients (124 -> 75 us), the 10880- / 2048-row products with K >= 256 (5-15 %) — and loses on small outputs (256 x 256
   // weight gradients: 22.6 -> 32.5 us: too few tiles to hide the staging), on K < 192 (conversion not amortised) and where
   // the epilogue's memory traffic bounds the launch anyway.
-  if (!on || !p.vecA || !p.vecB || p.K % 16 || p.K < k_min || p.M % 64 || p.N % 64) return c;
+  static const int edge_ok = getenv("RSCOTR_BF16X6_EDGE") ? atoi(getenv("RSCOTR_BF16X6_EDGE")) : 1;
+  if (!on || !p.vecA || !p.vecB || p.K % 4 || p.K < k_min || p.M < 64 || p.N < 64) return c;
+  // ragged shapes (M = 4 x 13 294 rows at 800 x 800, N = 96 / 288 columns of Swin stage 1, K = 53 176 of the 800 x 800 weight
+  // gradients) take the EDGE instantiations: clamped loads, zeros past K, guarded stores; a k-major operand is read four
+  // rows at a time, so its row count must be a multiple of 4
+  const bool ragged = p.M % 64 || p.N % 64 || p.K % 16;
+  if (ragged && (!edge_ok || (a_kmajor && p.M % 4) || (b_kmajor && p.N % 4))) return c;
   if (!gelu_ok && (p.act == ACT_GELU || p.act == ACT_GELU_GRAD || p.pre)) return c;
-  const long t64 = (long)(p.M / 64) * (p.N / 64);
-  const long t128 = (p.M % 128 == 0 && p.N % 128 == 0) ? (long)(p.M / 128) * (p.N / 128) : 0;
+  const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  // (a 128-wide tile on a ragged edge wastes up to half a tile per row / column of tiles: only where that is < 1/8 of the work)
+  const bool fit128 = (p.M % 128 == 0 || p.M >= 1024) && (p.N % 128 == 0 || p.N >= 1024);
   if (a_kmajor && b_kmajor) {  // weight gradients: small outputs, long reductions -> k-slices through slabs
-    if (!dw_ok || p.rowscale || p.K < 1024 || t128 < dw_t128_min) return c;
+    if (!dw_ok || p.rowscale || p.K < 1024 || p.M % 128 || p.N % 128 || t128 < dw_t128_min) return c;
     const int bm = 128;
     const long tiles = t128;
     if (tiles > 2048) return c;
@@ -1610,7 +1640,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
     return c;
   }
   if (p.kscale) return c;
-  if (t128 >= t128_min) c.bm = 128;
+  if (fit128 && t128 >= t128_min) c.bm = 128;
   else if (t64 >= t64_min && p.K <= 4096) c.bm = 64;
   else if (mid_split && t64 >= 128 && p.K >= 1024) {
     // mid-size outputs with a long reduction (Swin stage 3: 2048 x 384 x 1536): too few 64 x 64 tiles for the chip, so the
@@ -1629,12 +1659,12 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   return c;
 }
 
-template <int BM, int PIPE>
+template <int BM, int PIPE, bool EDGE = false>
 static void launch_split6(const GemmParams& p, int a_kmajor, int b_kmajor, unsigned nwg, hipStream_t s) {
-  if (!a_kmajor && !b_kmajor) gemm_bf16x6_kernel<BM, BM, false, false, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
-  else if (!a_kmajor) gemm_bf16x6_kernel<BM, BM, false, true, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
-  else if (!b_kmajor) gemm_bf16x6_kernel<BM, BM, true, false, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
-  else gemm_bf16x6_kernel<BM, BM, true, true, PIPE><<<dim3(nwg), 256, 0, s>>>(p);
+  if (!a_kmajor && !b_kmajor) gemm_bf16x6_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!a_kmajor) gemm_bf16x6_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!b_kmajor) gemm_bf16x6_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else gemm_bf16x6_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2269,11 +2299,11 @@ extern "C" int64_t rscotr_gemm_f32_workspace(int M, int N, int K) {
   const GemmCfg c = choose_cfg(M, N, K);
   const DwCfg d = choose_dw_direct(M, N, K);
   int64_t sp = std::max<int64_t>(c.splits > 1 ? c.splits : 0, d.splits);
-  if (g_gemm_prec.load(std::memory_order_relaxed) == 3 && M % 64 == 0 && N % 64 == 0 && K % 16 == 0 && K >= 1024) {
+  if (g_gemm_prec.load(std::memory_order_relaxed) == 3 && M >= 64 && N >= 64 && K % 4 == 0 && K >= 1024) {
     const long t128 = (M % 128 == 0 && N % 128 == 0) ? (long)(M / 128) * (N / 128) : 0;
-    const long tiles = t128 >= 16 ? t128 : (long)(M / 64) * (N / 64);
+    const long tiles = t128 >= 16 ? t128 : (long)((M + 63) / 64) * ((N + 63) / 64);
     sp = std::max<int64_t>(sp, std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, K / 256)));  // as a weight gradient
-    const long t64 = (long)(M / 64) * (N / 64);
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (t64 >= 128 && t64 < 512) sp = std::max<int64_t>(sp, std::min<long>((512 + t64 - 1) / t64, K / 256));  // mid-size k-slices
   }
   const int pm = g_gemm_prec.load(std::memory_order_relaxed);
@@ -2349,7 +2379,8 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
   if (prec_mode == 3) {
     const Split6Cfg sc = choose_split6(p, a_kmajor, b_kmajor, workspace ? workspace_bytes : 0);
     if (sc.bm) {
-      p.tiles = (M / sc.bm) * (N / sc.bm);
+      p.tiles = ((M + sc.bm - 1) / sc.bm) * ((N + sc.bm - 1) / sc.bm);
+      const bool ragged = M % sc.bm || N % sc.bm || K % 16;
       p.splits = sc.splits; p.ksplit_len = sc.klen;
       p.slabs = sc.splits > 1 ? workspace : nullptr;
       p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
@@ -2360,7 +2391,11 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
       ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", xname);
       const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
       static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;  // bit 0: 64 x 64 (measured -0.45 ms / round), bit 1: 128 x 128 (measured slower on every layout of the step: +0.65 ms)
-      if (sc.bm == 128) {
+      if (ragged) {  // (EDGE instantiations: the 128 x 128 one-stage loop and the pipelined 64 x 64 loop)
+        if (sc.bm == 128) launch_split6<128, 0, true>(p, a_kmajor, b_kmajor, nwg, s);
+        else if (sc.klen % 32 == 0) launch_split6<64, 2, true>(p, a_kmajor, b_kmajor, nwg, s);
+        else launch_split6<64, 1, true>(p, a_kmajor, b_kmajor, nwg, s);
+      } else if (sc.bm == 128) {
         if (pipelined & 2) launch_split6<128, 3>(p, a_kmajor, b_kmajor, nwg, s);
         else launch_split6<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
       } else {

@@ -373,7 +373,13 @@ def test_gemm_bf16x3_slices_and_kscale(cuda, gemm_precision):
 @pytest.mark.parametrize('M,N,K,ak,bk', [(10880, 2048, 256, 0, 0), (10880, 256, 2048, 0, 1), (2048, 1536, 384, 0, 0),
                                          (8192, 192, 768, 0, 1), (2048, 1024, 96, 1, 0), (256, 2048, 10880, 1, 1),
                                          (384, 1536, 2048, 1, 1), (256, 256, 10880, 1, 1), (4096, 4096, 4096, 0, 0),
-                                         (1000, 768, 3072, 0, 0)])
+                                         (1000, 768, 3072, 0, 0),
+                                         # ragged shapes (EDGE instantiations: clamped loads, zeros past K, guarded stores): the
+                                         # 800 x 800 det step's 4 x 13 294 rows (configs[3]) as M and as the reduction of a
+                                         # weight gradient, Swin stage 1's N = 96, ragged rows of k-major operands
+                                         (53176, 256, 256, 0, 0), (53176, 256, 256, 0, 1), (256, 2048, 53176, 1, 1),
+                                         (32768, 96, 384, 0, 0), (2000, 1024, 512, 1, 0), (8192, 200, 512, 0, 1),
+                                         (1604, 2048, 256, 0, 0)])
 def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
     """Precision mode 3 (gemm_bf16x6_kernel: three bf16 planes per fp32 operand, six MFMAs per k-step, fp32 accumulate)
     against fp64 next to the fp32 matrix pipe on the step's own shapes, all four operand layouts, both tile sizes, with
@@ -395,11 +401,20 @@ def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
         err[mode] = _rel(outs[mode], ref)
     # the shapes the dispatch rules of csrc/gemm.hip (choose_split6) send to the split product must really take it
     routed = (M, N, K, ak, bk) in {(10880, 2048, 256, 0, 0), (10880, 256, 2048, 0, 1), (2048, 1536, 384, 0, 0),
-                                   (256, 2048, 10880, 1, 1), (384, 1536, 2048, 1, 1), (4096, 4096, 4096, 0, 0)}
+                                   (256, 2048, 10880, 1, 1), (384, 1536, 2048, 1, 1), (4096, 4096, 4096, 0, 0),
+                                   (1000, 768, 3072, 0, 0), (53176, 256, 256, 0, 0), (53176, 256, 256, 0, 1),
+                                   (256, 2048, 53176, 1, 1), (32768, 96, 384, 0, 0), (2000, 1024, 512, 1, 0),
+                                   (8192, 200, 512, 0, 1), (1604, 2048, 256, 0, 0)}
     assert torch.equal(outs[0], outs[3]) != routed, (M, N, K, ak, bk, err)
     assert err[3] <= 2.0 * err[0] + 5e-7, err
     if K <= 2048:  # (the fp32 FMA chain itself reaches 9e-7 at K = 2048)
         assert err[3] <= max(1e-6, 1.5 * err[0]), err
+    if M % 64 or N % 64:  # ragged: nothing written past the edge (the result tensor is exactly M x N: a stray store would
+        assert torch.isfinite(outs[3]).all()  # have hit the allocator's neighbour; checked with a guard band below)
+        guard = torch.full((M + 8, N), 7.0, device=cuda)
+        ops.gemm(A.to(cuda), B.to(cuda), M, N, K, A.shape[1], B.shape[1], ak, bk, out=guard[:M], bias=bias.to(cuda), act=1,
+                 resid=resid.to(cuda))
+        assert torch.equal(guard[:M], outs[3]) and bool((guard[M:] == 7.0).all())
 
 
 def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
