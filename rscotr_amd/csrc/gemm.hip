@@ -956,6 +956,53 @@ __device__ __forceinline__ unsigned pack_bf16(__bf16 a, __bf16 b) {
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
+// The planes of TWO adjacent values as packed dwords (low half = a, high half = b): the same conversions and exact
+// subtractions as split_planes, written on 2-vectors so that they compile to v_cvt_pk_bf16_f32 (two conversions and the
+// pack in one instruction), one mask + one shift for the way back and v_pk_add_f32 for the two subtractions: 9 VALU
+// instructions per pair against ~19 for two scalar splits + two packs (a VALU instruction occupies its SIMD's issue port
+// for 4 cycles: the conversion was 41 % of the 4096^3 kernel's SIMD time next to 43 % of MFMA, profiles/r3_bf16x6_pmc.txt).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <int NPL>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[3]) {
+  const f32x2_t x = {a, b};
+  const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+  out[0] = __builtin_bit_cast(unsigned, h);
+  const f32x2_t r1 = x - __builtin_convertvector(h, f32x2_t);
+  const bf16x2_t m = __builtin_convertvector(r1, bf16x2_t);
+  out[1] = __builtin_bit_cast(unsigned, m);
+  if (NPL == 3) {
+    const f32x2_t r2 = r1 - __builtin_convertvector(m, f32x2_t);
+    out[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+  } else {
+    out[2] = 0u;
+  }
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const f32x2_t x = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+}
+
+// Planes of the pairs (e.x, o.x), (e.y, o.y), (e.z, o.z), (e.w, o.w) (low half = e): out[plane] = the four packed dwords.
+template <int NPL>
+__device__ __forceinline__ void split_rows4(const float4& e, const float4& o, uint4 (&out)[3]) {
+  f32x2_t e01 = {e.x, e.y}, e23 = {e.z, e.w}, o01 = {o.x, o.y}, o23 = {o.z, o.w};
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    const unsigned h0 = cvt_pk_bf16(e01.x, o01.x), h1 = cvt_pk_bf16(e01.y, o01.y);
+    const unsigned h2 = cvt_pk_bf16(e23.x, o23.x), h3 = cvt_pk_bf16(e23.y, o23.y);
+    out[pl] = make_uint4(h0, h1, h2, h3);
+    if (pl + 1 < NPL) {
+      const f32x2_t fe01 = {__uint_as_float(h0 << 16), __uint_as_float(h1 << 16)};
+      const f32x2_t fe23 = {__uint_as_float(h2 << 16), __uint_as_float(h3 << 16)};
+      const f32x2_t fo01 = {__uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 & 0xffff0000u)};
+      const f32x2_t fo23 = {__uint_as_float(h2 & 0xffff0000u), __uint_as_float(h3 & 0xffff0000u)};
+      e01 -= fe01; e23 -= fe23; o01 -= fo01; o23 -= fo23;
+    }
+  }
+}
+
 template <int R, bool KM, int NPL, int SBK = 16>
 struct SplitOperand {
   static constexpr int LDR = SBK * NPL + 8;                         // bf16 per LDS row (row-major source): 112 / 208 bytes
@@ -1029,30 +1076,25 @@ struct SplitOperand {
       if (ITEMS % 256 == 0 || idx < ITEMS) {
         if (!KM) {
           const int row = idx / Q, kq = (idx % Q) * 4;
-          __bf16 a[3], b[3], c[3], d[3];
-          split_planes<NPL>(v[i].x, a); split_planes<NPL>(v[i].y, b); split_planes<NPL>(v[i].z, c); split_planes<NPL>(v[i].w, d);
+          unsigned ab[3], cd[3];
+          split_pair<NPL>(v[i].x, v[i].y, ab);
+          split_pair<NPL>(v[i].z, v[i].w, cd);
           unsigned* dst = S + (row * LDR + kq) / 2;
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) {
             uint2 q;
-            q.x = pack_bf16(a[pl], b[pl]);
-            q.y = pack_bf16(c[pl], d[pl]);
+            q.x = ab[pl];
+            q.y = cd[pl];
             *reinterpret_cast<uint2*>(dst + pl * (SBK / 2)) = q;
           }
         } else {
           const int kp = idx / (R / 4), r4 = (idx % (R / 4)) * 4;
-          __bf16 e0[3], o0[3], e1[3], o1[3], e2[3], o2[3], e3[3], o3[3];
-          split_planes<NPL>(v[i].x, e0); split_planes<NPL>(w[i].x, o0);
-          split_planes<NPL>(v[i].y, e1); split_planes<NPL>(w[i].y, o1);
-          split_planes<NPL>(v[i].z, e2); split_planes<NPL>(w[i].z, o2);
-          split_planes<NPL>(v[i].w, e3); split_planes<NPL>(w[i].w, o3);
+          // (even k, odd k) pairs of the four rows: the conversions take one value of each row vector (v_cvt_pk_bf16_f32 has
+          // two independent sources), the exact subtractions run on the rows' own register pairs (v_pk_add_f32)
+          uint4 q[3];
+          split_rows4<NPL>(v[i], w[i], q);
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) {
-            uint4 q;
-            q.x = pack_bf16(e0[pl], o0[pl]); q.y = pack_bf16(e1[pl], o1[pl]);
-            q.z = pack_bf16(e2[pl], o2[pl]); q.w = pack_bf16(e3[pl], o3[pl]);
-            *reinterpret_cast<uint4*>(S + (pl * KP + kp) * R + r4) = q;
-          }
+          for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(S + (pl * KP + kp) * R + r4) = q[pl];
         }
       }
     }
@@ -1155,17 +1197,27 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, ks, af[i]);
 #pragma unroll
       for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, ks, bf[j]);
+      // small terms first; term-major over the MT x NT accumulators (same sums, bit for bit): consecutive MFMAs write
+      // DIFFERENT accumulators, so none waits for its predecessor's result (six back-to-back MFMAs on one accumulator are a
+      // dependent chain: RSCOTR_X6_CHAIN below restores that order for A/B builds)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#ifdef RSCOTR_X6_CHAIN
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {  // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int tm = 0; tm < 6; ++tm)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tm]], bf[j][PB[tm]], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+      for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tm]], bf[j][PB[tm]], acc[i][j], 0, 0, 0);
+#endif
     }
   };
   if (PIPE >= 2) {
