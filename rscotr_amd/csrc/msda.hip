@@ -171,6 +171,29 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) {
   return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
 }
 
+// Reduce-scatter over a lane group (see msda_bwd_kernel): one butterfly step at lane offset O on N live values per lane; the
+// lane whose `sub & O` is clear keeps the first ceil(N / 2) values, its partner the rest (zero-padded), each adding what the
+// other sends.  rs_final<N, O>() = values per lane after the steps O, O / 2, ..., 1.
+template <int N, int O>
+constexpr int rs_final() {
+  if constexpr (O == 0) return N; else return rs_final<(N + 1) / 2, O / 2>();
+}
+template <int N0, int N, int O>
+__device__ __forceinline__ void rs_steps(float (&cur)[N0], int sub, int& base, int& rend) {
+  if constexpr (O > 0) {
+    constexpr int KEEP = (N + 1) / 2;
+    const bool hi = (sub & O) != 0;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {  // (writes slots < KEEP only: slot i + KEEP is still this step's input)
+      const float lo_v = cur[i], hi_v = (i + KEEP < N) ? cur[i + KEEP] : 0.f;
+      const float mine = hi ? hi_v : lo_v, other = hi ? lo_v : hi_v;
+      cur[i] = mine + __shfl_xor(other, O, 64);
+    }
+    if (hi) base += KEEP; else rend = min(rend, base + KEEP);
+    rs_steps<N0, KEEP, O / 2>(cur, sub, base, rend);
+  }
+}
+
 // Tile geometry the sample kernel needs for the BLOCK MASKS of the tile-accumulation backward (see that section): per level,
 // reciprocal tile edges (in bins) and tiles per row.  mask[(b h, level, query tile of the sample kernel)] has bit
 // (tile & 63) set iff one of the block's samples has its bin in that tile: the tile workgroups skip the other blocks.
@@ -285,6 +308,8 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
       v3[p] = ld4(vl + (long)g[p].i3 * tok_stride, g[p].ok3);
       v4[p] = ld4(vl + (long)g[p].i4 * tok_stride, g[p].ok4);
     }
+    float part[3 * P];
+    unsigned inmask = 0u;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float hh = g[p].hh, hw = g[p].hw, lh = g[p].lh, lw = g[p].lw;
@@ -299,18 +324,34 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
       // d(sample)/d(h_im), d(sample)/d(w_im), and the sample itself, dotted with the grads
       const float d1 = dot4(top, v1[p]), d2 = dot4(top, v2[p]);
       const float d3 = dot4(top, v3[p]), d4 = dot4(top, v4[p]);
-      float gh = -hw * d1 - lw * d2 + hw * d3 + lw * d4;
-      float gw = -hh * d1 + hh * d2 - lh * d3 + lh * d4;
-      float ga = w1 * dot4(go, v1[p]) + w2 * dot4(go, v2[p]) + w3 * dot4(go, v3[p]) +
-                 w4 * dot4(go, v4[p]);
-      gh = group_sum<G>(gh);
-      gw = group_sum<G>(gw);
-      ga = group_sum<G>(ga);
-      if (sub == 0) {
-        const bool in = g[p].in;
-        s_gloc[(r * LP + l * P + p) * 2 + 0] = in ? (float)Wl * gw : 0.f;
-        s_gloc[(r * LP + l * P + p) * 2 + 1] = in ? (float)Hl * gh : 0.f;
-        s_gattn[r * LP + l * P + p] = in ? ga : 0.f;
+      // this lane's share (its 4 channels) of the sample's three sums: [3 p] = d/d(w_im), [3 p + 1] = d/d(h_im), [3 p + 2] = d/d(weight)
+      part[3 * p + 0] = -hh * d1 + hh * d2 - lh * d3 + lh * d4;
+      part[3 * p + 1] = -hw * d1 - lw * d2 + hw * d3 + lw * d4;
+      part[3 * p + 2] = w1 * dot4(go, v1[p]) + w2 * dot4(go, v2[p]) + w3 * dot4(go, v3[p]) + w4 * dot4(go, v4[p]);
+      if (g[p].in) inmask |= 1u << p;
+    }
+    // the 3 P sums of the level over the G lanes of the group as a REDUCE-SCATTER: at every butterfly step a lane keeps one
+    // half of the values and sends the other (12 values on 8 lanes: 6 + 3 + 2 = 11 exchanges against 36 for one all-reduce
+    // per value); the pairing of the steps is the butterfly's (offsets G/2 ... 1), so every sum is the same float as before.
+    // A lane ends with the values base .. base + NF - 1 (those below rend are real)
+    {
+      constexpr int N0 = 3 * P;
+      int base = 0, rend = N0;
+      float cur[N0];
+#pragma unroll
+      for (int i = 0; i < N0; ++i) cur[i] = part[i];
+      rs_steps<N0, N0, G / 2>(cur, sub, base, rend);
+      constexpr int NF = rs_final<N0, G / 2>();
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int idx = base + i;
+        if (idx < rend) {
+          const int pp = (idx * 11) >> 5, k = idx - 3 * pp;  // idx / 3 for idx < 32
+          const bool in = (inmask >> pp) & 1u;
+          const float val = cur[i];
+          if (k == 2) s_gattn[r * LP + l * P + pp] = in ? val : 0.f;
+          else s_gloc[(r * LP + l * P + pp) * 2 + k] = in ? (k == 0 ? (float)Wl : (float)Hl) * val : 0.f;
+        }
       }
     }
   }
