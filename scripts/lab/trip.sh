@@ -1,4 +1,2 @@
-python -m pytest tests/test_gemm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -2
-echo "== WS=1"; python scripts/bench_gemm.py 2>/dev/null | grep -v "^/opt"
-echo "== WS=0"; RSCOTR_BF16X6_WS=0 python scripts/bench_gemm.py 2>/dev/null | grep -v "^/opt"
-bash scripts/gpu_ab_bench.sh r3_ws5 "" "RSCOTR_BF16X6_WS=0"
+RSCOTR_DIST_SINGLE=1 python bench.py --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/r3_ds.json 2> gpurun_out/r3_ds.err; tail -c 1500 gpurun_out/r3_ds.err; head -c 300 gpurun_out/r3_ds.json
+bash scripts/gpu_ab_bench.sh r3_grp "" "RSCOTR_DW_GROUP_X6=1" "RSCOTR_DW_GROUP_X6=3" "RSCOTR_DW_GROUP_MAX=70000" "RSCOTR_DW_GROUP_WGS=6144"
