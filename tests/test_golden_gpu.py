@@ -79,3 +79,12 @@ def test_upsample_ce_matches_torch_golden(cuda):
     assert abs(float(loss) - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
     assert abs(float(acc) - float(z['acc'])) <= 1e-3
     assert _rel(logit.grad.cpu().numpy(), z['dlogit']) < 1e-4
+
+
+def test_sine_embed_kernel_matches_reference_vectors(cuda):
+    """rscotr_sine_embed4 against the output of the REFERENCE'S OWN gen_sineembed_for_position
+    (models/multi/bbox_head/transformer.py:43-76, run in the build container: tests/golden/make_reference_golden.py)."""
+    from rscotr_amd import ops
+    z = _load('reference_static.npz')
+    out = ops.sine_embed4(torch.from_numpy(z['sine4_in']).to(cuda)).cpu().numpy()
+    assert np.abs(out - z['sine4_out']).max() < 2e-4  # fp32 sin / cos of arguments up to 2 pi
