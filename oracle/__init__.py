@@ -12,10 +12,11 @@ What it restates
   scipy (unpinned) — README.md:71-82, requirement.txt:1-3 of the reference) the published
   algorithm of that pinned version is restated and the reference's own call site is cited.
 
-PARITY UNPINNED by the reference, three self-contained functions excepted: the reference ships
+PARITY UNPINNED by the reference, its self-contained functions excepted: the reference ships
 no tests, golden vectors or fixtures for this path and cannot be imported
 here (mmcv/mmdet/mmseg/mmcls absent, no network).  What of it runs without those libraries —
-gen_sineembed_for_position, extract_dn_outputs, get_num_groups — was run as it stands in the
+gen_sineembed_for_position, extract_dn_outputs, get_num_groups, Mask2FormerHead.forward_head,
+MTL._parse_losses, the iteration strategies' __call__ — was run as it stands in the
 build container and its outputs are committed (tests/golden/reference_static.npz,
 tests/golden/make_reference_golden.py).  The rest of the restatement is pinned by independent primitives instead
 (`F.grid_sample`, `torch.nn.MultiheadAttention`, `F.layer_norm/group_norm/conv2d/unfold`,

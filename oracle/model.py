@@ -338,6 +338,19 @@ def cls_losses(x, soft_label, P, smooth=0.1):
 # seg — models/multi/seg_head/pixel_decoder.py:80-171, mask2former_head.py:111-205, mmseg 0.28
 # BaseDecodeHead.losses
 # ------------------------------------------------------------------------------------------
+def seg_forward_head(dec_out, mask_feature, target_size, P, heads=8):
+    """Mask2FormerHead.forward_head, scheme 2 (models/multi/seg_head/mask2former_head.py:111-137): dec_out (Q,B,C)
+    sequence-first, mask_feature (B,C,h,w) -> (mask_pred (B,Q,h,w), attn_mask bool (B*heads,Q,th*tw)).  Pinned to the
+    reference's own function: tests/golden/reference_static.npz."""
+    d = _ln(dec_out, P, 'seg_head.transformer_decoder.post_norm').transpose(0, 1)
+    me = _lin(ops.relu(_lin(ops.relu(_lin(d, P, 'seg_head.mask_embed.0')), P, 'seg_head.mask_embed.2')), P, 'seg_head.mask_embed.4')
+    mp = torch.einsum('bqd,bdhw->bqhw', me, mask_feature)
+    am = F.interpolate(mp, target_size, mode='bilinear', align_corners=False)
+    am = am.flatten(2).unsqueeze(1).repeat(1, heads, 1, 1).flatten(0, 1)
+    am = (am.sigmoid() < 0.5).detach()
+    return mp, am
+
+
 def seg_forward(neck_feats, P, cfg, enc_layers, inject_masks=None):
     """`inject_masks`: optional list (one per decoder layer) of the boolean attention masks to USE
     instead of the ones computed here (the computed ones are still returned): the masks are hard
@@ -363,13 +376,7 @@ def seg_forward(neck_feats, P, cfg, enc_layers, inject_masks=None):
     qe = P['seg_head.query_embed.weight'].unsqueeze(1).repeat(1, B, 1)
 
     def forward_head(dec_out, target_size):
-        d = _ln(dec_out, P, 'seg_head.transformer_decoder.post_norm').transpose(0, 1)
-        me = _lin(ops.relu(_lin(ops.relu(_lin(d, P, 'seg_head.mask_embed.0')), P, 'seg_head.mask_embed.2')), P, 'seg_head.mask_embed.4')
-        mp = torch.einsum('bqd,bdhw->bqhw', me, mask_feature)
-        am = F.interpolate(mp, target_size, mode='bilinear', align_corners=False)
-        am = am.flatten(2).unsqueeze(1).repeat(1, heads, 1, 1).flatten(0, 1)
-        am = (am.sigmoid() < 0.5).detach()
-        return mp, am
+        return seg_forward_head(dec_out, mask_feature, target_size, P, heads)
 
     nl = scfg['transformer_decoder']['num_layers']
     mp, am = forward_head(qf, outs[0].shape[-2:])
@@ -783,9 +790,16 @@ def forward_train(P, cfg, batch, rnd=None, record=None):
 
 
 def parse_losses(losses):
+    """MTL._parse_losses, single process (models/multi/multitask_learner.py:275-304); pinned to the reference's own
+    function: tests/golden/reference_static.npz."""
     log_vars = OrderedDict()
     for k, v in losses.items():
-        log_vars[k] = v.mean()
+        if isinstance(v, torch.Tensor):
+            log_vars[k] = v.mean()
+        elif isinstance(v, list):
+            log_vars[k] = sum(x.mean() for x in v)
+        else:
+            raise TypeError(f'{k} is not a tensor or list of tensors')
     loss = sum(v for k, v in log_vars.items() if 'loss' in k)
     log_vars['loss'] = loss
     return loss, OrderedDict((k, float(v.item())) for k, v in log_vars.items())

@@ -88,3 +88,33 @@ def test_sine_embed_kernel_matches_reference_vectors(cuda):
     z = _load('reference_static.npz')
     out = ops.sine_embed4(torch.from_numpy(z['sine4_in']).to(cuda)).cpu().numpy()
     assert np.abs(out - z['sine4_out']).max() < 2e-4  # fp32 sin / cos of arguments up to 2 pi
+
+
+def test_seg_forward_head_matches_reference_vectors(cuda):
+    """The product's Mask2FormerHead.forward_head on the HIP path (LayerNorm, the three-layer mask embedding as MFMA GEMMs,
+    the mask logits on the batched GEMM, the fused resize + `sigmoid < 0.5` attention-mask kernel) against what the
+    REFERENCE'S OWN forward_head returned for the same seeded weights and inputs
+    (models/multi/seg_head/mask2former_head.py:111-137, scheme 2; tests/golden/make_reference_golden.py)."""
+    import types
+    import torch.nn as nn
+    from rscotr_amd.seg_head import Mask2FormerHead
+    z = _load('reference_static.npz')
+    C = z['fh_norm_w'].shape[0]
+    norm = nn.LayerNorm(C)
+    embed = nn.Sequential(nn.Linear(C, C), nn.ReLU(), nn.Linear(C, C), nn.ReLU(), nn.Linear(C, C))
+    with torch.no_grad():
+        norm.weight.copy_(torch.from_numpy(z['fh_norm_w']))
+        norm.bias.copy_(torch.from_numpy(z['fh_norm_b']))
+        for i in (0, 2, 4):
+            embed[i].weight.copy_(torch.from_numpy(z[f'fh_w{i}']))
+            embed[i].bias.copy_(torch.from_numpy(z[f'fh_b{i}']))
+    heads = int(z['fh_heads'])
+    head = types.SimpleNamespace(transformer_decoder=types.SimpleNamespace(post_norm=norm.to(cuda)), mask_embed=embed.to(cuda),
+                                 num_heads=heads)
+    dec_out = torch.from_numpy(z['fh_dec_out']).transpose(0, 1).contiguous().to(cuda)   # the product is batch-first
+    with torch.no_grad():
+        mp, am = Mask2FormerHead.forward_head(head, dec_out, torch.from_numpy(z['fh_mask_feature']).to(cuda), (6, 5))
+    assert _rel(mp.cpu().numpy(), z['fh_seg_mask']) < 1e-5
+    want = z['fh_attn_mask'].reshape(mp.shape[0], heads, mp.shape[1], -1)
+    assert (want == want[:, :1]).all()                  # the reference tiles one mask over the heads
+    assert np.array_equal(am.cpu().numpy(), want[:, 0])  # bit for bit (no logit within rounding of 0 in these vectors)
