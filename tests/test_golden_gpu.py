@@ -118,3 +118,25 @@ def test_seg_forward_head_matches_reference_vectors(cuda):
     want = z['fh_attn_mask'].reshape(mp.shape[0], heads, mp.shape[1], -1)
     assert (want == want[:, :1]).all()                  # the reference tiles one mask over the heads
     assert np.array_equal(am.cpu().numpy(), want[:, 0])  # bit for bit (no logit within rounding of 0 in these vectors)
+
+
+def test_mlvl_cls_pooling_schemes_match_reference_vectors(cuda):
+    """The product's MlvlClsHead.pre_logits (token projections on the HIP GEMM) against the reference's own
+    pre_logits_3 / 5 / 6 / 7 outputs (models/multi/cls_head/mlvl_cls_head.py:88-119)."""
+    import types
+    import torch.nn as nn
+    from rscotr_amd.cls_head import MlvlClsHead
+    z = _load('reference_static.npz')
+    feats = [torch.from_numpy(z[f'cls_feat{i}']).to(cuda) for i in range(4)]
+    for scheme in (3, 5, 6, 7):
+        head = types.SimpleNamespace(scheme=scheme)
+        if scheme != 3:
+            w = torch.from_numpy(z[f'cls_w{scheme}'])
+            head.out_proj = nn.Linear(w.shape[1], 1).to(cuda)
+            with torch.no_grad():
+                head.out_proj.weight.copy_(w)
+                head.out_proj.bias.copy_(torch.from_numpy(z[f'cls_b{scheme}']))
+        head._token_proj = types.MethodType(MlvlClsHead._token_proj, head)
+        with torch.no_grad():
+            got = MlvlClsHead.pre_logits(head, feats).cpu().numpy()
+        assert _rel(got, z[f'cls_token{scheme}']) < 1e-5, scheme
