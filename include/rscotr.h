@@ -50,9 +50,9 @@ int rscotr_prof_disable(void);
  *   attn (B,Nq,H,L,P) | out (B,Nq,H*D).  D in {16,32,64}, P in {1,2,4,8}.
  * Backward: grad_loc / grad_attn are fully overwritten.  grad_value (B,Nk,H,D), by what the caller provides:
  *   shapes_host = HOST copy of spatial_shapes (L <= 8) + rscotr_msda_bwd_tiled_workspace() bytes: TILE ACCUMULATION (the
- *     default of rscotr_amd.ops) — the sample kernel leaves one record per sample; one workgroup per (b, h, level, tile of
- *     16 x 8 bins, sample chunk) scans the level's records, keeps those of its tile in sample order, sorts them by bin in
- *     LDS and sums every bin's four tap rows in registers; a combine kernel folds the tiles' cells per token in fixed
+ *     default of rscotr_amd.ops) — the sample kernel leaves one 4-byte bin word per sample; one workgroup per (b, h, level,
+ *     tile of 16 x 8 bins, sample chunk) scans the level's bin words, keeps those of its tile in sample order, sorts them by
+ *     bin in LDS, re-derives every kept sample's tap weights from loc / attn and sums every bin's four tap rows in registers; a combine kernel folds the tiles' cells per token in fixed
  *     order: fully overwritten, no atomics, BIT-REPRODUCIBLE, 3 launches;
  *   shapes_host NULL + a `workspace` of rscotr_msda_bwd_workspace() bytes (16-byte aligned, contents irrelevant): the
  *     samples are counting-sorted by destination token (one wavefront per chunk: the ranks, hence the summation order,

@@ -32,6 +32,15 @@ def test_train_step_main_config_256(task, cuda):
     check_step_pair(model, out, oout, rec, orec, P)
 
 
+def test_cls_step_224_bs1_matches_oracle(cuda):
+    """BASELINE configs[0]'s shape (Swin-T, RESISC45 classification, 224 x 224, bs = 1: 3 136 stage-1 tokens, 7 x 7 at
+    stage 4) on the HIP path: the cls iteration of the MTL model against the oracle — the reference's CPU-runnable case."""
+    cfg, mcfg = load_model_cfg(tiny=False)
+    model = build_model(mcfg, seed=5).to(cuda)
+    out, oout, rec, orec, P = run_step_pair(model, mcfg, 'cls', 224, seed=13, device=cuda, batch_size=1, fp64=True)
+    check_step_pair(model, out, oout, rec, orec, P)
+
+
 @pytest.mark.parametrize('prec', [0, 3])
 @pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
 def test_train_step_main_config_512(task, prec, cuda):
