@@ -26,6 +26,30 @@ def _gt_host(batch):
     return None if hb is None or hl is None else (hb, hl)
 
 
+def _recover_from_failed_capture(graph, cause=None):
+    """After an exception inside a stream capture: make sure the stream has left capture mode and swallow the error the
+    runtime still holds (HIP reports a failed call of a capturing stream once more at the NEXT API call).  A capture that
+    cannot be ended — this runtime keeps the stream capturing after `hipErrorStreamCaptureUnjoined`, seen with gloo
+    collectives on device tensors (tests/test_dist_gpu.py) — is fatal: nothing can be launched on that stream any more, so
+    the run stops HERE with the cause instead of failing somewhere later or hanging the other ranks in a collective."""
+    for _ in range(4):
+        try:
+            if graph is not None and torch.cuda.is_current_stream_capturing():
+                graph.capture_end()
+            torch.cuda.synchronize()
+            return
+        except RuntimeError:
+            continue
+    still = True
+    try:
+        still = torch.cuda.is_current_stream_capturing()
+    except RuntimeError:
+        pass
+    if still:
+        raise RuntimeError('capturing the iteration failed and the stream cannot leave capture mode; rerun with '
+                           f'RSCOTR_DIST_CAPTURE=0 (graph = forward + backward, eager exchange).  Cause: {cause}') from cause
+
+
 def _wait_watchdog_idle(limit=2.0):
     """Block until the RCCL process group's watchdog has RETIRED every collective issued so far (call after a device
     synchronise, before a stream goes into capture).  The watchdog polls the end events of its pending works, and HIP refuses
@@ -107,6 +131,11 @@ class GraphedTask:
         # last wait inside the graph.  `split` (RSCOTR_DIST_CAPTURE=0, or if capturing the collectives fails): the graph
         # holds forward + backward only; buckets, log vector and optimizer are issued eagerly after each replay.
         self.exchange_in_graph = runner.sync is not None and os.environ.get('RSCOTR_DIST_CAPTURE', '1') != '0'
+        if self.exchange_in_graph:
+            import torch.distributed as dist
+            # only RCCL collectives can ride in a hipGraph (gloo stages through the host on streams of its own: the capture
+            # ends "unjoined" and the stream stays in capture mode): any other backend takes the split form from the start
+            self.exchange_in_graph = dist.get_backend() == 'nccl'
         self.split = runner.sync is not None and not self.exchange_in_graph
         self._capture_agreed()
         self._replay()  # capture only records: this replay is the iteration prepare_step() announced
@@ -130,6 +159,7 @@ class GraphedTask:
             if not self.exchange_in_graph:
                 raise
             err = e
+            _recover_from_failed_capture(getattr(self, 'graph', None), e)
         if not self.exchange_in_graph:
             return
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.static['img'].device)

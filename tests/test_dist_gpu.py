@@ -63,3 +63,81 @@ def test_one_rank_distributed_paths_train_like_the_plain_run(cuda):
         assert abs(got['param_norm'] - plain['param_norm']) <= 1e-6 * plain['param_norm'], (extra, got, plain)
         for k, v in plain['losses'].items():
             assert abs(got['losses'][k] - v) <= 2e-3 * max(abs(v), 1e-3), (extra, k, got['losses'][k], v)
+
+
+_CHILD2 = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as dist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dev = torch.device('cuda:0')
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+try:
+    t = torch.ones(4, device=dev) * (rank + 1)
+    dist.all_reduce(t)
+    assert float(t[0]) == 3.0
+except Exception as e:  # this build's gloo cannot reduce device tensors: nothing to test
+    print('RESULT ' + json.dumps(dict(skip=f'gloo all_reduce on device tensors: {type(e).__name__}: {e}')))
+    dist.destroy_process_group(); sys.exit(0)
+from rscotr_amd import Config, MODELS
+from rscotr_amd.data import build_synthetic_multidataloader
+from rscotr_amd.runner import build_runner
+cfg = Config.fromfile(os.path.join(sys.argv[1], 'configs', 'multi', 'MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py'))
+torch.manual_seed(0); np.random.seed(2022)            # identical init and task order on every rank (tools/train.py:211-215)
+model = MODELS.build(cfg.model); model.init_weights(); model.to(dev).train()
+loader = build_synthetic_multidataloader(cfg, dev, size=256, batch_size=2, rank=rank)   # every rank draws its own batches
+runner = build_runner(model, cfg, loader, logger=lambda m: None)
+assert runner.sync is not None and runner.ctrl is not None
+losses = {}
+import warnings
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    with runner.on_stream():
+        for it in range(9):   # three rounds: eager (bucket plans), capture in the split form (gloo collectives cannot ride in
+            out = runner.train_iter()   # a hipGraph: graph = forward + backward, eager exchange + optimizer) + first replay, replay
+            losses.update({k: float(v) for k, v in out['log_vars'].items() if k.endswith('.loss')})
+torch.cuda.synchronize()
+fell_back = any('falls back' in str(x.message) or 'fall back' in str(x.message) for x in w)
+digest = hashlib.sha256(runner.optimizer.flat_p.detach().cpu().numpy().tobytes()).hexdigest()
+outs = [None] * world
+dist.all_gather_object(outs, dict(digest=digest, losses=losses, graphed=sorted(runner.graphed),
+                                  split=sorted(t for t, g in runner.graphed.items() if g.split), fell_back=fell_back))
+if rank == 0:
+    print('RESULT ' + json.dumps(outs))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(1500)
+def test_two_ranks_on_one_gpu_train_in_lockstep(cuda):
+    """The N > 1 loop end to end with real kernels (the box has one GPU: two gloo ranks share it, each with its own
+    batches): bucket plans agreed, gradients averaged, the det capacity and the graph-or-eager decision agreed on through
+    the control group, the split form of the captured iteration (graph = forward + backward, then the eager bucket exchange,
+    the packed log all-reduce, clip + AdamW), rank-averaged log variables — after three rounds both ranks hold bit-identical
+    parameters and report the same (rank-averaged) losses.  RCCL itself needs one GPU per rank: the driver's 8-GPU run."""
+    port = 29561
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', _CHILD2, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=1200))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('RESULT ')]
+    assert lines, (outs[0][0][-1500:], outs[0][1][-3000:], outs[1][1][-3000:])
+    res = json.loads(lines[-1][7:])
+    if isinstance(res, dict) and 'skip' in res:
+        pytest.skip(res['skip'])
+    a, b = res
+    assert a['graphed'] == b['graphed'] == ['cls', 'det', 'seg'] and a['split'] == b['split'] == ['cls', 'det', 'seg']
+    assert a['digest'] == b['digest'], 'the ranks hold different parameters after three rounds'
+    assert a['losses'] == b['losses'] and len(a['losses']) == 3 and all(v == v and abs(v) < 1e6 for v in a['losses'].values())
