@@ -171,7 +171,9 @@ class TextLoggerHook(_LoggerHook):
     def log(self, runner, tags, mode):
         if not _is_rank0():
             return
-        lr = runner.optimizer.base_lr.max() * runner.optimizer.lr_factor if hasattr(runner.optimizer, 'base_lr') else 0.0
+        # mmcv logs `runner.current_lr()[0]`: the first parameter group's rate (here: one group per parameter, the first is
+        # backbone.patch_embed.projection.weight with its lr_mult)
+        lr = float(runner.optimizer.base_lr[0]) * runner.optimizer.lr_factor if hasattr(runner.optimizer, 'base_lr') else 0.0
         rec = OrderedDict(mode=mode, epoch=getattr(runner, 'epoch', 0) + 1, iter=runner.iter)
         if mode == 'train':
             mem = int(torch.cuda.max_memory_allocated() / (1024 * 1024)) if torch.cuda.is_available() else 0
