@@ -128,8 +128,11 @@ class _LoggerHook:
             tags = self.history.average(self.interval)
             if ready:  # the evaluation hook published '{dataset}.{metric}' values
                 val = OrderedDict(runner.log_buffer_output)
-                runner.log_buffer_output.clear()
-                runner.log_buffer_ready = False
+                # every logger hook reports them; the LAST one clears the buffer (mmcv: `reset_flag` of the last LoggerHook)
+                loggers = [h for h in getattr(runner, 'hooks', []) if isinstance(h, _LoggerHook)]
+                if not loggers or loggers[-1] is self:
+                    runner.log_buffer_output.clear()
+                    runner.log_buffer_ready = False
                 self.log(runner, val, mode='val')
             if tags:
                 now = time.time()
