@@ -212,10 +212,32 @@ int rscotr_colsum_f32(const float* X, float* out, int M, int N, int ld, int accu
  * rscotr_layernorm_bwd_workspace(M, C) bytes (16-byte aligned) holds per-workgroup partial sums. */
 int rscotr_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
                          float* rstd, int M, int C, float eps, void* stream);
+/* rscotr_layernorm_fwd with a second output y2 = y + add[row % add_rows] (add (add_rows, C)): mmcv BaseTransformerLayer's
+ * `norm` step followed by an attention whose wrapper forms `query + query_pos` (mmcv MultiheadAttention.forward /
+ * MultiScaleDeformableAttention.forward as built from cfg ...potsdam.py:34-50,76-98,139-160) — the sum leaves the norm's
+ * own launch instead of an element-wise add; y2 carries no gradient of its own (the attention's backward produces
+ * d(query) and d(query_pos) from its projections). */
+int rscotr_layernorm_fwd_sum(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
+                             const float* add, int add_rows, float* y2, int M, int C, float eps, void* stream);
 int64_t rscotr_layernorm_bwd_workspace(int M, int C);
 int rscotr_layernorm_bwd(const float* dy, const float* x, const float* weight, const float* mean,
                          const float* rstd, float* dx, const float* dx_add, float* dweight, float* dbias, int M, int C,
                          float* workspace, int64_t workspace_bytes, void* stream);
+
+/* mmcv PatchMerging's `nn.Unfold(kernel_size=2, stride=2)` (zero "corner" padding for odd H / W) followed by its
+ * LayerNorm(4 Cin) (mmdet 2.25.1 SwinTransformer stages' `downsample`, cfg ...potsdam.py:9-25), one launch per direction:
+ * x (B, H, W, Cin) token map, y (B * ceil(H/2) * ceil(W/2), 4 Cin) with element c * 4 + kh * 2 + kw of token (i, j) =
+ * LN over that row of x[b, 2i + kh, 2j + kw, c]; the unfold is done by the norm's own loads (forward) and stores (dx,
+ * (B, H, W, Cin): every position written exactly once); results equal rscotr_layernorm_* on the gathered copy bit for
+ * bit.  Cin <= 512.  Backward ADDS dweight / dbias
+ * (4 Cin each); fold = 0 leaves the per-workgroup partial rows in `workspace` for rscotr_layernorm_flush (table row
+ * {workspace, dweight, dbias, workspace_bytes / (32 Cin), 4 Cin}). */
+int rscotr_patch_merge_norm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
+                                int B, int H, int W, int Cin, float eps, void* stream);
+int64_t rscotr_patch_merge_norm_bwd_workspace(int B, int H, int W, int Cin);
+int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, const float* weight, const float* mean, const float* rstd,
+                                float* dx, float* dweight, float* dbias, int B, int H, int W, int Cin, float* workspace,
+                                int64_t workspace_bytes, int fold, void* stream);
 
 /* Deferred parameter-gradient fold: rscotr_layernorm_bwd_partials = rscotr_layernorm_bwd without its second launch (the
  * per-workgroup partial rows stay in `part`, rscotr_layernorm_bwd_workspace() bytes, caller-owned until the flush);
@@ -263,6 +285,8 @@ int rscotr_swin_wattn_flush(const int64_t* table, int n, int total_heads, void* 
  * is rscotr_col2im3x3s2_tokens of the GEMM's dcol; GroupNorm(32, 256) runs on tokens.
  *   x, y, dy, dx (B, L, C) with C in {64, 128, 256}; mean_rstd (B, G, 2) written by forward; proj_ws (B, G, 2)
  *   scratch; dweight/dbias (C) ACCUMULATED (caller zeroes), may be NULL.  Ho = (H+1)/2, Wo = (W+1)/2.
+ *   dy_batch_stride (elements, >= L * C, % 4 == 0): dy may be one level's rows of a gradient laid out over the
+ *   concatenated levels (B, sum L_l, C) — the encoder input's gradient — read in place.
  *   workspace: rscotr_groupnorm_tokens_workspace() bytes of per-workgroup partial sums, folded in fixed order (no
  *   atomics: the statistics are bit-reproducible). */
 int64_t rscotr_groupnorm_tokens_workspace(int B, int L, int C, int G);
@@ -271,7 +295,7 @@ int rscotr_groupnorm_tokens_fwd(const float* x, const float* weight, const float
                                 int64_t workspace_bytes, void* stream);
 int rscotr_groupnorm_tokens_bwd(const float* dy, const float* x, const float* weight, const float* mean_rstd,
                                 float* dx, float* dweight, float* dbias, float* proj_ws, int B, int L, int C,
-                                int G, float* workspace, int64_t workspace_bytes, void* stream);
+                                int G, int64_t dy_batch_stride, float* workspace, int64_t workspace_bytes, void* stream);
 int rscotr_im2col3x3s2_tokens(const float* x, float* col, int B, int H, int W, int C, void* stream);
 int rscotr_col2im3x3s2_tokens(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
 

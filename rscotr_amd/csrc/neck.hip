@@ -27,7 +27,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ mean_rstd, float* __restrict__ part,
-                                                       int L, int C, int G, int tokens_per_block) {
+                                                       int L, int C, int G, int tokens_per_block, long dy_bstride = 0) {
   // part: [B][chunks][2 G + 2 C] = {sum f, sum f h} per group, then (MODE 1) dgamma | dbeta partials per channel
   const int LT = C >> 2;            // lanes per token row
   const int TPW = kWave / LT;       // token rows per wavefront step
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
       s1 += xv.x + xv.y + xv.z + xv.w;
       s2 += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
     } else {
-      const float4 d = reinterpret_cast<const float4*>(dy + off)[sub];
+      const float4 d = reinterpret_cast<const float4*>(dy + (long)b * dy_bstride + (long)t * C)[sub];
       const float4 xh = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
       s1 += gm.x * d.x + gm.y * d.y + gm.z * d.z + gm.w * d.w;
       s2 += gm.x * d.x * xh.x + gm.y * d.y * xh.y + gm.z * d.z * xh.z + gm.w * d.w * xh.w;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean_rstd,
                                                        const float* __restrict__ proj, float* __restrict__ out, int L,
-                                                       int C, int G, float inv_count) {
+                                                       int C, int G, float inv_count, long dy_bstride4 = 0) {
   const int C4 = C >> 2, gs4 = (C / G) >> 2;
   const long total = (long)gridDim.y * L * C4;  // gridDim.y = B
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)L * C4; i += (long)gridDim.x * 256) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       o.x = (xv.x - mu) * rs * gm.x + bt.x; o.y = (xv.y - mu) * rs * gm.y + bt.y;
       o.z = (xv.z - mu) * rs * gm.z + bt.z; o.w = (xv.w - mu) * rs * gm.w + bt.w;
     } else {
-      const float4 d = reinterpret_cast<const float4*>(dy)[off];
+      const float4 d = reinterpret_cast<const float4*>(dy)[(long)b * dy_bstride4 + i];
       const float p1 = proj[((long)b * G + g) * 2] * inv_count, p2 = proj[((long)b * G + g) * 2 + 1] * inv_count;
       o.x = rs * (gm.x * d.x - p1 - (xv.x - mu) * rs * p2); o.y = rs * (gm.y * d.y - p1 - (xv.y - mu) * rs * p2);
       o.z = rs * (gm.z * d.z - p1 - (xv.z - mu) * rs * p2); o.w = rs * (gm.w * d.w - p1 - (xv.w - mu) * rs * p2);
@@ -274,10 +274,13 @@ extern "C" int rscotr_groupnorm_tokens_fwd(const float* x, const float* weight, 
 
 extern "C" int rscotr_groupnorm_tokens_bwd(const float* dy, const float* x, const float* weight,
                                            const float* mean_rstd, float* dx, float* dweight, float* dbias,
-                                           float* proj_ws, int B, int L, int C, int G, float* workspace,
-                                           int64_t workspace_bytes, void* stream) {
+                                           float* proj_ws, int B, int L, int C, int G, int64_t dy_batch_stride,
+                                           float* workspace, int64_t workspace_bytes, void* stream) {
   if (int e = gn_check("rscotr_groupnorm_tokens_bwd", B, L, C, G)) return e;
   if (B == 0 || L == 0) return RSCOTR_OK;
+  if (dy_batch_stride < (int64_t)L * C || (dy_batch_stride & 3))
+    return fail(RSCOTR_E_SHAPE, "rscotr_groupnorm_tokens_bwd: dy batch stride %lld must be >= L * C and a multiple of 4",
+                (long long)dy_batch_stride);
   if (!dy || !x || !mean_rstd || !dx || !proj_ws) return fail(RSCOTR_E_ARG, "rscotr_groupnorm_tokens_bwd: null pointer");
   if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || (weight && !aligned16(weight)))
     return fail(RSCOTR_E_ALIGN, "rscotr_groupnorm_tokens_bwd: pointers must be 16-byte aligned");
@@ -286,12 +289,13 @@ extern "C" int rscotr_groupnorm_tokens_bwd(const float* dy, const float* x, cons
   hipStream_t s = (hipStream_t)stream;
   int tpb;
   const dim3 grid = gn_stats_grid(B, L, &tpb);
-  gn_stats_kernel<1><<<grid, 256, 0, s>>>(x, dy, weight, mean_rstd, workspace, L, C, G, tpb);
+  gn_stats_kernel<1><<<grid, 256, 0, s>>>(x, dy, weight, mean_rstd, workspace, L, C, G, tpb, (long)dy_batch_stride);
   gn_finalize_bwd_kernel<<<(std::max(B * G, 2 * C) + 255) / 256, 256, 0, s>>>(workspace, proj_ws, dweight, dbias, B, G, C,
                                                                               (int)grid.x);
   const float inv = 1.f / ((float)L * (float)(C / G));
   const int ax = (int)std::min<long>(((long)L * (C / 4) + 255) / 256, 1024);
-  gn_apply_kernel<1><<<dim3(ax, B), 256, 0, s>>>(x, dy, weight, nullptr, mean_rstd, proj_ws, dx, L, C, G, inv);
+  gn_apply_kernel<1><<<dim3(ax, B), 256, 0, s>>>(x, dy, weight, nullptr, mean_rstd, proj_ws, dx, L, C, G, inv,
+                                                 (long)(dy_batch_stride / 4));
   return check_launch("rscotr_groupnorm_tokens_bwd");
 }
 

@@ -17,12 +17,43 @@
 
 namespace rscotr {
 
-template <int G, int NV>
+// Patch-merging mode (MG): the normalised row is mmcv PatchMerging's nn.Unfold(2, stride 2) row of the token map x
+// (B, H, W, Cin) — element c * 4 + kh * 2 + kw of output token (b, i, j) is x[b, 2i + kh, 2j + kw, c], zero past H / W —
+// gathered by the LOADS of the norm itself: float4 column c of the unfold-ordered row is channel c at the four window
+// positions, so a lane reads its columns as four 4-byte loads (one per position, coalesced across the lanes' adjacent
+// channels) into the same registers the plain kernel fills with one 16-byte load.  Ownership, summation order, affine,
+// dgamma / dbeta and the y / dy accesses are the plain kernels': the result equals LayerNorm of the gathered copy bit for bit.
+struct MergeGeom {
+  int H, W, Cin;  // input map; output tokens (H + 1) / 2 x (W + 1) / 2, row width 4 Cin
+};
+
+// element offsets of the four window positions of output row `row` (-1: past the map, reads as zero)
+__device__ __forceinline__ void merge_rows(const MergeGeom& mg, long row, long (&off)[4]) {
+  const int Ho = (mg.H + 1) >> 1, Wo = (mg.W + 1) >> 1;
+  const int oj = (int)(row % Wo);
+  const long t = row / Wo;
+  const int oi = (int)(t % Ho);
+  const long b = t / Ho;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = 2 * oi + (k >> 1), xx = 2 * oj + (k & 1);
+    off[k] = (yy < mg.H && xx < mg.W) ? ((b * mg.H + yy) * mg.W + xx) * (long)mg.Cin : -1;
+  }
+}
+
+__device__ __forceinline__ float4 merge_load(const float* __restrict__ x, const long (&off)[4], int c) {
+  return make_float4(off[0] >= 0 ? x[off[0] + c] : 0.f, off[1] >= 0 ? x[off[1] + c] : 0.f,
+                     off[2] >= 0 ? x[off[2] + c] : 0.f, off[3] >= 0 ? x[off[3] + c] : 0.f);
+}
+
+template <int G, int NV, bool MG = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int M, int C, float eps) {
+                                                            int M, int C, float eps,
+                                                            const float* __restrict__ add = nullptr, int add_rows = 1,
+                                                            float* __restrict__ y2 = nullptr, MergeGeom mg = MergeGeom{}) {
   constexpr int RW = kWave / G;  // rows per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rw = lane / G;
@@ -40,10 +71,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const bool ok = row < M;
     float4 v[NV];
     float s = 0.f;
+    long off[4];
+    if (MG) merge_rows(mg, ok ? row : 0, off);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = sub + i * G;
-      v[i] = (ok && c < C4) ? reinterpret_cast<const float4*>(x + row * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MG) v[i] = (ok && c < C4) ? merge_load(x, off, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else v[i] = (ok && c < C4) ? reinterpret_cast<const float4*>(x + row * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mu = group_sum<G>(s) * invC;
@@ -68,6 +102,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
           o.z = (v[i].z - mu) * rs * wv[i].z + bv[i].z;
           o.w = (v[i].w - mu) * rs * wv[i].w + bv[i].w;
           reinterpret_cast<float4*>(y + row * C)[c] = o;
+          if (y2) {  // second output: y + add[row % add_rows] (the positional embedding the next attention adds to its query)
+            const float4 a = reinterpret_cast<const float4*>(add + (row % add_rows) * C)[c];
+            reinterpret_cast<float4*>(y2 + row * C)[c] = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+          }
         }
       }
       if (sub == 0) {
@@ -78,14 +116,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-template <int G, int NV>
+template <int G, int NV, bool MG = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             const float* __restrict__ dres,
-                                                            float* __restrict__ part, int M, int C) {
+                                                            float* __restrict__ part, int M, int C,
+                                                            MergeGeom mg = MergeGeom{}) {
   constexpr int RW = kWave / G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rw = lane / G;
@@ -105,12 +144,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float mu = ok ? mean[row] : 0.f, rs = ok ? rstd[row] : 0.f;
     float4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
+    long off[4];
+    if (MG) merge_rows(mg, ok ? row : 0, off);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = sub + i * G;
       const bool in = ok && c < C4;
       const float4 d = in ? reinterpret_cast<const float4*>(dy + row * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 xv = in ? reinterpret_cast<const float4*>(x + row * C)[c] : make_float4(mu, mu, mu, mu);
+      const float4 xv = !in ? make_float4(mu, mu, mu, mu)
+                            : (MG ? merge_load(x, off, c) : reinterpret_cast<const float4*>(x + row * C)[c]);
       xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
       ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
       aw[i].x += d.x * xh[i].x; aw[i].y += d.y * xh[i].y; aw[i].z += d.z * xh[i].z; aw[i].w += d.w * xh[i].w;
@@ -129,11 +171,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.y = rs * (g[i].y - m1 - xh[i].y * m2);
           o.z = rs * (g[i].z - m1 - xh[i].z * m2);
           o.w = rs * (g[i].w - m1 - xh[i].w * m2);
-          if (dres) {  // gradient of the residual branch that forks at this LayerNorm's input
-            const float4 r = reinterpret_cast<const float4*>(dres + row * C)[c];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          if (!MG) {
+            if (dres) {  // gradient of the residual branch that forks at this LayerNorm's input
+              const float4 r = reinterpret_cast<const float4*>(dres + row * C)[c];
+              o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            reinterpret_cast<float4*>(dx + row * C)[c] = o;
+          } else {  // channel c back to its four window positions
+            if (off[0] >= 0) dx[off[0] + c] = o.x;
+            if (off[1] >= 0) dx[off[1] + c] = o.y;
+            if (off[2] >= 0) dx[off[2] + c] = o.z;
+            if (off[3] >= 0) dx[off[3] + c] = o.w;
           }
-          reinterpret_cast<float4*>(dx + row * C)[c] = o;
         }
       }
     }
@@ -153,8 +202,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       ab[i].z += __shfl_xor(ab[i].z, o, 64); ab[i].w += __shfl_xor(ab[i].w, o, 64);
     }
     if (rw == 0) {
-      red[0][wave][i * G + sub] = aw[i];
-      red[1][wave][i * G + sub] = ab[i];
+      red[0][wave][sub + i * G] = aw[i];
+      red[1][wave][sub + i * G] = ab[i];
     }
   }
   __syncthreads();
@@ -288,6 +337,25 @@ extern "C" int rscotr_layernorm_fwd(const float* x, const float* weight, const f
   return check_launch("rscotr_layernorm_fwd");
 }
 
+extern "C" int rscotr_layernorm_fwd_sum(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                                        float* rstd, const float* add, int add_rows, float* y2, int M, int C, float eps,
+                                        void* stream) {
+  if (M < 0 || C <= 0 || add_rows <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd_sum: bad shape M=%d C=%d add_rows=%d", M, C, add_rows);
+  if (C % 4 != 0 || C > 2048) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd_sum: C=%d must be a multiple of 4, <= 2048", C);
+  if (M == 0) return RSCOTR_OK;
+  if (!x || !y || !add || !y2) return fail(RSCOTR_E_ARG, "rscotr_layernorm_fwd_sum: null pointer");
+  if (!aligned16(x) || !aligned16(y) || !aligned16(add) || !aligned16(y2) || (weight && !aligned16(weight)) ||
+      (bias && !aligned16(bias)))
+    return fail(RSCOTR_E_ALIGN, "rscotr_layernorm_fwd_sum: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+#define CALL(G, NV)                                                                                                  \
+  layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps, add, \
+                                                                         add_rows, y2)
+  RSCOTR_LN_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("rscotr_layernorm_fwd_sum");
+}
+
 static int ln_bwd_blocks(int M, int C) {
   const int c4 = C >> 2;
   const int G = c4 <= 8 ? 8 : c4 <= 16 ? 16 : c4 <= 32 ? 32 : 64;
@@ -351,6 +419,72 @@ extern "C" int rscotr_layernorm_bwd_partials(const float* dy, const float* x, co
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("rscotr_layernorm_bwd_partials");
+}
+
+// ---- mmcv PatchMerging's unfold + LayerNorm(4 Cin) as one launch per direction (MG instantiations above) ----------------
+static int pm_bwd_blocks(long M, int Cin) { return ln_bwd_blocks((int)M, 4 * Cin); }
+
+static int pm_check(const char* who, int B, int H, int W, int Cin, long* M) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return fail(RSCOTR_E_SHAPE, "%s: bad shape B=%d H=%d W=%d Cin=%d", who, B, H, W, Cin);
+  if (Cin > 512) return fail(RSCOTR_E_SHAPE, "%s: Cin=%d must be <= 512", who, Cin);
+  *M = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  if (*M > 0x7fffffffL) return fail(RSCOTR_E_SHAPE, "%s: too many output tokens", who);
+  return RSCOTR_OK;
+}
+
+extern "C" int rscotr_patch_merge_norm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                                           float* rstd, int B, int H, int W, int Cin, float eps, void* stream) {
+  long M;
+  if (int e = pm_check("rscotr_patch_merge_norm_fwd", B, H, W, Cin, &M)) return e;
+  if (M == 0) return RSCOTR_OK;
+  if (!x || !y) return fail(RSCOTR_E_ARG, "rscotr_patch_merge_norm_fwd: null pointer");
+  if (!aligned16(x) || !aligned16(y) || (weight && !aligned16(weight)) || (bias && !aligned16(bias)))
+    return fail(RSCOTR_E_ALIGN, "rscotr_patch_merge_norm_fwd: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const MergeGeom mg{H, W, Cin};
+  const int C = 4 * Cin;
+#define CALL(G, NV)                                                                                                     \
+  layernorm_fwd_kernel<G, NV, true><<<ln_blocks((int)M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, (int)M, C, \
+                                                                                    eps, nullptr, 1, nullptr, mg)
+  RSCOTR_LN_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("rscotr_patch_merge_norm_fwd");
+}
+
+extern "C" int64_t rscotr_patch_merge_norm_bwd_workspace(int B, int H, int W, int Cin) {
+  long M;
+  if (pm_check("rscotr_patch_merge_norm_bwd_workspace", B, H, W, Cin, &M) || M == 0) return 0;
+  return (int64_t)pm_bwd_blocks(M, Cin) * 2 * (4 * Cin) * 4;
+}
+
+extern "C" int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, const float* weight, const float* mean,
+                                           const float* rstd, float* dx, float* dweight, float* dbias, int B, int H, int W,
+                                           int Cin, float* workspace, int64_t workspace_bytes, int fold, void* stream) {
+  long M;
+  if (int e = pm_check("rscotr_patch_merge_norm_bwd", B, H, W, Cin, &M)) return e;
+  if (M == 0) return RSCOTR_OK;
+  if (!dy || !x || !mean || !rstd) return fail(RSCOTR_E_ARG, "rscotr_patch_merge_norm_bwd: null pointer");
+  if (!aligned16(dy) || !aligned16(x) || (dx && !aligned16(dx)) || (weight && !aligned16(weight)) ||
+      (dweight && !aligned16(dweight)) || (dbias && !aligned16(dbias)))
+    return fail(RSCOTR_E_ALIGN, "rscotr_patch_merge_norm_bwd: pointers must be 16-byte aligned");
+  const int C = 4 * Cin;
+  const bool params = !fold || dweight || dbias;
+  const int nb = pm_bwd_blocks(M, Cin);
+  if (params && (!workspace || !aligned16(workspace) || workspace_bytes < (int64_t)nb * 2 * C * 4))
+    return fail(RSCOTR_E_ARG, "rscotr_patch_merge_norm_bwd: workspace of rscotr_patch_merge_norm_bwd_workspace() bytes required");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = params ? workspace : nullptr;
+  const MergeGeom mg{H, W, Cin};
+#define CALL(G, NV) \
+  layernorm_bwd_kernel<G, NV, true><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, nullptr, part, (int)M, C, mg)
+  RSCOTR_LN_DISPATCH(C, CALL);
+#undef CALL
+  if (int e = check_launch("rscotr_patch_merge_norm_bwd")) return e;
+  if (fold && params) {
+    layernorm_bwd_final_kernel<<<(2 * C + 63) / 64, 256, 0, s>>>(part, dweight, dbias, nb, C);
+    return check_launch("rscotr_patch_merge_norm_bwd (final)");
+  }
+  return RSCOTR_OK;
 }
 
 // table: device (n, 5) int64 rows {partial rows, dweight | 0, dbias | 0, G, C}; wgmap: device (nwg, 2) int32 rows

@@ -156,9 +156,11 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.constant_(self.output_proj.bias, 0.)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, offset_norm=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, offset_norm=None, query_sum=None,
+                **kwargs):
         """Batch-first: query (B,Nq,C), value (B,Nk,C); reference_points (B,Nq,L,2|4);
-        spatial_shapes (L,2) int64 device tensor; offset_norm (L,2) float (W_l,H_l)."""
+        spatial_shapes (L,2) int64 device tensor; offset_norm (L,2) float (W_l,H_l); query_sum = query + query_pos where
+        the producer of `query` already formed it (ops.layer_norm_sum)."""
         if identity is None:
             identity = query
         # projections, softmax / location arithmetic, sampling kernel, output projection + identity: one autograd node
@@ -168,7 +170,7 @@ class MultiScaleDeformableAttention(nn.Module):
             offset_norm, self.num_heads, self.num_levels, self.num_points,
             self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
             self.attention_weights.bias, self.value_proj.weight, self.value_proj.bias, self.output_proj.weight,
-            self.output_proj.bias)
+            self.output_proj.bias, q_sum=query_sum if query_pos is not None else None)
 
 
 @MODELS.register_module()
@@ -184,7 +186,7 @@ class MultiheadAttention(nn.Module):
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, 0.0)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
-                key_padding_mask=None, **kwargs):
+                key_padding_mask=None, query_sum=None, key_sum=None, **kwargs):
         if key_padding_mask is not None:
             raise NotImplementedError('key_padding_mask is never set for dense attention on this path')
         if key is None:
@@ -200,7 +202,9 @@ class MultiheadAttention(nn.Module):
         # the positional adds, the projections, the attention core, the output projection and the identity are one autograd
         # node (ops._MHA): what meets at `query` in backward is merged in GEMM epilogues
         return ops.mha(query, key, value, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                       self.num_heads, attn_mask, identity=identity, mask_mode=mode, q_pos=query_pos, k_pos=key_pos)
+                       self.num_heads, attn_mask, identity=identity, mask_mode=mode, q_pos=query_pos, k_pos=key_pos,
+                       q_sum=query_sum if query_pos is not None else None,
+                       k_sum=key_sum if (key_pos is not None and key is not query) else None)
 
 
 @MODELS.register_module()
@@ -225,35 +229,69 @@ class BaseTransformerLayer(nn.Module):
         self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
-                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+                query_key_padding_mask=None, key_padding_mask=None, query_sum=None, key_sum=None, next_query_pos=None,
+                **kwargs):
+        """query_sum: query + (the first attention's query_pos) where the caller already has it; key_sum: key + key_pos
+        likewise (cross-attention); next_query_pos: the positional embedding the NEXT consumer of this layer's output adds
+        to it — the layer's last `norm` then emits that sum from its own launch and the result is (output, output +
+        next_query_pos).  Sums are values only (no gradient of their own): every `norm` that is followed by an attention
+        emits `norm(x) + query_pos` the same way instead of the attention wrapper launching an element-wise add."""
         norm_i = attn_i = ffn_i = 0
+        sums = ops.STATE.pos_sum
+        q_sum = query_sum if sums else None
+        out_sum = None
+        order = self.operation_order
         if attn_masks is None:
             attn_masks = [None] * len(self.attentions)
         elif torch.is_tensor(attn_masks):
             attn_masks = [attn_masks for _ in self.attentions]
         qp_all = query_pos
-        for op in self.operation_order:
+
+        def pos_of(i):
+            # a tuple / list of query_pos: one handle per attention of the layer (ops.fan_out: the gradients of all
+            # consumers of a shared positional embedding are then summed by one launch)
+            return qp_all[i] if isinstance(qp_all, (tuple, list)) else qp_all
+
+        for j, op in enumerate(order):
             if op in ('self_attn', 'cross_attn'):
-                # a tuple / list of query_pos: one handle per attention of the layer (ops.fan_out: the gradients of all
-                # consumers of a shared positional embedding are then summed by one launch)
-                query_pos = qp_all[attn_i] if isinstance(qp_all, (tuple, list)) else qp_all
+                query_pos = pos_of(attn_i)
             if op == 'self_attn':
                 query = self.attentions[attn_i](query, query, query, None, query_pos=query_pos, key_pos=query_pos,
                                                 attn_mask=attn_masks[attn_i],
-                                                key_padding_mask=query_key_padding_mask, **kwargs)
+                                                key_padding_mask=query_key_padding_mask, query_sum=q_sum, **kwargs)
                 attn_i += 1
+                q_sum = None
             elif op == 'norm':
                 n = self.norms[norm_i]
-                query = ops.layer_norm(query, n.weight, n.bias)
+                last = j == len(order) - 1
+                nxt = order[j + 1] if not last else None
+                add = None
+                if sums:
+                    if nxt in ('self_attn', 'cross_attn'):
+                        add = pos_of(attn_i)
+                    elif last:
+                        add = next_query_pos
+                if torch.is_tensor(add) and (add.shape == query.shape or add.shape[1:] == query.shape[1:]):
+                    query, s_ = ops.layer_norm_sum(query, n.weight, n.bias, add)
+                    if last:
+                        out_sum = s_
+                    else:
+                        q_sum = s_
+                else:
+                    query = ops.layer_norm(query, n.weight, n.bias)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](query, key, value, None, query_pos=query_pos, key_pos=key_pos,
                                                 attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
-                                                **kwargs)
+                                                query_sum=q_sum, key_sum=key_sum if sums else None, **kwargs)
                 attn_i += 1
+                q_sum = None
             else:
                 query = self.ffns[ffn_i](query)
                 ffn_i += 1
+                q_sum = None
+        if next_query_pos is not None:
+            return query, out_sum
         return query
 
 
@@ -271,10 +309,16 @@ class TransformerLayerSequence(nn.Module):
         # the positional embedding is shared by all layers: one handle per layer, so that its gradients meet in one launch
         qp = kwargs.get('query_pos')
         qps = ops.fan_out(qp, len(self.layers)) if torch.is_tensor(qp) else None
+        q_sum = None
         for i, layer in enumerate(self.layers):
             if qps is not None:
                 kwargs['query_pos'] = qps[i]
-            query = layer(query, key, value, **kwargs)
+            if qps is not None and i + 1 < len(self.layers):
+                # the next layer's first attention adds the same embedding to this layer's output: that sum leaves this
+                # layer's last norm
+                query, q_sum = layer(query, key, value, query_sum=q_sum, next_query_pos=qps[i + 1], **kwargs)
+            else:
+                query = layer(query, key, value, query_sum=q_sum, **kwargs)
         return query
 
 

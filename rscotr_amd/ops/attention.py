@@ -88,13 +88,19 @@ class _MHA(Function):
     packed parameters, identity (Tensor | None, may be x), heads, mask, mask_mode."""
 
     @staticmethod
-    def forward(ctx, x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, mask, mask_mode):
+    def forward(ctx, x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, mask, mask_mode, q_sum=None,
+                k_sum=None):
         B, Lq, C = x.shape
         hd = C // heads
         dev = x.device
         self_attn = kx is None
         x2 = _f32c(x).reshape(B * Lq, C)
-        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos)).reshape(B * Lq, C)
+        # q_sum / k_sum: x + q_pos / kx + k_pos already formed by a producer (ops.layer_norm_sum, a per-level constant):
+        # plain data, no gradient of their own — d(x), d(q_pos), ... come from the projections below either way
+        if q_pos is None:
+            q2 = x2
+        else:
+            q2 = _f32c(torch.add(x, q_pos) if q_sum is None else q_sum).reshape(B * Lq, C)
         # self-attention with one positional embedding for both sides (query + pos feeds q and k): the q and k projections
         # are one GEMM over the first 2C rows of the packed in_proj weight; q / k are then the column halves of one
         # (B*L, 2C) tensor, addressed in place by the batched products (row stride 2C, element offset C for k)
@@ -104,7 +110,7 @@ class _MHA(Function):
             k2 = q2 if fused else (x2 if k_pos is None else _f32c(torch.add(x, k_pos)).reshape(B * Lq, C))
         else:
             kx2 = _f32c(kx).reshape(-1, C)
-            k2 = kx2 if k_pos is None else _f32c(torch.add(kx, k_pos)).reshape(-1, C)
+            k2 = kx2 if k_pos is None else _f32c(torch.add(kx, k_pos) if k_sum is None else k_sum).reshape(-1, C)
         Lk = k2.shape[0] // B
         v_is_kx = vx is None or vx is (x if self_attn else kx)
         v2 = kx2 if v_is_kx else _f32c(vx).reshape(B * Lk, C)
@@ -264,14 +270,16 @@ class _MHA(Function):
         def shaped(t, i):
             return None if t is None else t.view(sh[i])
         return (shaped(d_x, 0), shaped(d_qpos, 1), shaped(d_kx, 2), shaped(d_kpos, 3), shaped(d_vx, 4),
-                gw_in, gb_in, gw_o, gb_o, shaped(d_id, 5), None, None, None)
+                gw_in, gb_in, gw_o, gb_o, shaped(d_id, 5), None, None, None, None, None)
 
 
-def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None):
+def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None,
+        q_sum=None, k_sum=None):
     """torch.nn.MultiheadAttention semantics on batch-first tensors (+ the positional adds and the `identity` residual of
     mmcv's wrapper): query = x + q_pos (B,Lq,C), key = kx + k_pos, value = vx (B,Lk,C); kx None or x itself =
     self-attention (k_pos None then means q_pos), vx None = the key content; attn_mask bool, True = blocked: (Lq,Lk)
-    shared, (B,Lq,Lk) per image (mask_mode=MASK_PER_IMAGE) or (B*heads,Lq,Lk)."""
+    shared, (B,Lq,Lk) per image (mask_mode=MASK_PER_IMAGE) or (B*heads,Lq,Lk).  q_sum / k_sum: x + q_pos / kx + k_pos where a
+    producer already formed them (values only, detached)."""
     if attn_mask is not None and mask_mode is None:
         if attn_mask.dim() == 2:
             mask_mode = MASK_SHARED
@@ -292,7 +300,14 @@ def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=Non
         k_pos = q_pos
     elif k_pos is not None and k_pos.shape != (x if kx is None else kx).shape:
         k_pos = k_pos.expand_as(x if kx is None else kx)
-    return _MHA.apply(x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, attn_mask, mask_mode or 0)
+    if q_sum is not None:
+        assert q_pos is not None and q_sum.shape == x.shape
+        q_sum = q_sum.detach()
+    if k_sum is not None:
+        assert kx is not None and k_pos is not None and k_sum.shape == kx.shape
+        k_sum = k_sum.detach()
+    return _MHA.apply(x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, attn_mask, mask_mode or 0, q_sum,
+                      k_sum)
 
 
 class _MaskLogits(Function):

@@ -179,12 +179,13 @@ class _MSDAAttn(Function):
 
     @staticmethod
     def forward(ctx, x, q_pos, value_in, identity, kpm, ref, spatial_shapes, lsi, norm, heads, L, P,
-                w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+                w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o, q_sum=None):
         B, Nq, C = x.shape
         H, D = heads, C // heads
         M = B * Nq
         x2 = _f32c(x).reshape(M, C)
-        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos)).reshape(M, C)
+        # q_sum: x + q_pos already formed by the producer of x (ops.layer_norm_sum): data only, no gradient of its own
+        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos) if q_sum is None else q_sum).reshape(M, C)
         v_is_x = value_in is None or value_in is x
         id_is_x = identity is x
         val2 = x2 if v_is_x else _f32c(value_in).reshape(-1, C)
@@ -297,11 +298,11 @@ class _MSDAAttn(Function):
             d_id = None
         return (None if d_x is None else d_x.view(ctx.shapes[0]), None if d_pos is None else d_pos.view(ctx.shapes[1]),
                 d_val, d_id, None, None, None, None, None, None, None, None,
-                gw_off, gb_off, gw_aw, gb_aw, gw_v, gb_v, gw_o, gb_o)
+                gw_off, gb_off, gw_aw, gb_aw, gw_v, gb_v, gw_o, gb_o, None)
 
 
 def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes, level_start_index,
-                   offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+                   offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o, q_sum=None):
     """The whole of mmcv MultiScaleDeformableAttention.forward on batch-first tensors (see _MSDAAttn); `value` None or x
     itself = self-attention over the token map (encoder), `identity` None = no residual, x = the usual one."""
     assert not reference_points.requires_grad, 'reference points are detached on this path'
@@ -309,6 +310,9 @@ def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points
         raise ValueError(f'Last dim of reference_points must be 2 or 4, got {reference_points.shape[-1]}')
     if q_pos is not None and q_pos.shape != x.shape:
         q_pos = q_pos.expand_as(x)
+    if q_sum is not None:
+        assert q_pos is not None and q_sum.shape == x.shape
+        q_sum = q_sum.detach()
     return _MSDAAttn.apply(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes,
-                           level_start_index, offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)
+                           level_start_index, offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o, q_sum)
 

@@ -33,7 +33,12 @@ class _LayerNorm(Function):
     @staticmethod
     def _backward(ctx, dy, dres):
         x2, w, stats = ctx.saved_tensors
-        M, C = x2.shape
+        merge = getattr(ctx, 'merge', None)   # (B, H, W, Cin): patch-merging rows gathered by the kernel (_PatchMergeNorm)
+        if merge is None:
+            M, C = x2.shape
+        else:
+            M, C = stats.shape[1], 4 * merge[3]
+            assert dres is None
         g = _f32c(dy).reshape(M, C)
         r = None if dres is None else _f32c(dres).reshape(M, C)  # residual-branch gradient, added inside the kernel
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
@@ -42,23 +47,33 @@ class _LayerNorm(Function):
         dwb = None if direct else torch.zeros((2, C), dtype=torch.float32, device=x2.device)
         dw_ptr = skw[1].data_ptr() if direct else dwb[0].data_ptr()
         db_ptr = (skb[1].data_ptr() if ctx.has_b else 0) if direct else dwb[1].data_ptr()
-        nws = lib.rscotr_layernorm_bwd_workspace(M, C)
-        if direct and DEFER.enabled and STATE.side is None and STATE.profile is None:
+        nws = lib.rscotr_layernorm_bwd_workspace(M, C) if merge is None else lib.rscotr_patch_merge_norm_bwd_workspace(*merge)
+        dx_shape = dy.shape if merge is None else x2.shape
+        defer = direct and DEFER.enabled and STATE.side is None and STATE.profile is None
+        if merge is not None:
+            ws_ptr = DEFER.reserve(nws, x2.device) if defer else _WS.get(nws, x2.device).data_ptr()
+            lib.call('rscotr_patch_merge_norm_bwd', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
+                     stats[1].data_ptr(), _ptr(dx), dw_ptr, db_ptr, *merge, ws_ptr, nws, 0 if defer else 1, _stream())
+            if defer:
+                DEFER.ln_entries.append((ws_ptr, dw_ptr, db_ptr, nws // (8 * C), C))
+        elif defer:
             # the fold of the per-workgroup partial rows into dgamma / dbeta joins the end-of-pass flush (one launch for
             # all ~55 LayerNorms of a backward pass instead of one each)
             part = DEFER.reserve(nws, x2.device)
             lib.call('rscotr_layernorm_bwd_partials', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
                      stats[1].data_ptr(), _ptr(dx), _ptr(r), M, C, part, nws, _stream())
             DEFER.ln_entries.append((part, dw_ptr, db_ptr, nws // (8 * C), C))
+        else:
+            ws = _WS.get(nws, x2.device)
+            with _Prof('layernorm_bwd', 12 * M * C):
+                lib.call('rscotr_layernorm_bwd', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
+                         stats[1].data_ptr(), _ptr(dx), _ptr(r), dw_ptr, db_ptr, M, C, ws.data_ptr(), nws, _stream())
+        if defer:
             STATE.grad_sink.grad_written(skw[0])
             if ctx.has_b:
                 STATE.grad_sink.grad_written(skb[0])
-            return (None if dx is None else dx.view(dy.shape)), None, None, None
-        ws = _WS.get(nws, x2.device)
-        with _Prof('layernorm_bwd', 12 * M * C):
-            lib.call('rscotr_layernorm_bwd', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
-                     stats[1].data_ptr(), _ptr(dx), _ptr(r), dw_ptr, db_ptr, M, C, ws.data_ptr(), nws, _stream())
-        dxv = None if dx is None else dx.view(dy.shape)
+            return (None if dx is None else dx.view(dx_shape)), None, None, None
+        dxv = None if dx is None else dx.view(dx_shape)
         if direct:  # dgamma / dbeta were accumulated straight into the gradient arena
             STATE.grad_sink.grad_written(skw[0])
             if ctx.has_b:
@@ -85,8 +100,81 @@ class _LayerNormFork(Function):
         return _LayerNorm._backward(ctx, dy, dres)
 
 
+class _LayerNormSum(Function):
+    """(LayerNorm(x), LayerNorm(x) + add) from one launch; the second output carries NO gradient: it is the `query +
+    query_pos` an attention wrapper would form (ops._MHA / ops._MSDAAttn take it as `q_sum` and still return d(query) and
+    d(query_pos) from their own backward), so the norm's backward is the plain one."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, add):
+        C = x.shape[-1]
+        x2 = _f32c(x).reshape(-1, C)
+        M = x2.shape[0]
+        if add.dim() == 3 and add.shape[0] > 1 and add.stride(0) == 0:   # one embedding for every image (expanded view)
+            a2 = _f32c(add[0])
+        else:
+            a2 = _f32c(add).reshape(-1, C)
+        rows = a2.shape[0]
+        assert M % rows == 0 and a2.shape[-1] == C, (tuple(x.shape), tuple(add.shape))
+        _chk(x2, w, b, a2)
+        y, y2 = torch.empty_like(x2), torch.empty_like(x2)
+        stats = torch.empty((2, M), dtype=torch.float32, device=x2.device)
+        with _Prof('layernorm_fwd', 16 * M * C):
+            lib.call('rscotr_layernorm_fwd_sum', x2.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
+                     stats[1].data_ptr(), a2.data_ptr(), rows, y2.data_ptr(), M, C, float(eps), _stream())
+        ctx.save_for_backward(x2, w, stats)
+        ctx.has_b = b is not None
+        ctx.bias = b
+        y, y2 = y.view(x.shape), y2.view(x.shape)
+        ctx.mark_non_differentiable(y2)
+        return y, y2
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        return _LayerNorm._backward(ctx, dy, None) + (None,)
+
+
+class _PatchMergeNorm(Function):
+    """LayerNorm(4 Cin) of mmcv PatchMerging's nn.Unfold(2, stride 2) rows of a (B, H*W, Cin) token map, the unfold done by
+    the norm kernels' own loads / stores (no gathered copy in either direction)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, H, W):
+        B, L, Cin = x.shape
+        assert L == H * W
+        x3 = _f32c(x)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        M, C = B * Ho * Wo, 4 * Cin
+        _chk(x3, w, b)
+        y = torch.empty((B, Ho * Wo, C), dtype=torch.float32, device=x3.device)
+        stats = torch.empty((2, M), dtype=torch.float32, device=x3.device)
+        with _Prof('layernorm_fwd', 8 * M * C):
+            lib.call('rscotr_patch_merge_norm_fwd', x3.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
+                     stats[1].data_ptr(), B, H, W, Cin, float(eps), _stream())
+        ctx.save_for_backward(x3, w, stats)
+        ctx.has_b, ctx.bias, ctx.merge = b is not None, b, (B, H, W, Cin)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _LayerNorm._backward(ctx, dy, None) + (None, None)
+
+
 def layer_norm(x, w, b, eps=LN_EPS):
     return _LayerNorm.apply(x, w, b, eps)
+
+
+def patch_merge_norm(x, hw, w, b, eps=LN_EPS):
+    """(B, H*W, Cin) -> (LayerNorm over the (B, ceil(H/2)*ceil(W/2), 4 Cin) nn.Unfold(2, stride 2) rows (c*4 + kh*2 + kw, zero
+    padding for odd H / W), (ceil(H/2), ceil(W/2))): ops.layer_norm(ops.patch_merge_gather(x, hw)) without the gathered copy."""
+    H, W = hw
+    return _PatchMergeNorm.apply(x, w, b, eps, int(H), int(W)), ((H + 1) // 2, (W + 1) // 2)
+
+
+def layer_norm_sum(x, w, b, add, eps=LN_EPS):
+    """(LayerNorm(x), LayerNorm(x) + add.detach()): `add` (same shape as x, or one embedding expanded over the batch) is
+    the positional embedding of the attention that consumes the norm's output; see _LayerNormSum."""
+    return _LayerNormSum.apply(x, w, b, eps, add.detach())
 
 
 def layer_norm_fork(x, w, b, eps=LN_EPS):
@@ -113,7 +201,10 @@ class _GroupNormTokens(Function):
     def backward(ctx, dy):
         x, w, stats = ctx.saved_tensors
         B, L, C = x.shape
-        dy = _f32c(dy)
+        # one level's rows of a gradient over the concatenated levels (dense rows, batch stride of all levels): read in place
+        if not (dy.dtype == torch.float32 and dy.dim() == 3 and dy.stride(2) == 1 and dy.stride(1) == C
+                and dy.stride(0) >= L * C and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0):
+            dy = _f32c(dy)
         dx = torch.empty_like(x)
         # dgamma / dbeta are ADDED by the kernel: straight into the gradient arena when both parameters are sunk (no
         # zero-filled staging rows, no accumulate launches by autograd)
@@ -125,7 +216,7 @@ class _GroupNormTokens(Function):
         proj = torch.empty((B, ctx.groups, 2), dtype=torch.float32, device=x.device)
         nws = lib.rscotr_groupnorm_tokens_workspace(B, L, C, ctx.groups)
         lib.call('rscotr_groupnorm_tokens_bwd', dy.data_ptr(), x.data_ptr(), _ptr(w), stats.data_ptr(), dx.data_ptr(),
-                 dw_ptr, db_ptr, proj.data_ptr(), B, L, C, ctx.groups,
+                 dw_ptr, db_ptr, proj.data_ptr(), B, L, C, ctx.groups, dy.stride(0),
                  _WS.get(nws, x.device).data_ptr(), nws, _stream())
         if direct:
             STATE.grad_sink.grad_written(skw[0])

@@ -13,7 +13,8 @@ class OpsState:
         msda_bwd=('RSCOTR_MSDA_BWD', str, 'tiled'),          # 'tiled' | 'sorted' | 'scatter' (ops/deform.py)
         fan_out=('RSCOTR_FAN_OUT', lambda s: s != '0', '1'),  # ops.fan_out sums consumer gradients 8 at a time
         msda_packed=('RSCOTR_MSDA_PACKED', lambda s: s != '0', '1'),  # offsets | weights projections as one product
-        attn_fused=('RSCOTR_ATTN_FUSED', lambda s: s != '0', '1'),    # dense attention core as one kernel per direction
+        pos_sum=('RSCOTR_POS_SUM', lambda s: s != '0', '1'),  # `query + query_pos` leaves the preceding LayerNorm's launch
+        merge_norm=('RSCOTR_MERGE_NORM', lambda s: s != '0', '1'),  # PatchMerging's unfold done by its LayerNorm's loads / stores
     )
 
     def __init__(self):

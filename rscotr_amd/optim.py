@@ -168,14 +168,16 @@ class FlatAdamW:
 
     def grad_view(self, tensor):
         """-> (index, view of the gradient arena shaped like `tensor`) if `tensor` IS a registered
-        parameter (same storage start and size), else None."""
+        parameter or a contiguous reshaped alias of all of it (same storage start and size), else None."""
         i = self._by_ptr.get(tensor.data_ptr())
         if i is None:
             return None
         p = self.groups[i]['param']
-        if p.shape != tensor.shape or not tensor.is_contiguous():
+        if p.numel() != tensor.numel() or not tensor.is_contiguous():
             return None
-        return i, p.grad
+        # (a reshaped alias of the whole parameter — a convolution weight flattened to (O, C * k * k) for the GEMM — is the
+        # same memory: its gradient goes to the same rows of the arena)
+        return i, (p.grad if p.shape == tensor.shape else p.grad.view(tensor.shape))
 
     def grad_written(self, i):
         # while split-K weight gradients wait for their deferred combine (ops.DEFER), "written" is not true yet for any

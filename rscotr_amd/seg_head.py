@@ -174,14 +174,22 @@ class Mask2FormerHead(nn.Module):
         # backward in 3 launches instead of 17 pairwise adds)
         n_att = len(self.transformer_decoder.layers[0].attentions)
         qe = ops.fan_out(query_embed, nlay * n_att)
+        # key + key_pos of a level is the same for every layer that attends to it: formed once per level (values only; the
+        # attention's backward still returns d(key)); query + query_embed leaves the previous layer's last norm
+        key_sums = [torch.add(k.detach(), p) for k, p in zip(dec_in, dec_pos)] if ops.STATE.pos_sum else [None] * len(dec_in)
+        q_sum = None
         for i in range(nlay):
             li = i % self.num_transformer_feat_level
             layer = self.transformer_decoder.layers[i]
             query_embed = tuple(qe[i * n_att:(i + 1) * n_att])
             if record is not None:  # in the reference's (B*heads, Q, hw) form
                 record['attn_masks'].append(attn_mask.unsqueeze(1).expand(-1, self.num_heads, -1, -1).flatten(0, 1))
+            nxt = qe[(i + 1) * n_att] if i + 1 < nlay else None
             query_feat = layer(query_feat, dec_in[li], dec_in[li], query_pos=query_embed, key_pos=dec_pos[li],
-                               attn_masks=[attn_mask, None], query_key_padding_mask=None, key_padding_mask=None)
+                               attn_masks=[attn_mask, None], query_key_padding_mask=None, key_padding_mask=None,
+                               query_sum=q_sum, key_sum=key_sums[li], next_query_pos=nxt)
+            if nxt is not None:
+                query_feat, q_sum = query_feat
             mask_pred, attn_mask = self.forward_head(
                 query_feat, mask_features, memorys[(i + 1) % self.num_transformer_feat_level].shape[-2:])
         return mask_pred  # only the last prediction is supervised (mask2former_head.py:199)

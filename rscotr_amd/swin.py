@@ -94,8 +94,11 @@ class PatchMerging(nn.Module):
         self.reduction = nn.Linear(4 * in_channels, out_channels, bias=False)
 
     def forward(self, x, hw):
-        y, hw2 = ops.patch_merge_gather(x, hw)
-        y = ops.layer_norm(y, self.norm.weight, self.norm.bias)
+        if ops.STATE.merge_norm and x.shape[-1] <= 512:  # unfold done by the norm's own loads / stores
+            y, hw2 = ops.patch_merge_norm(x, hw, self.norm.weight, self.norm.bias)
+        else:
+            y, hw2 = ops.patch_merge_gather(x, hw)
+            y = ops.layer_norm(y, self.norm.weight, self.norm.bias)
         return ops.linear(y, self.reduction.weight, None), hw2
 
 
@@ -186,11 +189,15 @@ class SwinTransformer(nn.Module):
                 sf = None if (scales is None or b.drop_path == 0.0) else scales[2 * blk + 1]
                 x = b(x, hw, sa, sf)
                 blk += 1
-            out, out_hw = x, hw
-            if stage.downsample is not None:
-                x, hw = stage.downsample(x, hw)
             if i in self.out_indices:
                 n = getattr(self, f'norm{i}')
-                o = ops.layer_norm(out, n.weight, n.bias)
-                outs.append(ops.tokens_to_map(o, out_hw))
+                if stage.downsample is not None:
+                    # the stage output feeds its out-norm AND the next stage: forked at the norm, whose backward kernel adds
+                    # the downsample branch's gradient on its way out (no element-wise add by autograd)
+                    o, x = ops.layer_norm_fork(x, n.weight, n.bias)
+                else:
+                    o = ops.layer_norm(x, n.weight, n.bias)
+                outs.append(ops.tokens_to_map(o, hw))
+            if stage.downsample is not None:
+                x, hw = stage.downsample(x, hw)
         return tuple(outs)

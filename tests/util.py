@@ -82,6 +82,20 @@ def patch_ops_with_oracle(monkeypatch):
     def layer_norm(x, w, b, eps=1e-5):
         return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
+    def layer_norm_sum(x, w, b, add, eps=1e-5):
+        y = F.layer_norm(x, (x.shape[-1],), w, b, eps)
+        return y, (y + add).detach()
+
+    def patch_merge_norm(x, hw, w, b, eps=1e-5):
+        y, hw2 = ops.patch_merge_gather(x, hw)
+        return F.layer_norm(y, (y.shape[-1],), w, b, eps), hw2
+
+    def _check_sum(s, a, b):
+        # a producer-formed `a + b` (ops.layer_norm_sum, per-level key sums) carries values only: the stand-ins recompute
+        # the sum (autograd needs the real one) and check that what was handed over is that sum
+        if s is not None:
+            assert not s.requires_grad and torch.allclose(s, (a + b).detach(), rtol=0, atol=1e-5)
+
     def swin_window_attention(x, hw, qkv_w, qkv_b, bias_table, rel_index, proj_w, proj_b, heads, ws, shift,
                               identity=None, out_scale=None):
         from oracle.model import shift_window_msa
@@ -116,12 +130,15 @@ def patch_ops_with_oracle(monkeypatch):
                 out[p, torch.from_numpy(cs)] = torch.from_numpy(rs).int()
         return out
 
-    def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None):
+    def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=None, mask_mode=None, q_pos=None, k_pos=None,
+            q_sum=None, k_sum=None):
         # (ops.mha: the positional adds happen inside; k_pos None in self-attention means q_pos)
         kx = x if kx is None else kx
         vx = kx if vx is None else vx
         if k_pos is None and kx is x:
             k_pos = q_pos
+        _check_sum(q_sum, x, q_pos)
+        _check_sum(k_sum, kx, k_pos)
         q_in = x if q_pos is None else x + q_pos
         k_in = kx if k_pos is None else kx + k_pos
         v_in = vx
@@ -160,9 +177,10 @@ def patch_ops_with_oracle(monkeypatch):
         return loc, aw
 
     def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes, level_start_index,
-                       offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o):
+                       offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o, q_sum=None):
         # mmcv MultiScaleDeformableAttention.forward (batch-first), as ops._MSDAAttn computes it
         B, Nq, C = x.shape
+        _check_sum(q_sum, x, q_pos)
         q = x if q_pos is None else x + q_pos
         val = x if value is None else value
         v = F.linear(val, w_v, b_v)
@@ -252,6 +270,8 @@ def patch_ops_with_oracle(monkeypatch):
     _set('linear', linear)
     _set('mlp', mlp)
     _set('layer_norm', layer_norm)
+    _set('layer_norm_sum', layer_norm_sum)
+    _set('patch_merge_norm', patch_merge_norm)
     _set('layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
 
 
