@@ -114,7 +114,11 @@ class MlvlClsPixelDecoder(nn.Module):
             shapes.append((h, w))
             refs.append(_grid_refs(h, w, self.strides[level_idx], device))
         geom = LevelGeometry.get(shapes, device)
-        ref = torch.cat(refs, 0)[None, :, None].expand(B, -1, self.num_encoder_levels, -1)
+        rkey = (tuple(shapes), B, str(device))   # a constant of the level shapes: dense once (as seg_head's pixel decoder)
+        cache = self.__dict__.setdefault('_ref_cache', {})
+        ref = cache.get(rkey)
+        if ref is None:
+            ref = cache[rkey] = torch.cat(refs, 0)[None, :, None].expand(B, -1, self.num_encoder_levels, -1).contiguous()
         memory = encoder(torch.cat(inputs, 1), None, None, query_pos=torch.cat(poss, 1), query_key_padding_mask=None,
                          reference_points=ref, **geom.kwargs())
         return [ops.tokens_to_map(memory[:, geom.starts[i]:geom.starts[i] + h * w], (h, w))

@@ -586,7 +586,7 @@ class DinoTransformer(nn.Module):
         topk_unact = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).expand(-1, -1, 4))
         topk_anchor = topk_unact.sigmoid()
         topk_unact = topk_unact.detach()
-        query = self.query_embed.weight[None].expand(B, -1, -1)
+        query = ops.batch_param(self.query_embed.weight, B)
         if dn_label_query is not None:
             query = torch.cat([dn_label_query, query], dim=1)
         refp = torch.cat([dn_bbox_query, topk_unact], dim=1) if dn_bbox_query is not None else topk_unact

@@ -130,6 +130,38 @@ def fan_out(x, n):
     return list(_FanOut.apply(x, n))
 
 
+class _BatchParam(Function):
+    """p[None].expand(B, ...) of a parameter (query embeddings shared by the images of a batch) whose backward sums the B
+    gradient slices AND adds them to the parameter's rows of the gradient arena in one launch (rscotr_sum8 with the arena as
+    first addend and output) — instead of autograd's reduction over the batch axis plus an accumulate launch."""
+
+    @staticmethod
+    def forward(ctx, p, B):
+        ctx.param, ctx.B = p, B
+        return p.detach()[None].expand(B, *p.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, B = ctx.param, ctx.B
+        sk = _sink(p)
+        g = _f32c(g)
+        n = p.numel()
+        if sk is None or B > 7 or n % 4 or not g.is_cuda:
+            return g.sum(0), None
+        _chk(g)
+        ptrs = [sk[1].data_ptr()] + [g[b].data_ptr() for b in range(B)] + [0] * (7 - B)
+        lib.call('rscotr_sum8', *ptrs, B + 1, sk[1].data_ptr(), n, _stream())
+        STATE.grad_sink.grad_written(sk[0])
+        return None, None
+
+
+def batch_param(p, B):
+    """(B, *p.shape) expanded view of parameter p, one copy per image of the batch (see _BatchParam)."""
+    if not (p.requires_grad and p.is_cuda and p.is_contiguous()):
+        return p[None].expand(B, *p.shape)
+    return _BatchParam.apply(p, B)
+
+
 class _CdnQueries(Function):
     """The denoising queries of a det batch in slot layout, one launch (rscotr_cdn_queries); the only gradient is the
     label embedding's (fixed-order scatter, straight into the arena when the parameter is sunk)."""

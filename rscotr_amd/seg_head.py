@@ -69,7 +69,12 @@ class MlvlSegPixelDecoder(nn.Module):
                 [self.postional_encoding.unpadded(1, h, w, device).flatten(2).transpose(1, 2) for h, w in shapes], 1).contiguous()
         pos = ops.level_embed_add(None, self.level_encoding.weight, [h * w for h, w in shapes], const=pe_tok, batch=B)
         geom = LevelGeometry.get(shapes, device)
-        ref = torch.cat(refs, 0)[None, :, None].expand(B, -1, self.num_encoder_levels, -1)
+        # (a constant of the level shapes and the batch size: materialised once — every encoder layer's sampling kernel wants
+        # it dense, and an expanded view would be copied by each of them)
+        rkey = (tuple(shapes), B, str(device), 'ref')
+        ref = self._pe_cache.get(rkey)
+        if ref is None:
+            ref = self._pe_cache[rkey] = torch.cat(refs, 0)[None, :, None].expand(B, -1, self.num_encoder_levels, -1).contiguous()
         # the reference passes an all-False padding mask: value.masked_fill is the identity
         memory = encoder(x, None, None, query_pos=pos, query_key_padding_mask=None, reference_points=ref,
                          **geom.kwargs())
@@ -164,8 +169,8 @@ class Mask2FormerHead(nn.Module):
                                               [m.shape[-2] * m.shape[-1]], row0=i))
             dec_pos.append(self.decoder_positional_encoding.unpadded(B, m.shape[-2], m.shape[-1], device)
                            .flatten(2).transpose(1, 2))
-        query_feat = self.query_feat.weight[None].expand(B, -1, -1)
-        query_embed = self.query_embed.weight[None].expand(B, -1, -1)
+        query_feat = ops.batch_param(self.query_feat.weight, B)
+        query_embed = ops.batch_param(self.query_embed.weight, B)
         mask_pred, attn_mask = self.forward_head(query_feat, mask_features, memorys[0].shape[-2:])
         if record is not None:
             record['attn_masks'] = []

@@ -271,6 +271,7 @@ def patch_ops_with_oracle(monkeypatch):
     _set('mlp', mlp)
     _set('layer_norm', layer_norm)
     _set('layer_norm_sum', layer_norm_sum)
+    _set('batch_param', lambda p, B: p[None].expand(B, *p.shape))
     _set('patch_merge_norm', patch_merge_norm)
     _set('layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
 
