@@ -212,6 +212,21 @@ int rscotr_colsum_f32(const float* X, float* out, int M, int N, int ld, int accu
  * rscotr_layernorm_bwd_workspace(M, C) bytes (16-byte aligned) holds per-workgroup partial sums. */
 int rscotr_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
                          float* rstd, int M, int C, float eps, void* stream);
+/* ---- two-stage proposal selection of the DINO transformer (models/multi/bbox_head/transformer.py:226-241) ---------------
+ * topk_idx (B, K) int64 = torch.topk(enc_cls.max(-1)[0], K, dim=1)[1] (descending scores; equal scores: lower index first —
+ * torch leaves that order unspecified), topk_score (B, K, C) = gather(enc_cls), topk_unact (B, K, 4) = gather(enc_reg +
+ * proposals), topk_anchor = sigmoid(topk_unact); inv (B, N) int32 = rank of token n among the K winners or -1 (for the
+ * backward).  enc_cls (B, N, C) = cls_branches[num_layers](output_memory), enc_reg (B, N, 4) = reg_branches[num_layers](
+ * output_memory), proposals (B | 1, N, 4) = output_proposals (proposals_batched = 0: one set for all images).  One workgroup
+ * per image: K <= 1024, N <= 36864.  Backward: d_cls (B, N, C) / d_reg (B, N, 4) are written completely (zeros for tokens that
+ * were not selected): d_cls[b, n] = d_score[b, inv], d_reg[b, n] = d_anchor[b, inv] * a (1 - a); d_score / d_anchor may be NULL
+ * (= zero), d_cls / d_reg may be NULL (not wanted). */
+int rscotr_det_proposals(const float* enc_cls, const float* enc_reg, const float* proposals, int proposals_batched,
+                         int64_t* topk_idx, float* topk_score, float* topk_unact, float* topk_anchor, int32_t* inv, int B, int N,
+                         int C, int K, void* stream);
+int rscotr_det_proposals_bwd(const float* d_score, const float* d_anchor, const float* topk_anchor, const int32_t* inv,
+                             float* d_cls, float* d_reg, int B, int N, int C, int K, void* stream);
+
 /* rscotr_layernorm_fwd with a second output y2 = y + add[row % add_rows] (add (add_rows, C)): mmcv BaseTransformerLayer's
  * `norm` step followed by an attention whose wrapper forms `query + query_pos` (mmcv MultiheadAttention.forward /
  * MultiScaleDeformableAttention.forward as built from cfg ...potsdam.py:34-50,76-98,139-160) — the sum leaves the norm's

@@ -1,0 +1,212 @@
+// Two-stage proposal selection of the DINO transformer (gfx950): models/multi/bbox_head/transformer.py:226-241 —
+//   topk_proposals = torch.topk(enc_outputs_class.max(-1)[0], topk, dim=1)[1]
+//   topk_coords_unact = torch.gather(enc_outputs_coord_unact, 1, topk_proposals[..., None].repeat(1, 1, 4))
+//   topk_anchor = topk_coords_unact.sigmoid();  topk_score = torch.gather(enc_outputs_class, 1, ...)
+// with enc_outputs_coord_unact = reg_branch(output_memory) + output_proposals — a row maximum, a top-k (two library launches:
+// radix select + sort), an add, two gathers and a sigmoid forward; two zero-fills, two scatter-adds and a sigmoid backward in
+// backward: ~14 launches, ~150 us of a det iteration.  Here: ONE workgroup of 1024 threads per image forward, one launch over
+// the (B, N) rows backward.
+//
+// Forward, per image: (1) the row maxima become order-preserving 32-bit keys in LDS (N <= 36864: every pyramid of the configs,
+// up to 1024 x 1024 inputs); (2) MSD radix select, four 8-bit passes of LDS histograms, finds the K-th largest key T, the
+// number of keys above it and how many keys EQUAL to T are still needed; (3) one pass in index order collects the winners
+// (keys > T, then the first `need` keys == T: ties go to the lower index — torch.topk leaves that order unspecified);
+// (4) bitonic sort of the (key, ~index) pairs, descending: torch.topk(sorted=True) order; (5) the gathers, the proposal add
+// and the sigmoid for the K winners, plus inv[b, n] = rank of token n or -1 for the backward.
+// Backward: d(class)[b, n, :] = d(score)[b, inv, :] or 0, d(reg)[b, n, :] = d(anchor)[b, inv, :] * a * (1 - a) or 0 — every
+// row written exactly once (no zero-fill, no atomics: bit-reproducible).
+#include "common.h"
+
+namespace rscotr {
+
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_N = 36864;  // keys in LDS: 144 KB
+constexpr int SEL_MAX_K = 1024;
+
+__device__ __forceinline__ unsigned order_key(float v) {  // larger float <-> larger unsigned; -0 < +0; NaN sorts high
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void det_proposals_kernel(
+    const float* __restrict__ cls, const float* __restrict__ raw, const float* __restrict__ prop, long prop_bstride,
+    long long* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ out_unact,
+    float* __restrict__ out_anchor, int* __restrict__ inv, int N, int C, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned sel_lds[];
+  unsigned* keys = sel_lds;                                                       // [N]
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(sel_lds + ((N + 3) & ~3));  // [1024] (key << 32 | ~idx)
+  __shared__ int hist[256];
+  __shared__ int wsum[16][2];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need, s_above;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* cb = cls + (long)b * N * C;
+
+  for (int n = tid; n < N; n += SEL_THREADS) {  // (1) row maxima (enc_outputs_class.max(-1)[0])
+    const float* r = cb + (long)n * C;
+    float m = r[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, r[c]);
+    keys[n] = order_key(m);
+    inv[(long)b * N + n] = -1;
+  }
+  if (tid == 0) { s_prefix = 0u; s_need = K; s_above = 0; }
+  __syncthreads();
+
+  // (2) radix select from the most significant byte down: after pass p the K-th largest key is known to start with
+  // s_prefix (its top 8 (p + 1) bits), `s_above` keys are larger than anything with that prefix, `s_need` = K - s_above
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, hmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int n = tid; n < N; n += SEL_THREADS) {
+      const unsigned k = keys[n];
+      if ((k & hmask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {  // (256 bins: a serial walk from the top costs nothing next to the passes over N)
+      int need = s_need, bin = 255;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= need) break;
+        need -= hist[bin];
+      }
+      s_above += s_need - need;
+      s_need = need;
+      s_prefix = prefix | ((unsigned)bin << shift);
+    }
+    __syncthreads();
+  }
+  const unsigned T = s_prefix;     // the K-th largest key
+  const int need_eq = s_need;      // keys == T still to take (lowest indices first)
+  const int n_above = s_above;     // keys > T
+
+  // (3) winners in index order: positions [0, n_above) for keys > T, [n_above, K) for the first need_eq keys == T
+  for (int i = tid; i < SEL_MAX_K; i += SEL_THREADS) cand[i] = 0ull;  // padding sorts last (key 0 < every real key)
+  __syncthreads();
+  int base_gt = 0, base_eq = 0;
+  for (int n0 = 0; n0 < N; n0 += SEL_THREADS) {
+    const int n = n0 + tid;
+    const unsigned k = n < N ? keys[n] : 0u;
+    const bool gt = n < N && k > T, eq = n < N && k == T;
+    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    if (lane == 0) { wsum[wave][0] = __popcll(mg); wsum[wave][1] = __popcll(me); }
+    __syncthreads();
+    int og = 0, oe = 0, tg = 0, te = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int a = wsum[w][0], c = wsum[w][1];
+      if (w < wave) { og += a; oe += c; }
+      tg += a; te += c;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (gt) cand[base_gt + og + __popcll(mg & below)] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)n);
+    if (eq) {
+      const int r = base_eq + oe + __popcll(me & below);
+      if (r < need_eq) cand[n_above + r] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)n);
+    }
+    base_gt += tg; base_eq += te;
+    __syncthreads();
+  }
+
+  // (4) bitonic sort of 1024 pairs, descending (one element per thread)
+  for (int size = 2; size <= SEL_MAX_K; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = tid ^ stride;
+      if (partner > tid) {
+        const unsigned long long a = cand[tid], c = cand[partner];
+        const bool desc = (tid & size) == 0;
+        if (desc ? a < c : a > c) { cand[tid] = c; cand[partner] = a; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // (5) outputs
+  for (int k = tid; k < K; k += SEL_THREADS) {
+    const int n = (int)(0xffffffffu - (unsigned)(cand[k] & 0xffffffffull));
+    out_idx[(long)b * K + k] = n;
+    inv[(long)b * N + n] = k;
+    const float4 r = *reinterpret_cast<const float4*>(raw + ((long)b * N + n) * 4);
+    const float4 p = *reinterpret_cast<const float4*>(prop + b * prop_bstride + (long)n * 4);
+    const float4 u = make_float4(r.x + p.x, r.y + p.y, r.z + p.z, r.w + p.w);
+    *reinterpret_cast<float4*>(out_unact + ((long)b * K + k) * 4) = u;
+    *reinterpret_cast<float4*>(out_anchor + ((long)b * K + k) * 4) =
+        make_float4(1.f / (1.f + expf(-u.x)), 1.f / (1.f + expf(-u.y)), 1.f / (1.f + expf(-u.z)), 1.f / (1.f + expf(-u.w)));
+  }
+  for (int i = tid; i < K * C; i += SEL_THREADS) {
+    const int k = i / C, c = i - k * C;
+    const int n = (int)(0xffffffffu - (unsigned)(cand[k] & 0xffffffffull));
+    out_score[((long)b * K + k) * C + c] = cb[(long)n * C + c];
+  }
+}
+
+// one thread per (b, n) row
+__global__ __launch_bounds__(256) void det_proposals_bwd_kernel(const float* __restrict__ d_score, const float* __restrict__ d_anchor,
+                                                                const float* __restrict__ anchor, const int* __restrict__ inv,
+                                                                float* __restrict__ d_cls, float* __restrict__ d_raw, long rows,
+                                                                int N, int C, int K) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const int b = (int)(i / N);
+  const int k = inv[i];
+  if (d_cls) {
+    float* o = d_cls + i * C;
+    if (k >= 0 && d_score) {
+      const float* g = d_score + ((long)b * K + k) * C;
+      for (int c = 0; c < C; ++c) o[c] = g[c];
+    } else {
+      for (int c = 0; c < C; ++c) o[c] = 0.f;
+    }
+  }
+  if (d_raw) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k >= 0 && d_anchor) {
+      const float4 g = *reinterpret_cast<const float4*>(d_anchor + ((long)b * K + k) * 4);
+      const float4 a = *reinterpret_cast<const float4*>(anchor + ((long)b * K + k) * 4);
+      v = make_float4(g.x * (1.f - a.x) * a.x, g.y * (1.f - a.y) * a.y, g.z * (1.f - a.z) * a.z, g.w * (1.f - a.w) * a.w);
+    }
+    *reinterpret_cast<float4*>(d_raw + i * 4) = v;
+  }
+}
+
+}  // namespace rscotr
+
+using namespace rscotr;
+
+extern "C" int rscotr_det_proposals(const float* enc_cls, const float* enc_reg, const float* proposals, int proposals_batched,
+                                    int64_t* topk_idx, float* topk_score, float* topk_unact, float* topk_anchor, int32_t* inv,
+                                    int B, int N, int C, int K, void* stream) {
+  if (B < 0 || N <= 0 || C <= 0 || K <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_det_proposals: bad shape B=%d N=%d C=%d K=%d", B, N, C, K);
+  if (K > N || K > SEL_MAX_K || N > SEL_MAX_N)
+    return fail(RSCOTR_E_SHAPE, "rscotr_det_proposals: needs K <= min(N, %d) and N <= %d (K=%d N=%d)", SEL_MAX_K, SEL_MAX_N, K, N);
+  if (B == 0) return RSCOTR_OK;
+  if (!enc_cls || !enc_reg || !proposals || !topk_idx || !topk_score || !topk_unact || !topk_anchor || !inv)
+    return fail(RSCOTR_E_ARG, "rscotr_det_proposals: null pointer");
+  if (!aligned16(enc_reg) || !aligned16(proposals) || !aligned16(topk_unact) || !aligned16(topk_anchor))
+    return fail(RSCOTR_E_ALIGN, "rscotr_det_proposals: box tensors must be 16-byte aligned");
+  const size_t lds = (size_t)((N + 3) & ~3) * 4 + (size_t)SEL_MAX_K * 8;
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(det_proposals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              SEL_MAX_N * 4 + SEL_MAX_K * 8);
+    return true;
+  }();
+  (void)attr_set;
+  det_proposals_kernel<<<dim3((unsigned)B), SEL_THREADS, lds, (hipStream_t)stream>>>(
+      enc_cls, enc_reg, proposals, proposals_batched ? (long)N * 4 : 0, reinterpret_cast<long long*>(topk_idx), topk_score,
+      topk_unact, topk_anchor, inv, N, C, K);
+  return check_launch("rscotr_det_proposals");
+}
+
+extern "C" int rscotr_det_proposals_bwd(const float* d_score, const float* d_anchor, const float* topk_anchor, const int32_t* inv,
+                                        float* d_cls, float* d_reg, int B, int N, int C, int K, void* stream) {
+  if (B < 0 || N <= 0 || C <= 0 || K <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_det_proposals_bwd: bad shape");
+  if (B == 0) return RSCOTR_OK;
+  if (!inv || (d_anchor && !topk_anchor)) return fail(RSCOTR_E_ARG, "rscotr_det_proposals_bwd: null pointer");
+  if ((d_anchor && !aligned16(d_anchor)) || (topk_anchor && !aligned16(topk_anchor)) || (d_reg && !aligned16(d_reg)))
+    return fail(RSCOTR_E_ALIGN, "rscotr_det_proposals_bwd: box tensors must be 16-byte aligned");
+  const long rows = (long)B * N;
+  det_proposals_bwd_kernel<<<dim3((unsigned)((rows + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+      d_score, d_anchor, topk_anchor, inv, d_cls, d_reg, rows, N, C, K);
+  return check_launch("rscotr_det_proposals_bwd");
+}

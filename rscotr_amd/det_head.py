@@ -577,15 +577,20 @@ class DinoTransformer(nn.Module):
                             self.enc_output_norm.weight, self.enc_output_norm.bias)
         nl = self.decoder.num_layers
         enc_cls = ops.linear(om, cls_branches[nl].weight, cls_branches[nl].bias)
-        enc_coord = _mlp(om, reg_branches[nl]) + proposals
         topk = self.two_stage_num_proposals
-        topk_idx = torch.topk(enc_cls.max(-1)[0], topk, dim=1)[1]
+        N_tok = enc_cls.shape[1]
+        if topk <= min(N_tok, ops.DET_PROPOSALS_MAX_K) and N_tok <= ops.DET_PROPOSALS_MAX_N:
+            # row maximum, top-k, proposal add, gathers, sigmoid: one launch (and one for the scattered gradients)
+            topk_idx, topk_score, topk_unact, topk_anchor = ops.det_proposals(enc_cls, _mlp(om, reg_branches[nl]), proposals, topk)
+        else:
+            enc_coord = _mlp(om, reg_branches[nl]) + proposals
+            topk_idx = torch.topk(enc_cls.max(-1)[0], topk, dim=1)[1]
+            topk_score = torch.gather(enc_cls, 1, topk_idx.unsqueeze(-1).expand(-1, -1, enc_cls.shape[-1]))
+            topk_unact = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).expand(-1, -1, 4))
+            topk_anchor = topk_unact.sigmoid()
+            topk_unact = topk_unact.detach()
         if record is not None:
             record['topk_idx'] = topk_idx
-        topk_score = torch.gather(enc_cls, 1, topk_idx.unsqueeze(-1).expand(-1, -1, enc_cls.shape[-1]))
-        topk_unact = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).expand(-1, -1, 4))
-        topk_anchor = topk_unact.sigmoid()
-        topk_unact = topk_unact.detach()
         query = ops.batch_param(self.query_embed.weight, B)
         if dn_label_query is not None:
             query = torch.cat([dn_label_query, query], dim=1)

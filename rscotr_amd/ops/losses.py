@@ -229,3 +229,53 @@ def upsample_ce(seg_logit, label, ignore_index=255):
     acc = (sums[1] * 100.0 / (sums[2] + torch.finfo(torch.float32).eps)).reshape(1)
     return loss, acc
 
+
+
+class _DetProposals(Function):
+    """Two-stage proposal selection of the DINO transformer (transformer.py:226-241) as one launch per direction
+    (rscotr_det_proposals / _bwd): row maximum, top-k, the proposal add, both gathers and the sigmoid forward; the two
+    scattered gradients backward (every row of d(enc_cls) / d(enc_reg) written once: no zero-fill, no scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, enc_cls, enc_reg, proposals, K):
+        B, N, C = enc_cls.shape
+        cls2, reg2, prop = _f32c(enc_cls), _f32c(enc_reg), _f32c(proposals)
+        assert reg2.shape == (B, N, 4) and prop.shape[1:] == (N, 4) and prop.shape[0] in (1, B)
+        _chk(cls2, reg2, prop)
+        dev = cls2.device
+        idx = torch.empty((B, K), dtype=torch.int64, device=dev)
+        score = torch.empty((B, K, C), dtype=torch.float32, device=dev)
+        unact = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
+        anchor = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
+        inv = torch.empty((B, N), dtype=torch.int32, device=dev)
+        lib.call('rscotr_det_proposals', cls2.data_ptr(), reg2.data_ptr(), prop.data_ptr(), int(prop.shape[0] == B and B > 1),
+                 idx.data_ptr(), score.data_ptr(), unact.data_ptr(), anchor.data_ptr(), inv.data_ptr(), B, N, C, K, _stream())
+        ctx.save_for_backward(anchor, inv)
+        ctx.geom = (B, N, C, K)
+        ctx.mark_non_differentiable(idx, unact)
+        ctx.set_materialize_grads(False)
+        return idx, score, unact, anchor
+
+    @staticmethod
+    def backward(ctx, _gi, g_score, _gu, g_anchor):
+        anchor, inv = ctx.saved_tensors
+        B, N, C, K = ctx.geom
+        need = ctx.needs_input_grad
+        gs = None if g_score is None else _f32c(g_score)
+        ga = None if g_anchor is None else _f32c(g_anchor)
+        d_cls = torch.empty((B, N, C), dtype=torch.float32, device=anchor.device) if need[0] else None
+        d_reg = torch.empty((B, N, 4), dtype=torch.float32, device=anchor.device) if need[1] else None
+        if d_cls is not None or d_reg is not None:
+            lib.call('rscotr_det_proposals_bwd', _ptr(gs), _ptr(ga), anchor.data_ptr(), inv.data_ptr(), _ptr(d_cls), _ptr(d_reg),
+                     B, N, C, K, _stream())
+        return d_cls, d_reg, None, None
+
+
+DET_PROPOSALS_MAX_N, DET_PROPOSALS_MAX_K = 36864, 1024
+
+
+def det_proposals(enc_cls, enc_reg, proposals, K):
+    """-> (topk_idx (B,K) int64, topk_score (B,K,C), topk_unact (B,K,4) detached, topk_anchor (B,K,4)): the K tokens with the
+    largest class score (torch.topk order: descending; equal scores: lower index first), their class rows, enc_reg + proposals
+    and its sigmoid.  enc_cls (B,N,C), enc_reg (B,N,4), proposals (B|1,N,4) (no gradient)."""
+    return _DetProposals.apply(enc_cls, enc_reg, proposals.detach(), int(K))

@@ -123,3 +123,62 @@ def test_refine_box_and_gradient(cuda):
     out = ops.refine_box(dd, rd, 1e-3)
     (out * go.to(cuda)).sum().backward()
     assert _rel(out, out_r) < 1e-5 and _rel(dd.grad, dr.grad) < 1e-5 and _rel(rd.grad, rr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,N,C,K,batched', [(2, 5440, 20, 600, True), (2, 5440, 20, 600, False), (4, 13294, 20, 600, True),
+                                             (1, 21760, 20, 900, False), (2, 85, 20, 30, True), (3, 64, 5, 64, True),
+                                             (2, 36864, 3, 1024, False)])
+def test_det_proposals_matches_torch(cuda, B, N, C, K, batched):
+    """ops.det_proposals (row maximum, top-k, proposal add, gathers, sigmoid in one launch; the scattered gradients in one)
+    against the reference's own sequence (models/multi/bbox_head/transformer.py:226-241) in torch: identical indices (no ties
+    in random scores), scores, unactivated boxes, anchors; gradients of enc_cls / enc_reg equal torch autograd's."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    cls = torch.randn(B, N, C, generator=g)
+    reg = torch.randn(B, N, 4, generator=g)
+    prop = torch.randn(B if batched else 1, N, 4, generator=g)
+    prop[:, ::17] = float('inf')                      # invalid proposals are +inf in the reference (transformer.py:177-182)
+    gs, ga = torch.randn(B, K, C, generator=g), torch.randn(B, K, 4, generator=g)
+    cr, rr = cls.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    coord = rr + prop
+    idx_r = torch.topk(cr.max(-1)[0], K, dim=1)[1]
+    score_r = torch.gather(cr, 1, idx_r.unsqueeze(-1).expand(-1, -1, C))
+    unact_r = torch.gather(coord, 1, idx_r.unsqueeze(-1).expand(-1, -1, 4))
+    anchor_r = unact_r.sigmoid()
+    ((score_r * gs).sum() + (anchor_r * ga).sum()).backward()
+    cd, rd = cls.to(cuda).requires_grad_(True), reg.to(cuda).requires_grad_(True)
+    idx, score, unact, anchor = ops.det_proposals(cd, rd, prop.to(cuda), K)
+    assert not unact.requires_grad and not idx.requires_grad
+    ((score * gs.to(cuda)).sum() + (anchor * ga.to(cuda)).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(idx.cpu(), idx_r)
+    assert torch.equal(score.detach().cpu(), score_r.detach()) and torch.equal(unact.cpu(), unact_r.detach())
+    assert torch.allclose(anchor.detach().cpu(), anchor_r.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(cd.grad.cpu(), cr.grad)
+    assert torch.allclose(rd.grad.cpu(), rr.grad, rtol=1e-5, atol=1e-7)
+    assert torch.isfinite(rd.grad).all()
+
+
+def test_det_proposals_ties_go_to_the_lower_index(cuda):
+    """Equal scores (torch.topk leaves their order unspecified): the selected VALUES are torch.topk's, in descending order,
+    and among equal values the lower token index wins and comes first — the rule the kernel documents."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, N, C, K = 2, 3000, 4, 600
+    cls = (torch.randint(0, 40, (B, N, C), generator=g).float() - 20.0) / 4.0    # ~40 distinct row maxima: massive ties
+    reg, prop = torch.randn(B, N, 4, generator=g), torch.zeros(1, N, 4)
+    idx, score, unact, anchor = ops.det_proposals(cls.to(cuda), reg.to(cuda), prop.to(cuda), K)
+    idx = idx.cpu()
+    rowmax = cls.max(-1)[0]
+    vals = torch.gather(rowmax, 1, idx)
+    assert torch.equal(vals, torch.topk(rowmax, K, dim=1)[0])
+    for b in range(B):
+        v, i = vals[b], idx[b]
+        assert len(set(i.tolist())) == K
+        same = v[1:] == v[:-1]
+        assert bool((i[1:][same] > i[:-1][same]).all())             # ascending index inside a run of equal scores
+        thr = float(v[-1])                                            # at the threshold value: the lowest indices were taken
+        at = (rowmax[b] == thr).nonzero().flatten()
+        taken = i[v == thr]
+        assert torch.equal(taken, at[:len(taken)])
+    assert torch.equal(score.cpu(), torch.gather(cls, 1, idx.unsqueeze(-1).expand(-1, -1, C)))

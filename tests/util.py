@@ -271,6 +271,15 @@ def patch_ops_with_oracle(monkeypatch):
     _set('mlp', mlp)
     _set('layer_norm', layer_norm)
     _set('layer_norm_sum', layer_norm_sum)
+
+    def det_proposals(enc_cls, enc_reg, proposals, K):
+        enc_coord = enc_reg + proposals
+        idx = torch.topk(enc_cls.max(-1)[0], K, dim=1)[1]
+        score = torch.gather(enc_cls, 1, idx.unsqueeze(-1).expand(-1, -1, enc_cls.shape[-1]))
+        unact = torch.gather(enc_coord, 1, idx.unsqueeze(-1).expand(-1, -1, 4))
+        return idx, score, unact.detach(), unact.sigmoid()
+
+    _set('det_proposals', det_proposals)
     _set('batch_param', lambda p, B: p[None].expand(B, *p.shape))
     _set('patch_merge_norm', patch_merge_norm)
     _set('layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
