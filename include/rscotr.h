@@ -227,6 +227,14 @@ int rscotr_det_proposals(const float* enc_cls, const float* enc_reg, const float
 int rscotr_det_proposals_bwd(const float* d_score, const float* d_anchor, const float* topk_anchor, const int32_t* inv,
                              float* d_cls, float* d_reg, int B, int N, int C, int K, void* stream);
 
+/* Classification / box targets of the Hungarian assignment for S prediction sets x B images in one launch
+ * (mmdet_detr_head/detr_head.py:475-543 `_get_target_single`, batched): q_for_gt (S, B, G) int32 = the query assigned to
+ * ground truth g of image b in set s (rscotr_lsap_dev_f32's output; -1 = padding column), gt_lab (B, G) int64, gt_boxn
+ * (B, G, 4) normalised cxcywh.  labels (S, B, Q) int64 = gt_lab of the assigned ground truth or num_classes (background),
+ * bbox_targets (S, B, Q, 4) = its box or zeros, bbox_weights (S, B, Q, 4) = 1 or 0: every row written once. */
+int rscotr_det_targets(const int32_t* q_for_gt, const int64_t* gt_lab, const float* gt_boxn, int64_t* labels, float* bbox_targets,
+                       float* bbox_weights, int S, int B, int Q, int G, int num_classes, void* stream);
+
 /* rscotr_layernorm_fwd with a second output y2 = y + add[row % add_rows] (add (add_rows, C)): mmcv BaseTransformerLayer's
  * `norm` step followed by an attention whose wrapper forms `query + query_pos` (mmcv MultiheadAttention.forward /
  * MultiScaleDeformableAttention.forward as built from cfg ...potsdam.py:34-50,76-98,139-160) — the sum leaves the norm's

@@ -170,9 +170,51 @@ __global__ __launch_bounds__(256) void det_proposals_bwd_kernel(const float* __r
   }
 }
 
+// Targets of the Hungarian matching for S x B (prediction set, image) pairs (detr_head.py:475-543 `_get_target_single`): query
+// q of (s, b) gets label gt_lab[b, g] / box gt_boxn[b, g] / weight 1 if ground truth g was assigned to it (qfg[s, b, g] == q),
+// else the background class / a zero box / weight 0.  One workgroup per (s, b): the assignment is inverted in LDS, then every
+// query row is written once — instead of three fills, three scatters, the index arithmetic and the slices around them.
+__global__ __launch_bounds__(256) void det_targets_kernel(const int* __restrict__ qfg, const long long* __restrict__ gt_lab,
+                                                          const float* __restrict__ gt_boxn, long long* __restrict__ labels,
+                                                          float* __restrict__ bbox_t, float* __restrict__ bbox_w, int B, int Q, int G,
+                                                          int bg) {
+  extern __shared__ int tg_map[];  // [Q] ground truth of a query or -1
+  const int sb = blockIdx.x, b = sb % B;
+  for (int q = threadIdx.x; q < Q; q += 256) tg_map[q] = -1;
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const int q = qfg[(long)sb * G + g];
+    if (q >= 0 && q < Q) tg_map[q] = g;  // (an assignment: every query appears at most once)
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    const int g = tg_map[q];
+    const long o = (long)sb * Q + q;
+    labels[o] = g >= 0 ? gt_lab[(long)b * G + g] : (long long)bg;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), one = make_float4(1.f, 1.f, 1.f, 1.f);
+    reinterpret_cast<float4*>(bbox_t)[o] = g >= 0 ? reinterpret_cast<const float4*>(gt_boxn)[(long)b * G + g] : z;
+    reinterpret_cast<float4*>(bbox_w)[o] = g >= 0 ? one : z;
+  }
+}
+
 }  // namespace rscotr
 
 using namespace rscotr;
+
+extern "C" int rscotr_det_targets(const int32_t* q_for_gt, const int64_t* gt_lab, const float* gt_boxn, int64_t* labels,
+                                  float* bbox_targets, float* bbox_weights, int S, int B, int Q, int G, int num_classes,
+                                  void* stream) {
+  if (S < 0 || B < 0 || Q <= 0 || G < 0 || Q > 16384) return fail(RSCOTR_E_SHAPE, "rscotr_det_targets: bad shape S=%d B=%d Q=%d G=%d", S, B, Q, G);
+  if (S == 0 || B == 0) return RSCOTR_OK;
+  if ((G > 0 && (!q_for_gt || !gt_lab || !gt_boxn)) || !labels || !bbox_targets || !bbox_weights)
+    return fail(RSCOTR_E_ARG, "rscotr_det_targets: null pointer");
+  if ((gt_boxn && !aligned16(gt_boxn)) || !aligned16(bbox_targets) || !aligned16(bbox_weights))
+    return fail(RSCOTR_E_ALIGN, "rscotr_det_targets: box tensors must be 16-byte aligned");
+  det_targets_kernel<<<dim3((unsigned)(S * B)), 256, (size_t)Q * 4, (hipStream_t)stream>>>(
+      q_for_gt, reinterpret_cast<const long long*>(gt_lab), gt_boxn, reinterpret_cast<long long*>(labels), bbox_targets,
+      bbox_weights, B, Q, G, num_classes);
+  return check_launch("rscotr_det_targets");
+}
 
 extern "C" int rscotr_det_proposals(const float* enc_cls, const float* enc_reg, const float* proposals, int proposals_batched,
                                     int64_t* topk_idx, float* topk_score, float* topk_unact, float* topk_anchor, int32_t* inv,

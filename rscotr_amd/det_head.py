@@ -208,8 +208,8 @@ class DetStatic:
     All tensors are built on the host from the ground-truth COUNTS (known without a device sync) and
     uploaded; `update_into` refreshes a captured iteration's static copies."""
 
-    KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
-            'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales')
+    KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'gcount_s', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
+            'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales', 'dn_lab', 'dn_bt', 'dn_bw', 'dn_cw')
 
     def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None, gt_host=None):
         gen = head.dn_generator
@@ -311,8 +311,18 @@ class DetStatic:
                     gt_lab[b, :counts[b]] = np.asarray(hl[b], dtype=np.int64).reshape(-1)
             q = gt_box / factors_np[:, None, :]  # bbox_xyxy_to_cxcywh(gt_box / factors) in fp32, as ops does it
             x1, y1, x2, y2 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-            host.update(gt_box=gt_box, gt_lab=gt_lab,
-                        gt_boxn=np.stack([(x1 + x2) / np.float32(2), (y1 + y2) / np.float32(2), x2 - x1, y2 - y1], -1))
+            gt_boxn = np.stack([(x1 + x2) / np.float32(2), (y1 + y2) / np.float32(2), x2 - x1, y2 - y1], -1)
+            host.update(gt_box=gt_box, gt_lab=gt_lab, gt_boxn=gt_boxn)
+            # denoising targets (dino_head.py:323-365: by construction, in slot layout) for the nl decoder layers and the
+            # per-set ground-truth counts of the matcher: functions of the ground truth alone, so they ride the same block
+            nl = head.transformer.decoder.num_layers
+            lab_slot = gt_lab.reshape(-1)[slot_src]
+            dn_lab = np.where(slot_pos > 0, lab_slot, head.num_classes).astype(np.int64)
+            dn_bt = (gt_boxn.reshape(-1, 4)[slot_src] * slot_pos[..., None]).astype(np.float32)
+            dn_bw = np.broadcast_to(slot_pos[..., None], (B, PC, 4))
+            rep = lambda a: np.ascontiguousarray(np.broadcast_to(a[None], (nl,) + a.shape))
+            host.update(dn_lab=rep(dn_lab), dn_bt=rep(dn_bt), dn_bw=rep(np.ascontiguousarray(dn_bw, dtype=np.float32)),
+                        dn_cw=rep(slot_inpad), gcount_s=np.tile(np.asarray(counts, dtype=np.int32), nl + 1))
             self._pack(host, device, pinned)
         else:
             gt_box = torch.zeros((B, G, 4), device=device)
@@ -688,7 +698,8 @@ class DINOHead(nn.Module):
         a = self.assigner
         cost = ops.match_cost_batched(cls_sets.detach(), box_sets.detach(), t['gt_box'], t['gt_lab'], t['factors'],
                                       a.w_cls, a.w_l1, a.w_iou, a.alpha, a.gamma, a.eps)
-        qfg = ops.lsap_device(cost.reshape(S * B, Q, G), t['gcount'].repeat(S)).view(S, B, G).long()
+        gcount_s = t['gcount_s'] if 'gcount_s' in t else t['gcount'].repeat(S)
+        qfg = ops.lsap_device(cost.reshape(S * B, Q, G), gcount_s).view(S, B, G)
         if record is not None:
             host = qfg.cpu().numpy()
             for s_ in range(S):
@@ -697,13 +708,8 @@ class DINOHead(nn.Module):
                         q = host[s_, i, :g]
                         order = np.argsort(q, kind='stable')
                         record.setdefault('match', {})[(s_, i)] = (q[order].astype(np.int64), order.astype(np.int64))
-        idx = torch.where(qfg >= 0, qfg, torch.full_like(qfg, Q))          # padding columns -> dummy slot Q
-        idx4 = idx.unsqueeze(-1).expand(-1, -1, -1, 4)
-        dev = cls_sets.device
-        labels = torch.full((S, B, Q + 1), self.num_classes, dtype=torch.long, device=dev) \
-            .scatter_(2, idx, t['gt_lab'][None].expand(S, -1, -1))[:, :, :Q]
-        bbox_t = torch.zeros((S, B, Q + 1, 4), device=dev).scatter_(2, idx4, t['gt_boxn'][None].expand(S, -1, -1, -1))[:, :, :Q]
-        bbox_w = torch.zeros((S, B, Q + 1, 4), device=dev).scatter_(2, idx4, torch.ones((S, B, G, 4), device=dev))[:, :, :Q]
+        # labels / boxes / weights of the assignment for all S x B problems: one launch (ops.det_targets)
+        labels, bbox_t, bbox_w = ops.det_targets(qfg, t['gt_lab'], t['gt_boxn'], Q, self.num_classes)
         # (S, 3) = [cls, bbox, iou] sums of every set times the batch's precomputed weight / normaliser (DetStatic.scales)
         m3 = self._set_losses(cls_sets, box_sets, labels, bbox_t, bbox_w, None, None, st.img_shapes,
                               factors=t['factors'], scales=t['scales'][0])  # rows = interm, d0..d{nl-2}, final
@@ -714,14 +720,19 @@ class DINOHead(nn.Module):
         for l in range(nl - 1):
             d[f'd{l}.loss_cls'], d[f'd{l}.loss_bbox'], d[f'd{l}.loss_iou'] = l_cls[l + 1], l_box[l + 1], l_iou[l + 1]
         # denoising part: targets by construction (dino_head.py:323-365) in slot layout
-        lab_slot = t['gt_lab'].reshape(-1)[t['slot_src']]
-        pos = t['slot_pos']
-        dlabels = torch.where(pos > 0, lab_slot, torch.full_like(lab_slot, self.num_classes))
-        dbt = t['gt_boxn'].reshape(-1, 4)[t['slot_src']] * pos.unsqueeze(-1)
-        dbw = pos.unsqueeze(-1).expand(-1, -1, 4)
-        exp = lambda x: x[None].expand(nl, *x.shape)
-        d3 = self._set_losses(dn_cls, dn_box, exp(dlabels), exp(dbt), exp(dbw), None, None, st.img_shapes,
-                              factors=t['factors'], cls_weight=exp(t['slot_inpad']), scales=t['scales'][1])
+        if 'dn_lab' in t and t['dn_lab'].shape[0] == nl:
+            # built on the host with the rest of the batch block (DetStatic): they depend on the ground truth only
+            dn_lab, dn_bt, dn_bw, dn_cw = t['dn_lab'], t['dn_bt'], t['dn_bw'], t['dn_cw']
+        else:
+            lab_slot = t['gt_lab'].reshape(-1)[t['slot_src']]
+            pos = t['slot_pos']
+            dlabels = torch.where(pos > 0, lab_slot, torch.full_like(lab_slot, self.num_classes))
+            dbt = t['gt_boxn'].reshape(-1, 4)[t['slot_src']] * pos.unsqueeze(-1)
+            dbw = pos.unsqueeze(-1).expand(-1, -1, 4)
+            exp = lambda x: x[None].expand(nl, *x.shape)
+            dn_lab, dn_bt, dn_bw, dn_cw = exp(dlabels), exp(dbt), exp(dbw), exp(t['slot_inpad'])
+        d3 = self._set_losses(dn_cls, dn_box, dn_lab, dn_bt, dn_bw, None, None, st.img_shapes,
+                              factors=t['factors'], cls_weight=dn_cw, scales=t['scales'][1])
         l_cls, l_box, l_iou = d3[:, 0], d3[:, 1], d3[:, 2]  # (nl, 3): rows = d0..d{nl-2}, final
         d['dn_loss_cls'], d['dn_loss_bbox'], d['dn_loss_iou'] = l_cls[nl - 1], l_box[nl - 1], l_iou[nl - 1]
         for l in range(nl - 1):

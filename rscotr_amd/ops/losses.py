@@ -279,3 +279,19 @@ def det_proposals(enc_cls, enc_reg, proposals, K):
     largest class score (torch.topk order: descending; equal scores: lower index first), their class rows, enc_reg + proposals
     and its sigmoid.  enc_cls (B,N,C), enc_reg (B,N,4), proposals (B|1,N,4) (no gradient)."""
     return _DetProposals.apply(enc_cls, enc_reg, proposals.detach(), int(K))
+
+
+def det_targets(q_for_gt, gt_lab, gt_boxn, Q, num_classes):
+    """q_for_gt (S,B,G) int32 (ops.lsap_device), gt_lab (B,G) int64, gt_boxn (B,G,4) -> (labels (S,B,Q) int64, bbox_targets
+    (S,B,Q,4), bbox_weights (S,B,Q,4)) of the assignment (detr_head.py:475-543), one launch."""
+    S, B, G = q_for_gt.shape
+    assert q_for_gt.dtype == torch.int32 and gt_lab.dtype == torch.int64 and gt_lab.shape == (B, G)
+    q_for_gt, gt_lab, gt_boxn = q_for_gt.contiguous(), gt_lab.contiguous(), _f32c(gt_boxn)
+    _chk(q_for_gt, gt_lab, gt_boxn)
+    dev = gt_boxn.device
+    labels = torch.empty((S, B, Q), dtype=torch.int64, device=dev)
+    bt = torch.empty((S, B, Q, 4), dtype=torch.float32, device=dev)
+    bw = torch.empty((S, B, Q, 4), dtype=torch.float32, device=dev)
+    lib.call('rscotr_det_targets', q_for_gt.data_ptr(), gt_lab.data_ptr(), gt_boxn.data_ptr(), labels.data_ptr(), bt.data_ptr(),
+             bw.data_ptr(), S, B, Q, G, int(num_classes), _stream())
+    return labels, bt, bw

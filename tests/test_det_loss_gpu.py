@@ -182,3 +182,26 @@ def test_det_proposals_ties_go_to_the_lower_index(cuda):
         taken = i[v == thr]
         assert torch.equal(taken, at[:len(taken)])
     assert torch.equal(score.cpu(), torch.gather(cls, 1, idx.unsqueeze(-1).expand(-1, -1, C)))
+
+
+@pytest.mark.parametrize('S,B,Q,G', [(7, 2, 600, 32), (7, 4, 900, 64), (1, 1, 30, 32), (3, 2, 100, 0)])
+def test_det_targets_matches_the_scatter_formulation(cuda, S, B, Q, G):
+    """ops.det_targets against the fill + scatter formulation of detr_head.py:475-543 (labels / box targets / box weights of
+    an assignment): identical tensors."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(S * 100 + Q + G)
+    qfg = torch.full((S, B, max(G, 1)), -1, dtype=torch.int32)[:, :, :G].contiguous()
+    for s in range(S):
+        for b in range(B):
+            n = int(torch.randint(0, G + 1, (1,), generator=g)) if G else 0
+            qfg[s, b, :n] = torch.randperm(Q, generator=g)[:n].int()
+    gt_lab = torch.randint(0, 20, (B, G), generator=g)
+    gt_boxn = torch.rand(B, G, 4, generator=g)
+    labels, bt, bw = ops.det_targets(qfg.to(cuda), gt_lab.to(cuda), gt_boxn.to(cuda), Q, 20)
+    q64 = qfg.long()
+    idx = torch.where(q64 >= 0, q64, torch.full_like(q64, Q))
+    idx4 = idx.unsqueeze(-1).expand(-1, -1, -1, 4)
+    want_l = torch.full((S, B, Q + 1), 20, dtype=torch.long).scatter_(2, idx, gt_lab[None].expand(S, -1, -1))[:, :, :Q]
+    want_t = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, gt_boxn[None].expand(S, -1, -1, -1))[:, :, :Q]
+    want_w = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, torch.ones((S, B, G, 4)))[:, :, :Q]
+    assert torch.equal(labels.cpu(), want_l) and torch.equal(bt.cpu(), want_t) and torch.equal(bw.cpu(), want_w)

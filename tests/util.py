@@ -280,6 +280,18 @@ def patch_ops_with_oracle(monkeypatch):
         return idx, score, unact.detach(), unact.sigmoid()
 
     _set('det_proposals', det_proposals)
+
+    def det_targets(q_for_gt, gt_lab, gt_boxn, Q, num_classes):
+        S, B, G = q_for_gt.shape
+        qfg = q_for_gt.long()
+        idx = torch.where(qfg >= 0, qfg, torch.full_like(qfg, Q))
+        idx4 = idx.unsqueeze(-1).expand(-1, -1, -1, 4)
+        labels = torch.full((S, B, Q + 1), num_classes, dtype=torch.long).scatter_(2, idx, gt_lab[None].expand(S, -1, -1))[:, :, :Q]
+        bt = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, gt_boxn[None].expand(S, -1, -1, -1))[:, :, :Q]
+        bw = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, torch.ones((S, B, G, 4)))[:, :, :Q]
+        return labels, bt, bw
+
+    _set('det_targets', det_targets)
     _set('batch_param', lambda p, B: p[None].expand(B, *p.shape))
     _set('patch_merge_norm', patch_merge_norm)
     _set('layer_norm_fork', lambda x, w, b, eps=1e-5: (layer_norm(x, w, b, eps), x))
