@@ -30,7 +30,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA peak, dense (no spa
 BF16X3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 # gemm_bf16x6_kernel (precision mode 3, fp32-accurate): six bf16 MFMAs per fp32-equivalent product
 BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
-PROF_EVERY_GEMM = 4  # one GEMM launch in n carries a pair of HIP events during the roofline rounds
+PROF_EVERY_GEMM = 1  # every GEMM launch of the roofline rounds carries a pair of HIP events (1 in 4 made the choice of the dominant instantiation depend on which launches were drawn)
 
 
 def parse():

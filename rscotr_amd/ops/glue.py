@@ -144,11 +144,13 @@ class _BatchParam(Function):
     def backward(ctx, g):
         p, B = ctx.param, ctx.B
         sk = _sink(p)
-        g = _f32c(g)
         n = p.numel()
+        # (a batch-strided gradient with dense per-image blocks — a slice of a concatenation along the query axis — is read in place)
+        dense = g.dtype == torch.float32 and all(g[b].is_contiguous() and g[b].data_ptr() % 16 == 0 for b in range(B))
+        if not dense:
+            g = _f32c(g)
         if sk is None or B > 7 or n % 4 or not g.is_cuda:
             return g.sum(0), None
-        _chk(g)
         ptrs = [sk[1].data_ptr()] + [g[b].data_ptr() for b in range(B)] + [0] * (7 - B)
         lib.call('rscotr_sum8', *ptrs, B + 1, sk[1].data_ptr(), n, _stream())
         STATE.grad_sink.grad_written(sk[0])

@@ -127,10 +127,14 @@ class _LayerNormSum(Function):
         ctx.bias = b
         y, y2 = y.view(x.shape), y2.view(x.shape)
         ctx.mark_non_differentiable(y2)
+        ctx.set_materialize_grads(False)   # (no zero-filled stand-in for the sum's absent gradient)
+        ctx.out_shape = tuple(x.shape)
         return y, y2
 
     @staticmethod
     def backward(ctx, dy, _):
+        if dy is None:  # (the norm's output was not used by anything that needs a gradient)
+            dy = torch.zeros(ctx.out_shape, dtype=torch.float32, device=ctx.saved_tensors[0].device)
         return _LayerNorm._backward(ctx, dy, None) + (None,)
 
 
