@@ -156,6 +156,12 @@ def main():
     if a.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(a.watchdog, exit=True)
+    # stdout carries ONE JSON line and nothing else: libraries write to file descriptor 1 behind Python's back (RCCL prints
+    # its version banner there at exit, after the JSON line, whatever NCCL_DEBUG says), so descriptor 1 is pointed at stderr for
+    # the life of the process and the JSON line goes to a private duplicate of the real stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -397,7 +403,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
