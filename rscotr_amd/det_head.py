@@ -451,11 +451,18 @@ class DinoTransformerDecoder(TransformerLayerSequence):
             assert reference_points.shape[-1] == 4
             if unit_ratios:  # nothing padded: the valid ratios are ones, every level sees the reference points themselves
                 rp_in = reference_points[:, :, None]        # (B, Q, 1, 4): shared by the levels (no product, no copy)
-                query_pos = _mlp(ops.sine_embed4(reference_points), self.ref_point_head)
+                pos_in = ops.sine_embed4(reference_points)
             else:
                 rp_in = reference_points[:, :, None] * vr4
-                query_pos = _mlp(ops.sine_embed4(rp_in[:, :, 0, :]), self.ref_point_head)
-            output = layer(output, None, values[lid], query_pos=query_pos, attn_masks=attn_mask,
+                pos_in = ops.sine_embed4(rp_in[:, :, 0, :])
+            # query_pos = ref_point_head(...); the layer's first attention adds it to `output`: that sum leaves the MLP's last
+            # epilogue as a second output (values only) instead of an element-wise add inside the attention wrapper
+            head = [(m.weight, m.bias) for m in self.ref_point_head if isinstance(m, nn.Linear)]
+            if ops.STATE.pos_sum:
+                query_pos, q_sum = ops.mlp(pos_in, head, act='relu', sum_with=output)
+            else:
+                query_pos, q_sum = ops.mlp(pos_in, head, act='relu'), None
+            output = layer(output, None, values[lid], query_pos=query_pos, attn_masks=attn_mask, query_sum=q_sum,
                            key_padding_mask=key_padding_mask, reference_points=rp_in, **geom.kwargs())
             # three consumers of a layer's output: the next layer, the box branch, the shared norm
             last = lid == len(self.layers) - 1

@@ -432,10 +432,13 @@ class _MLP(Function):
     `out_scale` (B,) or None: per-sample factor on the last layer's output before the identity is added (the
     DropPath of a Swin block folded into its proj / fc2 Linear): forward rides the epilogue, backward the
     epilogue of dH and the operand staging of dW / db.
-    args: x, identity (Tensor | None), act code, out_scale, then W_1, b_1, ..., W_n, b_n (b may be None)."""
+    `sum_with` (same shape as the output) or None: a second, non-differentiable output `y + sum_with` leaves the last
+    epilogue (the `query + query_pos` of the attention that follows a positional MLP: ops.mha / ops.msda_attention take it as
+    `q_sum`); only without identity / out_scale.
+    args: x, identity (Tensor | None), act code, out_scale, sum_with, then W_1, b_1, ..., W_n, b_n (b may be None)."""
 
     @staticmethod
-    def forward(ctx, x, identity, act, out_scale, *wb):
+    def forward(ctx, x, identity, act, out_scale, sum_with, *wb):
         n = len(wb) // 2
         ws, bs = wb[0::2], wb[1::2]
         K0 = x.shape[-1]
@@ -448,6 +451,10 @@ class _MLP(Function):
             assert x.dim() == 3 and out_scale.numel() == x.shape[0]
             rows_per = x.shape[1]
         id2 = None if identity is None else (x2 if id_is_x else _f32c(identity).reshape(M, -1))
+        s2 = y2 = None
+        if sum_with is not None:
+            assert identity is None and out_scale is None
+            s2 = _f32c(sum_with).reshape(M, -1)
         hs, auxs = [x2], []
         h = x2
         for i in range(n):
@@ -458,8 +465,12 @@ class _MLP(Function):
             if not last and act == ACT_GELU:
                 pre = torch.empty((M, N), dtype=torch.float32, device=x2.device)
             sc = out_scale if last else None
-            h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else act, pre=pre,
-                     resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0)
+            if last and s2 is not None:  # out2 = y + sum_with, y itself stored without it (epilogue's second output)
+                y2 = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+                h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE, resid=s2, out2=y2)
+            else:
+                h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else act, pre=pre,
+                         resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0)
             if not last:
                 hs.append(h)
                 auxs.append(pre if act == ACT_GELU else h)
@@ -470,10 +481,19 @@ class _MLP(Function):
         ctx.biases = bs  # parameter handles only (for the gradient sink); not needed as saved tensors
         ctx.x_shape = x.shape
         ctx.id_shape = None if identity is None else identity.shape
-        return h.view(*x.shape[:-1], h.shape[-1])
+        out = h.view(*x.shape[:-1], h.shape[-1])
+        if y2 is None:
+            return out
+        y2 = y2.view(out.shape)
+        ctx.mark_non_differentiable(y2)
+        ctx.set_materialize_grads(False)
+        ctx.two_outputs = True
+        return out, y2
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsum=None):
+        if dy is None:  # (only the non-differentiable sum was used)
+            return (None,) * (5 + 2 * ctx.n)
         n, act = ctx.n, ctx.act
         saved = ctx.saved_tensors
         hs, auxs, ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
@@ -487,8 +507,8 @@ class _MLP(Function):
         for i in range(n - 1, -1, -1):
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
             N, K = W.shape
-            want_w = ctx.needs_input_grad[4 + 2 * i]
-            want_b = ctx.has_bias[i] and ctx.needs_input_grad[5 + 2 * i]
+            want_w = ctx.needs_input_grad[5 + 2 * i]
+            want_b = ctx.has_bias[i] and ctx.needs_input_grad[6 + 2 * i]
             # the last layer's upstream gradient is s_b * dy: folded into the three contractions that read it
             sc = ctx.out_scale if i == n - 1 else None
             sck = dict(kscale=sc, krows_per=ctx.rows_per) if sc is not None else {}
@@ -525,24 +545,25 @@ class _MLP(Function):
             elif ctx.needs_input_grad[0]:
                 # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
                 dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr).view(ctx.x_shape)
-        return (dx, d_id, None, None, *grads_wb)
+        return (dx, d_id, None, None, None, *grads_wb)
 
 
-def mlp(x, layers, act='relu', identity=None, out_scale=None):
+def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None):
     """layers: [(W, b), ...]; activation between layers, none after the last; `identity` (same shape
     as the output) is added in the last epilogue (mmcv FFN add_identity); `out_scale` (B,) multiplies the
-    output per sample before that (DropPath)."""
+    output per sample before that (DropPath).  With `sum_with` (shape of the output, values only): -> (y, y + sum_with), the
+    sum without a gradient of its own."""
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _MLP.apply(x, identity, _ACT[act], out_scale, *flat)
+    return _MLP.apply(x, identity, _ACT[act], out_scale, None if sum_with is None else sum_with.detach(), *flat)
 
 
 def linear(x, w, b=None, act=None, resid=None, out_scale=None):
     """F.linear(x, w, b) [* out_scale per sample] (+ resid) on the matrix cores.  Activations belong to `mlp`."""
     if act is not None:
         raise RuntimeError('ops.linear has no activation: use ops.mlp')
-    return _MLP.apply(x, resid, ACT_NONE, out_scale, w, b)
+    return _MLP.apply(x, resid, ACT_NONE, out_scale, None, w, b)
 
 
 def _attn_ksplits(M, N, K, nb):

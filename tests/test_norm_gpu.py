@@ -125,3 +125,41 @@ def test_attention_nodes_accept_producer_formed_sums(cuda):
 
     for a, b in zip(run_msda(False), run_msda(True)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('M,dims', [(1600, (512, 256, 256)), (200, (512, 256, 256)), (37, (64, 128, 32))])
+def test_mlp_sum_output(cuda, M, dims):
+    """ops.mlp(..., sum_with=s) -> (y, y + s): y and its gradients as without the sum, the sum carries values only (the
+    `query + query_pos` a DINO decoder layer's first attention would form from the positional MLP's output)."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(M + dims[0])
+    x = torch.randn(2, M // 2 if M % 2 == 0 else M, dims[0], generator=g)
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    s = torch.randn(*x.shape[:-1], dims[-1], generator=g)
+    dy = torch.randn(*x.shape[:-1], dims[-1], generator=g)
+
+    def run(with_sum):
+        xd = x.to(cuda).requires_grad_(True)
+        layers = [(w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)) for w, b in zip(Ws, bs)]
+        sd = s.to(cuda).requires_grad_(True)
+        out = ops.mlp(xd, layers, act='relu', sum_with=sd if with_sum else None)
+        y, ysum = out if with_sum else (out, None)
+        y.backward(dy.to(cuda))
+        torch.cuda.synchronize()
+        assert sd.grad is None
+        return y.detach(), ysum, xd.grad, [w.grad for w, _ in layers], [b.grad for _, b in layers], sd
+
+    y0, _, gx0, gw0, gb0, _ = run(False)
+    y1, ysum, gx1, gw1, gb1, sd = run(True)
+    assert not ysum.requires_grad
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    for a, b in zip(gw0 + gb0, gw1 + gb1):
+        assert torch.equal(a, b)
+    assert torch.allclose(ysum, y1 + sd.detach(), rtol=0, atol=1e-6)
+    ref = x.double()
+    for i, (w, b) in enumerate(zip(Ws, bs)):
+        ref = ref @ w.double().t() + b.double()
+        if i < len(Ws) - 1:
+            ref = torch.relu(ref)
+    assert _rel(y1, ref) <= 1e-5

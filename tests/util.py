@@ -70,13 +70,16 @@ def patch_ops_with_oracle(monkeypatch):
         y = _scaled(F.linear(x, w, b), out_scale)
         return y if resid is None else y + resid
 
-    def mlp(x, layers, act='relu', identity=None, out_scale=None):
+    def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None):
         h = x
         for i, (w, b) in enumerate(layers):
             h = F.linear(h, w, b)
             if i < len(layers) - 1:
                 h = F.relu(h) if act == 'relu' else F.gelu(h)
         h = _scaled(h, out_scale)
+        if sum_with is not None:
+            assert identity is None
+            return h, (h + sum_with).detach()
         return h if identity is None else identity + h
 
     def layer_norm(x, w, b, eps=1e-5):
