@@ -1,4 +1,4 @@
-"""LAB: planes x planes product (both operands pre-split) against the shipped routes.  python scripts/lab/pplanes_lab.py"""
+"""LAB: planes x planes product (both operands pre-split) against the shipped routes.  Needs the lab kernel: `git apply scripts/lab/pplanes_kernel.patch` and rebuild first (the entry rscotr_gemm_f32_pplanes is not in the tree).  python scripts/lab/pplanes_lab.py"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
