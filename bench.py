@@ -1,7 +1,8 @@
 """Benchmark of the RSCoTr multi-task co-training step on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank
-per GPU over RCCL).  A bench "step" is ONE ROUND of the reference's round-robin alternation
+`python bench.py --gpus N --steps K --warmup W`: N > 1 ranks are either started by a launcher (the driver:
+torch.distributed.run, one rank per GPU over RCCL; WORLD_SIZE must equal --gpus) or, when no launcher is in the
+environment, by this script itself (spawn_ranks).  A bench "step" is ONE ROUND of the reference's round-robin alternation
 (cls batch, det batch, seg batch — SURVEY.md §8d), i.e. 3 train iterations = 3*B images per GPU,
 each with forward, loss, backward, gradient exchange, global-norm clip and AdamW.  Prints one JSON
 line on rank 0 (contract in the task statement): images/sec whole-job, the roofline of the MSDA
@@ -54,6 +55,14 @@ def parse():
     ap.add_argument('--host-trace', action='store_true', help='per-iteration HOST times (no sync) on stderr')
     ap.add_argument('--watchdog', type=int, default=0,
                     help='dump all Python stacks and exit if the run takes longer than this many seconds')
+    ap.add_argument('--launcher', choices=('auto', 'spawn', 'none'), default='auto',
+                    help='auto: with --gpus N > 1 and no WORLD_SIZE in the environment, start the N ranks here (torch.distributed.run, '
+                         'one process per GPU over RCCL) — tools/train.py:173-182 / mtl/apis/train.py:37-46; spawn: do that for N = 1 '
+                         'too; none: never (this process is the only rank)')
+    ap.add_argument('--exchange', choices=('inline', 'overlap'), default=None,
+                    help='form of the gradient exchange inside the captured iteration (rscotr_amd/dist.py): inline = collectives on '
+                         'the compute stream after backward; overlap = bucket all-reduces on RCCL\'s stream under backward '
+                         '(torch DDP\'s form). Default: RSCOTR_DIST_INLINE, else inline')
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     a.size = a.size or w['size']
@@ -149,10 +158,39 @@ def cpu_baseline(size, batch, rounds, workload='mtl512', limit_s=420):
                     sample=f'one round did not finish within {limit_s}s on the host cores')
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` started by hand (no launcher in the environment): start the N ranks — what the reference's
+    `init_dist(args.launcher, ...)` expects a launcher to have done (tools/train.py:173-182) — by re-running this command under
+    `torch.distributed.run` on 127.0.0.1, one process per GPU.  Rank 0 of the children prints the ONE JSON line on the stdout
+    they inherit.  -> exit code of the launcher."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus}: this node shows {n_dev} GPU(s)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(a.gpus, 1))))
+    print(f'[bench] starting {a.gpus} rank(s): {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
     if a.cpu_baseline_worker:
         return cpu_baseline_worker(a.size, a.batch, a.cpu_rounds, a.workload)
+    if a.exchange is not None:  # read by rscotr_amd.dist at import (below)
+        os.environ['RSCOTR_DIST_INLINE'] = '1' if a.exchange == 'inline' else '0'
+    launched = 'WORLD_SIZE' in os.environ
+    if not launched and a.launcher != 'none' and (a.gpus > 1 or a.launcher == 'spawn'):
+        sys.exit(spawn_ranks(a))
+    if int(os.environ.get('WORLD_SIZE', '1')) != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get("WORLD_SIZE", "unset (1 rank)")}: the bench line '
+                         'would not be an N-GPU measurement — launch N ranks (or drop --launcher none)')
     if a.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(a.watchdog, exit=True)
@@ -396,6 +434,8 @@ def main():
                                optimizer='AdamW+clip0.1 (fused HIP)', precision='fp32',
                                gemm_precision_mode={0: 'fp32', 1: 'bf16x3', 2: 'bf16x3-big', 3: 'bf16x6'}[lib.rscotr_gemm_get_precision()],
                                rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0,
+                               exchange=(('inline' if os.environ.get('RSCOTR_DIST_INLINE', '1') != '0' else 'overlap')
+                                         if dist.is_initialized() else None),
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region

@@ -337,6 +337,18 @@ class DetStatic:
                 self.t[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device, non_blocking=True)
             f = self.t['factors']
             self.t['gt_boxn'] = ops.bbox_xyxy_to_cxcywh(gt_box / f[:, None, :])
+            # the same key set as the host-packed path (a captured iteration refreshes its static tensors key by key:
+            # update_into): denoising targets in slot layout (dino_head.py:323-365) and the per-set ground-truth counts
+            nl = head.transformer.decoder.num_layers
+            t = self.t
+            lab_slot = gt_lab.reshape(-1)[t['slot_src']]
+            pos = t['slot_pos']
+            rep = lambda a: a[None].expand(nl, *a.shape).contiguous()
+            t['dn_lab'] = rep(torch.where(pos > 0, lab_slot, torch.full_like(lab_slot, head.num_classes)))
+            t['dn_bt'] = rep(t['gt_boxn'].reshape(-1, 4)[t['slot_src']] * pos.unsqueeze(-1))
+            t['dn_bw'] = rep(pos.unsqueeze(-1).expand(-1, -1, 4))
+            t['dn_cw'] = rep(t['slot_inpad'])
+            t['gcount_s'] = t['gcount'].repeat(nl + 1)
         if not one_rank:
             # every reduce_mean of the reference's det losses (detr_head.py:379-381,389-390; dino_head.py:266-268,
             # 282-283) averages one of these four numbers over the ranks: one small all-reduce, here, outside
@@ -399,8 +411,12 @@ class DetStatic:
                 if k in self.t and k not in packed:
                     static.t[k].copy_(self.t[k], non_blocking=True)
         else:
+            missing = [k for k in self.KEYS if (k in static.t) != (k in self.t)]
+            if missing:
+                raise RuntimeError(f'DetStatic.update_into: the captured iteration and this batch hold different tensors {missing}')
             for k in self.KEYS:
-                static.t[k].copy_(self.t[k], non_blocking=True)
+                if k in self.t:
+                    static.t[k].copy_(self.t[k], non_blocking=True)
         for a in ('counts', 'max_gt', 'ng', 'single_pad', 'pad_size'):
             setattr(static, a, getattr(self, a))
 

@@ -153,6 +153,11 @@ class GraphedTask:
         drops its graph, resets the exchange state and captures again in the split form.  Only errors of the capture
         itself are caught (RuntimeError from HIP / RCCL / torch's graph machinery); anything else propagates."""
         err = None
+        # state of the optimizer BEFORE any attempt: a rank whose capture succeeded has already announced the captured
+        # iteration (prepare_step after the roll-back of its warm-ups: step counts + 1); if the ranks then agree to fall back,
+        # every rank starts its second attempt from this same state, or the Adam bias corrections would differ between the
+        # ranks for the rest of the run (ADVICE r3, medium)
+        snap0 = self.opt.snapshot() if self.exchange_in_graph else None
         try:
             self._warm_and_capture()
         except RuntimeError as e:
@@ -166,6 +171,8 @@ class GraphedTask:
         import torch.distributed as dist
         torch.cuda.synchronize()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if os.environ.get('RSCOTR_TEST_CAPTURE_VETO') == '1':  # test hook: "another rank's capture failed" (tests/test_dist_gpu.py)
+            ok.zero_()
         if int(ok.item()) == 1:
             return
         import warnings
@@ -177,7 +184,14 @@ class GraphedTask:
         self.runner.sync.reset_step()
         ops.DEFER.drop()
         self.exchange_in_graph, self.split = False, True
+        self.opt.restore(snap0)
         self._warm_and_capture()
+        steps = torch.tensor([float(self.opt.steps.sum())], dtype=torch.float64, device=self.static['img'].device)
+        lo, hi = steps.clone(), steps.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(lo.item()) != float(hi.item()):
+            raise RuntimeError(f'optimizer step counts differ between the ranks after the capture fallback ({lo.item()} / {hi.item()})')
 
     def _replay(self):
         self.graph.replay()

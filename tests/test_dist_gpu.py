@@ -39,7 +39,8 @@ with runner.on_stream():
         last.update({k: float(v) for k, v in out['log_vars'].items() if k.endswith('.loss')})  # (the task's latest loss)
 torch.cuda.synchronize()
 norm = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in model.parameters())))
-print('RESULT ' + json.dumps(dict(losses=last, param_norm=norm, graphed=sorted(runner.graphed))))
+print('RESULT ' + json.dumps(dict(losses=last, param_norm=norm, graphed=sorted(runner.graphed), steps=int(runner.optimizer.steps.sum()),
+                                  split=sorted(t for t, g in runner.graphed.items() if g.split))))
 if dist.is_initialized():
     dist.destroy_process_group()
 '''
@@ -63,6 +64,22 @@ def test_one_rank_distributed_paths_train_like_the_plain_run(cuda):
         assert abs(got['param_norm'] - plain['param_norm']) <= 1e-6 * plain['param_norm'], (extra, got, plain)
         for k, v in plain['losses'].items():
             assert abs(got['losses'][k] - v) <= 2e-3 * max(abs(v), 1e-3), (extra, k, got['losses'][k], v)
+
+
+def test_capture_fallback_keeps_the_step_counts(cuda):
+    """when the ranks agree to drop a captured iteration (one of them failed to capture the RCCL
+    collectives), a rank whose capture had SUCCEEDED must start its second attempt from the optimizer state before the first
+    one — it has already announced the captured iteration (step counts + 1).  One-rank RCCL group with the veto hook (MIN over
+    ranks forced to "failed"): every task ends in the split form, and step counts, weights and losses equal the run that
+    took the split form from the start."""
+    want = _run({'RSCOTR_DIST_SINGLE': '1', 'RSCOTR_DIST_CAPTURE': '0'}, 29551)
+    got = _run({'RSCOTR_DIST_SINGLE': '1', 'RSCOTR_TEST_CAPTURE_VETO': '1'}, 29552)
+    assert got['graphed'] == want['graphed'] == ['cls', 'det', 'seg']
+    assert got['split'] == want['split'] == ['cls', 'det', 'seg']
+    assert got['steps'] == want['steps'], (got['steps'], want['steps'])
+    assert abs(got['param_norm'] - want['param_norm']) <= 1e-7 * want['param_norm'], (got, want)
+    for k, v in want['losses'].items():
+        assert abs(got['losses'][k] - v) <= 1e-4 * max(abs(v), 1e-3), (k, got['losses'][k], v)
 
 
 _CHILD2 = r'''

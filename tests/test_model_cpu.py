@@ -57,6 +57,41 @@ def test_det_static_path_equals_dynamic_path(tiny, monkeypatch, seed):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+def test_det_static_refresh_without_host_ground_truth(tiny, monkeypatch):
+    """a captured det iteration refreshes its static tensors key by key (DetStatic.update_into).  A batch
+    WITHOUT host copies of its ground truth (any loader other than synth / pipeline) must carry the same tensors as a
+    host-packed one — same keys, same values — and must refresh a static built either way."""
+    patch_ops_with_oracle(monkeypatch)
+    import numpy as np
+    from rscotr_amd import synth
+    from rscotr_amd.det_head import DetStatic
+    mcfg, model = tiny
+    head, dev = model.bbox_head, torch.device('cpu')
+    b1, b2 = synth.make_batch('det', 2, 64, seed=3), synth.make_batch('det', 2, 64, seed=8)
+    mk = lambda b, host, **kw: DetStatic(head, b['gt_bboxes'], b['gt_labels'], b['img_metas'], dev,
+                                         gt_host=(b['gt_bboxes_host'], b['gt_labels_host']) if host else None, **kw)
+    packed = mk(b1, True)
+    caps = dict(gcap=packed.gcap, padcap=packed.padcap)
+    plain = mk(b1, False, **caps)
+    assert set(plain.t) == set(packed.t) == set(DetStatic.KEYS)
+    for k in DetStatic.KEYS:
+        a, b = packed.t[k], plain.t[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-7), k
+    # a device-path batch refreshes a static captured from a device-path batch and one captured from a packed batch
+    for static in (mk(b1, False, **caps), mk(b1, True, **caps)):
+        nxt = mk(b2, False, **caps)
+        nxt.update_into(static)
+        for k in DetStatic.KEYS:
+            assert torch.equal(static.t[k], nxt.t[k]), k
+        assert static.counts == nxt.counts
+    # and a packed batch refreshes a static captured from a device-path batch
+    static, nxt = mk(b1, False, **caps), mk(b2, True, **caps)
+    nxt.update_into(static)
+    for k in DetStatic.KEYS:
+        assert torch.equal(static.t[k], nxt.t[k]), k
+
+
 def test_log_keys_per_task(tiny, monkeypatch):
     """log_vars naming contract (multitask_learner.py:235-243, dino_head.py:183-232)."""
     patch_ops_with_oracle(monkeypatch)
