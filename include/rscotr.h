@@ -142,6 +142,38 @@ int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int npad, float*
                             const float* bias, int act, const float* aux, float* pre, const float* resid, int accumulate,
                             const float* rowscale, int rows_per_scale, float* out2, float* workspace,
                             int64_t workspace_bytes, void* stream);
+/* The same six-term product with BOTH operands as plane sets, fed by LDS-DMA (csrc/gemm_pp.hip).  A plane set holds the three
+ * bf16 planes (h, m, l: x = h + m + l exactly) of a stored fp32 tensor X (rows x cols, cols contiguous) in the ST32 layout: rows
+ * and cols padded with zeros to multiples of 32; 32 x 32 super-tiles in row-major order, three planes of 2 KB per super-tile,
+ * inside a plane 128 units of 16 bytes, unit (r, c8) = row r, columns 8 c8 .. 8 c8 + 7 at slot 32 c8 + 16 (r / 16) +
+ * 4 ((r / 4 + c8) & 3) + (r & 3).  rscotr_planes_bytes(rows, cols) = ceil(rows / 32) * ceil(cols / 32) * 6144.
+ * rscotr_split_planes writes the plane set of X; rowscale (may be NULL): row r is multiplied by rowscale[r / rows_per_scale]
+ * first (the per-sample DropPath / Mixup factor folded into the Linear: the planes of s * dy serve dx and dW alike);
+ * colsum_parts (may be NULL): (rscotr_split_planes_parts(rows), cols) floats, row g = the column sums of the (scaled) rows
+ * 256 g .. 256 g + 255 — the bias gradient of the Linear whose dy is being split, as partial rows for rscotr_splitk_flush
+ * (its row-sum columns: {0, colsum_parts, 0, db, cols, 0, 0, parts}).
+ * rscotr_gemm_pp: C[m, n] = epilogue(sum_k Aop[m, k] Bop[n, k]), epilogue arguments as rscotr_gemm_f32.  ONE plane set serves
+ * both uses of a tensor: x_col = 0 ("row mode"): the operand's rows are the stored rows and the reduction runs over the
+ * stored columns (x in y = x W^T, dy in dx = dy W, W in y = x W^T); x_col = 1 ("col mode"): the operand's rows are the
+ * stored COLUMNS and the reduction runs over the stored rows (dy and x in dW = dy^T x, W in dx = dy W) — read through the
+ * LDS transpose read of gfx950.  x_ct = column tiles ceil(cols / 32) of the stored tensor.  Any M, N, K (tiles past the
+ * operands are clamped reads / guarded stores; the reduction is zero-padded inside the planes).  Short grids are cut into
+ * k-slices through `workspace` (rscotr_gemm_pp_workspace bytes; fixed-order combine); defer != 0: the combine is left to
+ * rscotr_splitk_flush (slabs [splits][M][N] stay in `workspace`; *splits_out (HOST int, required then) = slabs written, 1 =
+ * C already holds the result).  Replaces torch F.linear and the two backward contractions autograd derives from it, for the
+ * large Linears of the step (cfg ...potsdam.py:9-25, 34-50). */
+int64_t rscotr_planes_bytes(int rows, int cols);
+int rscotr_split_planes_parts(int rows);
+int rscotr_split_planes(const float* X, int rows, int cols, int ld, void* planes, const float* rowscale,
+                        int rows_per_scale, float* colsum_parts, void* stream);
+/* many tensors (the parameters a task multiplies with, once per optimizer step) in ONE launch: table = device (n, 8) int64 rows
+ * {X, planes, rows, cols, ld, first block, 0, 0}; an entry takes ceil(cols / 32) * ceil(32 ceil(rows / 32) / 256) blocks */
+int rscotr_split_planes_group(const int64_t* table, int n, int total_blocks, void* stream);
+int64_t rscotr_gemm_pp_workspace(int M, int N, int K);
+int rscotr_gemm_pp(const void* a_planes, int a_ct, int a_col, const void* b_planes, int b_ct, int b_col, float* C,
+                   int M, int N, int K, int ldc, const float* bias, int act, const float* aux, float* pre,
+                   const float* resid, int accumulate, const float* rowscale, int rows_per_scale, float* out2,
+                   float* workspace, int64_t workspace_bytes, int defer, int32_t* splits_out, void* stream);
 int rscotr_gemm_set_precision(int prec);
 int rscotr_gemm_get_precision(void);
 int64_t rscotr_gemm_f32_workspace(int M, int N, int K);

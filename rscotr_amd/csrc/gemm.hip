@@ -29,7 +29,7 @@
 // workgroup was tried: the device-scope fences it needs write back / invalidate the whole per-XCD L2 on
 // every workgroup and made the step 2.5x slower.)
 // A k-major A operand can also deliver its row sums over k (the bias gradient of the dW contraction).
-#include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -41,209 +41,6 @@
 #endif
 
 namespace rscotr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_GRAD = 3, ACT_GELU_GRAD = 4 };
-
-constexpr int GEMM_BK = 16;
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-
-struct GemmParams {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* bias;
-  const float* aux;
-  float* pre;
-  const float* resid;
-  float* C2;          // optional second output (same ldc): C2 = C + resid while C itself is stored WITHOUT the residual
-                      // (a gradient that is wanted both alone and merged with another one: no element-wise add launch)
-  int M, N, K;
-  int lda, ldb, ldc;
-  int act, accumulate;
-  int vecA, vecB;     // 16-byte vector loads legal for this operand
-  int vecC;           // C / aux / pre / resid / bias: 16-byte accesses legal at (m, n % 4 == 0) (split-K combine)
-  int ksplit_len;     // k elements per split (multiple of GEMM_BK)
-  int splits;         // > 1: split-K through slabs, combined by gemm_splitk_reduce_kernel
-  int tiles;          // output tiles (tiles_m * tiles_n)
-  float* slabs;       // [splits][M][N] when splits > 1
-  float* rs_slabs;    // [splits][M] row-sum partials when splits > 1 and rowsum
-  float* rowsum;      // a_kmajor only: rowsum[m] (+)= sum_k Aop[m,k]  (bias gradient riding the dW contraction)
-  int rowsum_acc;
-  // batched mode (nb1 > 0): blockIdx.y = (b0 * nb1 + b1) * nb2 + b2 selects the problem; element offsets per
-  // level (level 2 is used to cut a long reduction into slices that write separate slabs)
-  int nb1, nb2;
-  long sA0, sA1, sA2, sB0, sB1, sB2, sC0, sC1, sC2;
-  // per-sample scaling (stochastic depth folded into the Linear around it): the epilogue multiplies row m by
-  // rowscale[m / rows_per]; a k-major A operand is multiplied by kscale[k / krows_per] while it is staged
-  const float* rowscale;
-  const float* kscale;
-  int rows_per, krows_per;
-};
-
-__device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
-
-__device__ __forceinline__ float epilogue_one(const GemmParams& p, float v, int m, int n) {
-  if (p.bias) v += p.bias[n];
-  const long o = (long)m * p.ldc + n;
-  if (p.pre) p.pre[o] = v;
-  switch (p.act) {
-    case ACT_RELU: v = fmaxf(v, 0.f); break;
-    case ACT_GELU: v = gelu_f(v); break;
-    case ACT_RELU_GRAD: v = p.aux[o] > 0.f ? v : 0.f; break;
-    case ACT_GELU_GRAD: v *= gelu_grad_f(p.aux[o]); break;
-    default: break;
-  }
-  if (p.rowscale) v *= p.rowscale[m / p.rows_per];
-  if (p.C2) {
-    if (p.accumulate) v += p.C[o];
-    p.C2[o] = p.resid ? v + p.resid[o] : v;
-    return v;
-  }
-  if (p.resid) v += p.resid[o];
-  if (p.accumulate) v += p.C[o];
-  return v;
-}
-
-// Four consecutive columns of one row (n % 4 == 0, p.vecC): every load is issued before the first store — the
-// element-wise form chains load -> store four times, and each wait also drains the store queued before it.
-__device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, int m, int n) {
-  const long o = (long)m * p.ldc + n;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = a, c = a;
-  const bool need_aux = p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD;
-  if (need_aux) a = *reinterpret_cast<const float4*>(p.aux + o);
-  if (p.resid) r = *reinterpret_cast<const float4*>(p.resid + o);
-  if (p.accumulate) c = *reinterpret_cast<const float4*>(p.C + o);
-  if (p.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-  }
-  if (p.pre) *reinterpret_cast<float4*>(p.pre + o) = v;
-  switch (p.act) {
-    case ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
-    case ACT_GELU: v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); break;
-    case ACT_RELU_GRAD:
-      v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
-      break;
-    case ACT_GELU_GRAD:
-      v.x *= gelu_grad_f(a.x); v.y *= gelu_grad_f(a.y); v.z *= gelu_grad_f(a.z); v.w *= gelu_grad_f(a.w);
-      break;
-    default: break;
-  }
-  if (p.rowscale) {
-    const float f = p.rowscale[m / p.rows_per];
-    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
-  }
-  if (p.C2) {
-    if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-    *reinterpret_cast<float4*>(p.C + o) = v;
-    *reinterpret_cast<float4*>(p.C2 + o) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
-    return;
-  }
-  if (p.resid) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-  if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-  *reinterpret_cast<float4*>(p.C + o) = v;
-}
-
-// Staged epilogue of four consecutive rows m..m+3 of one column n (v already holds accumulator + bias): the loads of
-// the four rows are issued together, phase by phase (aux -> row scale -> residual -> old C), ahead of the C stores.
-// epilogue_one in a loop costs one dependent load latency per element because the stores in between may alias (~40 %
-// of a K = 256 tile); four rows at a time keep the 64x64 kernels at 55-76 VGPRs (8 rows: 75-96, 16 rows: 110-170;
-// measured on the step: 41.3 / 42.0 / 43.0 ms of GEMM per round against 44.3 element-wise).
-template <bool EDGE>
-__device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4], int m, int n) {
-  float x[4];
-  int o[4];  // element offsets from row m
-  bool ok[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    ok[u] = !EDGE || m + u < p.M;
-    o[u] = u * p.ldc;
-  }
-  const long base = (long)m * p.ldc + n;
-  float* crow = p.C + base;
-  if (p.pre) {  // (stores do not hold back the loads issued after them; only load -> use -> store chains hurt)
-    float* pp = p.pre + base;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (ok[u]) pp[o[u]] = v[u];
-  }
-  if (p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) {
-    const float* auxp = p.aux + base;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = ok[u] ? auxp[o[u]] : 0.f;
-  }
-  switch (p.act) {
-    case ACT_RELU:
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-      break;
-    case ACT_GELU:
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = gelu_f(v[u]);
-      break;
-    case ACT_RELU_GRAD:
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = x[u] > 0.f ? v[u] : 0.f;
-      break;
-    case ACT_GELU_GRAD:
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] *= gelu_grad_f(x[u]);
-      break;
-    default: break;
-  }
-  if (p.rowscale) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = ok[u] ? p.rowscale[(m + u) / p.rows_per] : 1.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] *= x[u];
-  }
-  if (p.C2) {  // C = value (+ old C), C2 = C + resid
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.resid) {
-      const float* rp = p.resid + base;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = ok[u] ? rp[o[u]] : 0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = ok[u] ? crow[o[u]] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] += x[u];
-    }
-    float* c2 = p.C2 + base;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (ok[u]) { crow[o[u]] = v[u]; c2[o[u]] = v[u] + r[u]; }
-    return;
-  }
-  if (p.resid) {
-    const float* rp = p.resid + base;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = ok[u] ? rp[o[u]] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] += x[u];
-  }
-  if (p.accumulate) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = ok[u] ? crow[o[u]] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] += x[u];
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (ok[u]) crow[o[u]] = v[u];
-}
 
 // Load the (R rows x 16 k) operand tile at (row0, k0) into registers: NV float4 per thread.
 template <int R, bool KMAJOR>
@@ -377,13 +174,6 @@ struct TileLoader {
   }
 };
 
-// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, used for speed
-// only); give each XCD a contiguous run of tiles in row-major (tile_m, tile_n) order so that the
-// A row-panel a run shares is fetched into ONE private L2 (bijective for any tile count).
-__device__ __forceinline__ int xcd_swizzle(int id, int n) {
-  const int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
 
 // EDGE = false: the host guarantees M % BM == 0, N % BN == 0, every k range a whole number of k-tiles and
 // 16-byte vector loads legal on both operands — no bounds logic is compiled in (10-30 % faster on the
@@ -944,18 +734,6 @@ static void launch_bf16x3_big(const GemmParams& p, unsigned nwg, hipStream_t s) 
 // two barriers per k-tile (1-3 resident workgroups cover each other), 64 x 64 tiles double-buffered with one barrier.
 // Interior shapes only (host-checked); split-K slabs, deferred combine, bias-gradient row sums, per-sample k scaling and
 // the staged epilogue are shared with the kernels above.
-template <int NPL>
-__device__ __forceinline__ void split_planes(float x, __bf16 (&p)[3]) {
-  p[0] = (__bf16)x;
-  const float r1 = x - (float)p[0];
-  p[1] = (__bf16)r1;
-  if (NPL == 3) p[2] = (__bf16)(r1 - (float)p[1]);
-}
-
-__device__ __forceinline__ unsigned pack_bf16(__bf16 a, __bf16 b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
 // The planes of TWO adjacent values as packed dwords (low half = a, high half = b): the same conversions and exact
 // subtractions as split_planes, written on 2-vectors so that they compile to v_cvt_pk_bf16_f32 (two conversions and the
 // pack in one instruction), one mask + one shift for the way back and v_pk_add_f32 for the two subtractions: 9 VALU
@@ -2283,6 +2061,8 @@ static void launch_splitk_reduce(const GemmParams& p, const float* workspace, hi
   else if (vec) gemm_splitk_reduce_kernel<true><<<blocks, 256, 0, s>>>(p);
   else gemm_splitk_reduce_kernel<false><<<blocks, 256, 0, s>>>(p);
 }
+
+void splitk_reduce_launch(const GemmParams& p, const float* workspace, hipStream_t s) { launch_splitk_reduce(p, workspace, s); }
 
 }  // namespace rscotr
 

@@ -1,0 +1,482 @@
+// LAB (round 4): planes x planes split-product GEMM fed by LDS-DMA (global_load_lds), stand-alone.
+//   hipcc --offload-arch=gfx950 -O3 -o pp_lab scripts/lab/pp_lab.hip && ./pp_lab [probe|check|time]
+// C[P x Q] = sum_k Aop[p,k] Bop[q,k], every operand given as a bf16 PLANE SET in the "ST32" layout:
+//   stored tensor X (R rows, C cols, C contiguous), padded to multiples of 32; super-tile (rt, ct) = 32 x 32 elements; per
+//   super-tile three planes (h, m, l) of 2 KB each; inside a plane 128 units of 16 bytes = (row r, 8 consecutive cols c8*8..):
+//     slot(r, c8) = c8*32 + 16*(r/16) + 4*((r/4 + c8) & 3) + (r & 3)
+//   ROW mode (MFMA rows = stored rows, contraction = stored cols): lane (r = lane & 31, g = lane >> 5) reads unit
+//   (r, c8 = 2*ks + g) with one ds_read_b128 — conflict-free (the 16 rows of a b128 lane group fall on 16 distinct slots mod 16).
+//   COL mode (MFMA rows = stored cols, contraction = stored rows): ds_read_b64_tr_b16 on the same image — conflict-free too
+//   (4 rows x 4 c8 of a 32-lane group fall on 16 distinct slots mod 16).  One plane set serves both uses of a tensor.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__host__ __device__ inline int st32_slot(int r, int c8) { return c8 * 32 + ((r >> 4) << 4) + ((((r >> 2) + c8) & 3) << 2) + (r & 3); }
+// unit index (16-byte units) of (row, col8 = col / 8), CT = column tiles of the stored tensor
+__host__ __device__ inline long st32_unit(int row, int col8, int CT, int pl) {
+  const long tile = ((long)(row >> 5) * CT + (col8 >> 2)) * 3 + pl;
+  return tile * 128 + st32_slot(row & 31, col8 & 3);
+}
+
+// ------------------------------------------------------------------ tr probe
+__global__ void tr_probe_kernel(short* out) {
+  __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+  for (int j = 0; j < 4; ++j) lds[threadIdx.x * 4 + j] = (short)(threadIdx.x * 4 + j);  // chunk of lane l = elements 4l .. 4l+3
+  __syncthreads();
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + threadIdx.x * 4));
+  out[threadIdx.x * 4 + 0] = v.x; out[threadIdx.x * 4 + 1] = v.y; out[threadIdx.x * 4 + 2] = v.z; out[threadIdx.x * 4 + 3] = v.w;
+}
+
+// ------------------------------------------------------------------ split: fp32 (R x C, ld) -> ST32 planes (zero padded)
+__device__ __forceinline__ void split3(float x, unsigned short (&p)[3]) {
+  __bf16 h = (__bf16)x;
+  float r1 = x - (float)h;
+  __bf16 m = (__bf16)r1;
+  float r2 = r1 - (float)m;
+  __bf16 l = (__bf16)r2;
+  p[0] = __builtin_bit_cast(unsigned short, h); p[1] = __builtin_bit_cast(unsigned short, m); p[2] = __builtin_bit_cast(unsigned short, l);
+}
+__global__ void split_st32_kernel(const float* __restrict__ X, int R, int C, int ld, uint4* __restrict__ planes, int RT, int CT) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8n = CT * 4;
+  const long total = (long)RT * 32 * c8n;
+  if (idx >= total) return;
+  const int row = (int)(idx / c8n), col8 = (int)(idx % c8n);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = col8 * 8 + j;
+    v[j] = (row < R && c < C) ? X[(long)row * ld + c] : 0.f;
+  }
+  unsigned short q[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(v[j], q[j]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    uint4 o;
+    o.x = q[0][pl] | ((unsigned)q[1][pl] << 16); o.y = q[2][pl] | ((unsigned)q[3][pl] << 16);
+    o.z = q[4][pl] | ((unsigned)q[5][pl] << 16); o.w = q[6][pl] | ((unsigned)q[7][pl] << 16);
+    planes[st32_unit(row, col8, CT, pl)] = o;
+  }
+}
+
+// ------------------------------------------------------------------ the product
+struct PPParams {
+  const char* A;   // plane set of the tensor behind the A operand
+  const char* B;
+  float* C;
+  int P, Q, K;     // output rows, output cols, reduction length (K % 16 == 0; P % BM == 0, Q % BN == 0 in the lab)
+  int ctA, ctB;    // column tiles of the stored tensors
+  int ldc;
+  int tiles_q;
+  int splits;      // k-slices: slice s of every tile writes slab s (C + s * P * ldc) — combined by slab_sum_kernel
+  int tiles;
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bx, int gx) {
+  const int q = gx >> 3, r = gx & 7, x = bx & 7, j = bx >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// BM x BN workgroup tile, (BM/64) x (BN/64) wavefronts with 64 x 64 wave tiles; NST ring stages of 16 k.
+// ILV: 0 = the LDS-DMA pieces of stage t + 2 are issued in a block right after the barrier; 1 = one piece after every
+// 24 / PW MFMAs of stage t (the matrix pipe has work queued while a piece is being issued).
+// ABL (ablation, wrong numbers / right timing): 1 = no LDS-DMA in the loop, 2 = no barrier, 4 = no fragment reads in the loop,
+// 8 = no MFMAs
+template <int BM, int BN, bool ACOL, bool BCOL, int NST, int ILV, int ABL = 0>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void pp_gemm_kernel(PPParams p) {
+  constexpr int WM = BM / 64, WN = BN / 64, NW = WM * WN;
+  constexpr int NA = BM / 32 * 3, NB = BN / 32 * 3, NP = NA + NB;   // 1 KB pieces per stage
+  constexpr int PW = (NP + NW - 1) / NW;                            // pieces per wavefront per stage
+  constexpr int STAGE = NP * 1024;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int idx = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = idx / p.tiles, tile = idx - split * p.tiles;   // (all tiles of a k-slice are neighbours: they share operands)
+  const int tp = tile / p.tiles_q, tq = tile % p.tiles_q;
+  const int nk_all = (p.K + 15) / 16;
+  const int kt0 = (int)((long)split * nk_all / p.splits), nk = (int)((long)(split + 1) * nk_all / p.splits) - kt0;
+
+  // per-lane source offset inside a 2 KB plane for a 1 KB LDS piece (lane L fills LDS bytes 16 L ..): ROW: the k-step's half is
+  // contiguous; COL: four 256-byte runs (one per c8 block), the k-step selects the 16-row half
+  const unsigned src_row = lane * 16, src_col = (lane >> 4) * 512 + (lane & 15) * 16;
+  // per-lane read offsets inside a 1 KB piece
+  const int r = lane & 31, g = lane >> 5;
+  // ROW: unit (r, c8 = 2 ks + g): half-local slot = g*32 + 16 (r/16) + 4 ((r/4 + g + 2 ks) & 3) + (r & 3); parity flips bit 7
+  const int rd_row0 = (g * 32 + ((r >> 4) << 4) + ((((r >> 2) + g) & 3) << 2) + (r & 3)) * 16;
+  // COL: 16-lane group G = lane >> 4 (MFMA rows 16 (G & 1) ..), c_l = lane & 15 -> chunk (row j = c_l / 4 of the quad, col quad
+  // c_l % 4): c8 = 2 (G & 1) + (c_l % 4) / 2, half8 = c_l & 1; rows 8 g + 4 hr + j of the k-step
+  const int G = lane >> 4, cl = lane & 15, c8c = 2 * (G & 1) + ((cl & 3) >> 1), gq = G >> 1;
+  const int rd_col0 = c8c * 256 + ((((2 * gq + 0 + c8c) & 3) << 2) + (cl >> 2)) * 16 + (cl & 1) * 8;
+  const int rd_col1 = c8c * 256 + ((((2 * gq + 1 + c8c) & 3) << 2) + (cl >> 2)) * 16 + (cl & 1) * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // the PW pieces this wavefront brings in per stage: piece q = wave + i NW -> (operand, 32-row tile j, plane): everything that
+  // does not depend on the k-step is fixed here
+  const char* pbase[PW];
+  bool pisA[PW];
+  unsigned plane_off[PW], plds[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    int q = wave + i * NW;
+    if (NP % NW != 0 && q >= NP) q -= NW;  // (uneven division: a duplicate of an earlier piece, identical bytes)
+    const bool isA = q < NA;
+    const int qq = isA ? q : q - NA;
+    const int j = qq / 3, pl = qq - 3 * j;
+    pisA[i] = isA;
+    plds[i] = q * 1024;
+    if (isA) {
+      const int mt = tp * (BM / 32) + j;
+      pbase[i] = p.A + ((ACOL ? (long)mt : (long)mt * p.ctA) * 3 + pl) * 2048;
+      plane_off[i] = ACOL ? src_col : src_row;
+    } else {
+      const int nt = tq * (BN / 32) + j;
+      pbase[i] = p.B + ((BCOL ? (long)nt : (long)nt * p.ctB) * 3 + pl) * 2048;
+      plane_off[i] = BCOL ? src_col : src_row;
+    }
+  }
+  // k-step dependent part of a source address: ROW: super-tile kt / 2 along the row of tiles, half kt & 1 of the plane;
+  // COL: super-tile row kt / 2 (ct tiles each), 16-row half kt & 1 of every c8 block
+  auto koffA = [&](int kt) -> long { return ACOL ? (long)(kt >> 1) * p.ctA * 6144 + (kt & 1) * 256 : (long)(kt >> 1) * 6144 + (kt & 1) * 1024; };
+  auto koffB = [&](int kt) -> long { return BCOL ? (long)(kt >> 1) * p.ctB * 6144 + (kt & 1) * 256 : (long)(kt >> 1) * 6144 + (kt & 1) * 1024; };
+  auto issue_one = [&](int i, long ka, long kb, int st_off) {
+    const char* src = pbase[i] + (pisA[i] ? ka : kb) + plane_off[i];
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + st_off + plds[i]), 16, 0, 0);
+  };
+  auto issue = [&](int kt, int st_off) {
+    const long ka = koffA(kt), kb = koffB(kt);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue_one(i, ka, kb, st_off);
+  };
+
+  auto frag_row = [&](const char* piece, int par) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(piece + (rd_row0 ^ (par << 7))));
+  };
+  auto frag_col = [&](const char* piece) -> bf16x8 {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(piece + rd_col0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(piece + rd_col1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  issue(kt0, 0);
+  if (nk > 1) issue(kt0 + 1, STAGE);
+  int st_off = 0;
+  bf16x8 af[2][3], bf[2][3];
+  if (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        af[i][pl] = frag_row(lds + (i * 3 + pl) * 1024, 0);
+        bf[i][pl] = frag_row(lds + (NA + i * 3 + pl) * 1024, 0);
+      }
+  }
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk && !(ABL & 1)) { WAIT_VM(PW); } else { WAIT_VM(0); }
+    if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = t + 2 < nk && !(ABL & 1);
+    const int nst_off = st_off + 2 * STAGE >= NST * STAGE ? st_off + 2 * STAGE - NST * STAGE : st_off + 2 * STAGE;
+    const long ka = koffA(kt0 + t + 2), kb = koffB(kt0 + t + 2);
+    if (ILV == 0 && more) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) issue_one(i, ka, kb, nst_off);
+    }
+    const char* sb = lds + st_off;
+    const int par = (kt0 + t) & 1;
+    if (!(ABL & 4))
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const char* pa = sb + ((wm * 2 + i) * 3 + pl) * 1024;
+        af[i][pl] = ACOL ? frag_col(pa) : frag_row(pa, par);
+        const char* pb = sb + (NA + (wn * 2 + i) * 3 + pl) * 1024;
+        bf[i][pl] = BCOL ? frag_col(pb) : frag_row(pb, par);
+      }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int EVERY = 24 / PW;
+#pragma unroll
+    for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tm]], bf[j][PB[tm]], acc[i][j], 0, 0, 0);
+          else acc[i][j][0] += (float)af[i][PA[tm]][0] + (float)bf[j][PB[tm]][0];
+          if (ILV == 1) {
+            const int n = tm * 4 + i * 2 + j;  // MFMA number inside the stage
+            if (n % EVERY == EVERY - 1 && n / EVERY < PW && more) issue_one(n / EVERY, ka, kb, nst_off);
+          }
+        }
+    if (ILV == 1) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, EVERY, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the LDS-DMA piece)
+      }
+    }
+    st_off = st_off + STAGE == NST * STAGE ? 0 : st_off + STAGE;
+  }
+
+  const int fr = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = tq * BN + wn * 64 + j * 32 + fr;
+      const int mb = tp * BM + wm * 64 + i * 32 + 4 * g;
+      float* crow = p.C + (long)split * p.P * p.ldc + (long)mb * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) crow[(long)((e & 3) + 8 * (e >> 2)) * p.ldc] = acc[i][j][e];
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_sum_kernel(float4* __restrict__ C, long n4, int splits) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = C[i];
+    for (int s = 1; s < splits; ++s) { const float4 v = C[(long)s * n4 + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    C[i] = a;
+  }
+}
+
+// The split pass as the product would run it: a wavefront takes 16 rows x 32 cols (lane = (row r16, c8): full 128-byte lines in,
+// 256-byte runs of units out), workgroup = 4 wavefronts = 64 rows x 32 cols... grid (col tiles, row groups of 64)
+__global__ __launch_bounds__(256) void split_fast_kernel(const float* __restrict__ X, int R, int C, int ld, uint4* __restrict__ planes, int CT) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ct = blockIdx.x, row = blockIdx.y * 64 + w * 16 + (lane >> 2), c8 = lane & 3, col = ct * 32 + c8 * 8;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (row < R && col + 8 <= C) {
+    const float4* src = reinterpret_cast<const float4*>(X + (long)row * ld + col);
+    a = src[0]; b = src[1];
+  }
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned short q[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(v[j], q[j]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    uint4 o;
+    o.x = q[0][pl] | ((unsigned)q[1][pl] << 16); o.y = q[2][pl] | ((unsigned)q[3][pl] << 16);
+    o.z = q[4][pl] | ((unsigned)q[5][pl] << 16); o.w = q[6][pl] | ((unsigned)q[7][pl] << 16);
+    planes[st32_unit(row, ct * 4 + c8, CT, pl)] = o;
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct Tensor {
+  int R, C, RT, CT;
+  std::vector<float> h;
+  float* d = nullptr;
+  char* planes = nullptr;
+  void init(int R_, int C_, unsigned seed) {
+    R = R_; C = C_; RT = (R + 31) / 32; CT = (C + 31) / 32;
+    h.resize((size_t)R * C);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    for (auto& x : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; x = ((float)((s >> 40) & 0xFFFFFF) / 8388608.f - 1.f); }
+    CK(hipMalloc(&d, h.size() * 4));
+    CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&planes, (size_t)RT * CT * 3 * 2048));
+    const long total = (long)RT * 32 * CT * 4;
+    split_st32_kernel<<<(unsigned)((total + 255) / 256), 256>>>(d, R, C, C, (uint4*)planes, RT, CT);
+    CK(hipGetLastError());
+  }
+  void release() { hipFree(d); hipFree(planes); }
+};
+
+template <int BM, int BN, bool ACOL, bool BCOL, int NST, int ILV, int ABL = 0>
+static void launch(const PPParams& p, hipStream_t s) {
+  constexpr int NP = (BM + BN) / 32 * 3;
+  constexpr size_t lds = (size_t)NST * NP * 1024;
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute((const void*)pp_gemm_kernel<BM, BN, ACOL, BCOL, NST, ILV, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+  const int tiles = (p.P / BM) * (p.Q / BN);
+  PPParams q = p;
+  q.tiles_q = p.Q / BN;
+  q.tiles = tiles;
+  pp_gemm_kernel<BM, BN, ACOL, BCOL, NST, ILV, ABL><<<tiles * p.splits, (BM / 64) * (BN / 64) * 64, lds, s>>>(q);
+  if (p.splits > 1) slab_sum_kernel<<<1024, 256, 0, s>>>((float4*)p.C, (long)p.P * p.Q / 4, p.splits);
+}
+
+typedef void (*LaunchFn)(const PPParams&, hipStream_t);
+struct Variant { const char* name; int BM, BN; LaunchFn fn[2][2]; };
+
+#define VARA(BM, BN, NST, ILV, ABL) {#BM "x" #BN "/" #NST "i" #ILV "a" #ABL, BM, BN, {{launch<BM, BN, false, false, NST, ILV, ABL>, launch<BM, BN, false, true, NST, ILV, ABL>}, {launch<BM, BN, true, false, NST, ILV, ABL>, launch<BM, BN, true, true, NST, ILV, ABL>}}}
+#define VAR(BM, BN, NST, ILV) VARA(BM, BN, NST, ILV, 0)
+static Variant variants[] = {VAR(128, 128, 3, 0), VAR(128, 128, 3, 1), VAR(256, 128, 3, 1), VAR(256, 256, 3, 1)};
+static Variant ablations[] = {VARA(128, 128, 3, 1, 0), VARA(128, 128, 3, 1, 1), VARA(128, 128, 3, 1, 2), VARA(128, 128, 3, 1, 4), VARA(128, 128, 3, 1, 8),
+                              VARA(128, 128, 3, 1, 3), VARA(128, 128, 3, 1, 7), VARA(128, 128, 3, 1, 14)};
+
+// mode: acol, bcol.  Stored tensors: A: row mode (P x K), col mode (K x P); same for B with Q.
+static double run_case(const Variant& v, int P, int Q, int K, int acol, int bcol, bool check, int iters, double* err_out, int splits = 1) {
+  Tensor A, B;
+  if (acol) A.init(K, P, 1); else A.init(P, K, 1);
+  if (bcol) B.init(K, Q, 2); else B.init(Q, K, 2);
+  float* C;
+  CK(hipMalloc(&C, (size_t)splits * P * Q * 4));
+  CK(hipMemset(C, 0xff, (size_t)splits * P * Q * 4));
+  PPParams p{A.planes, B.planes, C, P, Q, K, A.CT, B.CT, Q, 0, splits, 0};
+  v.fn[acol][bcol](p, 0);
+  CK(hipDeviceSynchronize());
+  double err = 0;
+  if (check) {
+    std::vector<float> hc((size_t)P * Q);
+    CK(hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t s = 777;
+    const int ns = (long)P * Q <= 70000 ? P * Q : 20000;
+    double maxc = 0;
+    for (int it = 0; it < ns; ++it) {
+      long idx;
+      if ((long)P * Q <= 70000) idx = it; else { s = s * 6364136223846793005ull + 1442695040888963407ull; idx = (long)((s >> 20) % ((uint64_t)P * Q)); }
+      const int m = (int)(idx / Q), n = (int)(idx % Q);
+      double ref = 0;
+      for (int k = 0; k < K; ++k) {
+        const double a = acol ? A.h[(size_t)k * P + m] : A.h[(size_t)m * K + k];
+        const double b = bcol ? B.h[(size_t)k * Q + n] : B.h[(size_t)n * K + k];
+        ref += a * b;
+      }
+      err = fmax(err, fabs(ref - (double)hc[idx]));
+      maxc = fmax(maxc, fabs(ref));
+    }
+    err /= fmax(maxc, 1e-30);
+  }
+  if (err_out) *err_out = err;
+  double us = 0;
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) v.fn[acol][bcol](p, 0);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) v.fn[acol][bcol](p, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    us = ms * 1e3 / iters;
+  }
+  A.release(); B.release(); hipFree(C);
+  return us;
+}
+
+struct Shape { int P, Q, K, ac, bc; const char* what; double ref_us; int splits; };
+
+int main(int argc, char** argv) {
+  const char* what = argc > 1 ? argv[1] : "all";
+  if (!strcmp(what, "probe") || !strcmp(what, "all")) {
+    short* d; short h[256];
+    CK(hipMalloc(&d, 512));
+    tr_probe_kernel<<<1, 64>>>(d);
+    CK(hipMemcpy(h, d, 512, hipMemcpyDeviceToHost));
+    // expectation: lane i (i' = i & 15 inside its 16-lane group Gb = i & ~15), element j <- element (i' % 4) of the chunk of lane Gb + 4 j + i' / 4
+    int bad = 0;
+    for (int i = 0; i < 64; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const int ip = i & 15, gb = i & ~15;
+        const int want = (gb + 4 * j + ip / 4) * 4 + (ip % 4);
+        if (h[i * 4 + j] != want) ++bad;
+      }
+    printf("tr probe: %d mismatches against the assumed semantics\n", bad);
+    if (bad) for (int i = 0; i < 64; ++i) printf("  lane %2d: %3d %3d %3d %3d\n", i, h[i * 4], h[i * 4 + 1], h[i * 4 + 2], h[i * 4 + 3]);
+    hipFree(d);
+  }
+  if (!strcmp(what, "check") || !strcmp(what, "all")) {
+    for (auto& v : variants)
+      for (int ac = 0; ac < 2; ++ac)
+        for (int bc = 0; bc < 2; ++bc) {
+          double err, err2, err3;
+          run_case(v, 256, 256, 96, ac, bc, true, 0, &err);
+          run_case(v, 512, 768, 352, ac, bc, true, 0, &err2);
+          run_case(v, 256, 512, 1136, ac, bc, true, 0, &err3, 3);
+          printf("check %-14s acol=%d bcol=%d: rel err %.3e (256x256x96) %.3e (512x768x352) %.3e (256x512x1136 / 3 slices) %s\n", v.name, ac, bc, err, err2,
+                 err3, (err < 2e-6 && err2 < 2e-6 && err3 < 4e-6) ? "ok" : "WRONG");
+        }
+  }
+  if (!strcmp(what, "split") || !strcmp(what, "all")) {
+    const int shapes[][2] = {{10880, 256}, {10880, 2048}, {32768, 96}, {8192, 768}, {1600, 256}};
+    for (auto& sh : shapes) {
+      Tensor T;
+      T.init(sh[0], sh[1], 5);
+      std::vector<char> want((size_t)T.RT * T.CT * 3 * 2048);
+      CK(hipMemcpy(want.data(), T.planes, want.size(), hipMemcpyDeviceToHost));
+      CK(hipMemset(T.planes, 0, want.size()));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      const dim3 grid(T.CT, (sh[0] + 63) / 64);
+      for (int i = 0; i < 3; ++i) split_fast_kernel<<<grid, 256>>>(T.d, sh[0], sh[1], sh[1], (uint4*)T.planes, T.CT);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; ++i) split_fast_kernel<<<grid, 256>>>(T.d, sh[0], sh[1], sh[1], (uint4*)T.planes, T.CT);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      std::vector<char> got(want.size());
+      CK(hipMemcpy(got.data(), T.planes, got.size(), hipMemcpyDeviceToHost));
+      // (rows past R inside the last 64-row group of a tile row are written as zeros by both kernels)
+      const bool same = !memcmp(got.data(), want.data(), got.size());
+      const double bytes = (double)sh[0] * sh[1] * 10;
+      printf("split %5d x %4d: %6.1f us  %.2f TB/s of 10 B/element  %s\n", sh[0], sh[1], ms * 1e3 / 20, bytes / (ms * 1e-3 / 20) * 1e-12, same ? "identical" : "DIFFERENT");
+      T.release();
+    }
+  }
+  Shape shapes[] = {
+      {10880, 2048, 256, 0, 0, "FFN1 fwd", 88.8, 1}, {10880, 256, 2048, 0, 0, "FFN2 fwd (wplanes)", 58.5, 3}, {10880, 256, 256, 0, 0, "proj 256", 19.8, 1},
+      {10880, 384, 256, 0, 0, "offs+attn", 24.2, 1}, {32768, 384, 96, 0, 0, "swin s1 fc1", 34.7, 1}, {8192, 768, 192, 0, 0, "swin s2 fc1", 26.4, 1},
+      {2048, 1536, 384, 0, 0, "swin s3 fc1", 23.9, 1}, {2048, 384, 1536, 0, 0, "swin s3 fc2", 31.5, 4},
+      {10880, 2048, 256, 0, 1, "FFN dH = g W2", 101.0, 1}, {10880, 256, 2048, 0, 1, "FFN dX (wplanes)", 58.5, 3},
+      {2048, 256, 10880, 1, 1, "dW1", 98.0, 16}, {256, 2048, 10880, 1, 1, "dW2", 98.0, 16}, {384, 1536, 2048, 1, 1, "swin s3 dW", 41.1, 8},
+      {256, 256, 10880, 1, 1, "dW proj 256", 0, 64}, {4096, 4096, 4096, 0, 0, "4096^3", 0, 1}, {4096, 4096, 4096, 1, 1, "4096^3 dW", 0, 1},
+  };
+  if (!strcmp(what, "time") || !strcmp(what, "all")) {
+    // ref_us: the shipped kernels on the same shapes (profiles/r3_gemm_ceiling_lab.txt section 6 / r3b stats), hot operands
+    for (auto& sh : shapes) {
+      for (auto& v : variants) {
+        if (sh.Q % v.BN) continue;
+        const int Pp = (sh.P + v.BM - 1) / v.BM * v.BM;  // (rows padded to the tile: the lab kernel has no edge handling)
+        int sp = sh.splits;
+        if (v.BM * v.BN > 128 * 128) sp = sp * 2 > 1 ? sp : 1;
+        double err;
+        const double us = run_case(v, Pp, sh.Q, sh.K, sh.ac, sh.bc, true, 20, &err, sp);
+        const double tf = 2.0 * sh.P * sh.Q * sh.K / us * 1e-6;
+        printf("time %-22s %5dx%5dx%5d a%db%d /%2d %-14s %8.1f us %7.1f TF-eq (%.2f of 416.7)  shipped %6.1f us  err %.1e\n", sh.what, sh.P, sh.Q, sh.K,
+               sh.ac, sh.bc, sp, v.name, us, tf, tf / 416.7, sh.ref_us, err);
+      }
+    }
+  }
+  if (!strcmp(what, "abl") || !strcmp(what, "all")) {
+    const int pick[] = {0, 8, 14};
+    for (int si : pick) {
+      auto& sh = shapes[si];
+      for (auto& v : ablations) {
+        const double us = run_case(v, sh.P, sh.Q, sh.K, sh.ac, sh.bc, false, 20, nullptr, sh.splits);
+        printf("abl  %-22s %5dx%5dx%5d a%db%d %-16s %8.1f us\n", sh.what, sh.P, sh.Q, sh.K, sh.ac, sh.bc, v.name, us);
+      }
+    }
+  }
+  return 0;
+}
