@@ -153,10 +153,29 @@ static_assert(PP_NP % 4 == 0, "pieces divide evenly over the four wavefronts");
 
 #define RSCOTR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// Epilogue operands through LDS.  After the product loop the ring (72 KB) is idle; a 128 x 128 fp32 tile of an epilogue operand
+// (aux, residual, old C) is 64 KB = 64 pieces of 1 KB (two rows of 128 floats), brought in by LDS-DMA — sixteen pieces per
+// wavefront, all in flight at once: ONE memory round trip per operand and workgroup.  A short grid has one workgroup per CU and
+// nothing else to hide the ~2 us of an HBM-cold load; loads into registers in row groups (csrc/gemm_common.h) pay that latency
+// eight to sixteen times per wavefront (measured in the step: 10880 x 256 x 256 with a residual 32 us against 15 without).
+// Needs 16-byte aligned rows (p.vecC).  Rows past M are clamped, columns past N start at N - 4 (in-bounds garbage, never used).
+template <bool EDGE>
+__device__ __forceinline__ void pp_stage_tile(const GemmParams& p, const float* __restrict__ T, char* lds, const int m0,
+                                              const int n0, const int wave, const int lane) {
+  const int col = EDGE ? min(n0 + (lane & 31) * 4, p.N - 4) : n0 + (lane & 31) * 4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int piece = wave * 16 + i;
+    const int row = EDGE ? min(m0 + 2 * piece + (lane >> 5), p.M - 1) : m0 + 2 * piece + (lane >> 5);
+    const float* src = T + (long)row * p.ldc + col;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
+  }
+}
+
 // p: the epilogue / split-K fields of GemmParams (A, B, lda, ldb unused); p.tiles = output tiles, p.splits = k-slices (the 16-k
 // steps divided evenly), p.slabs as in csrc/gemm.hip.
 template <bool ACOL, bool BCOL, bool EDGE>
-__global__ __launch_bounds__(256) void gemm_pp_kernel(GemmParams p, PPOperands o) {
+__global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p, PPOperands o) {
   extern __shared__ __attribute__((aligned(1024))) char pp_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,6 +257,16 @@ __global__ __launch_bounds__(256) void gemm_pp_kernel(GemmParams p, PPOperands o
 
   if (nk > 0) issue(kt0, 0);
   if (nk > 1) issue(kt0 + 1, PP_STAGE);
+  // the bias of this lane's two output columns: requested now, used after the loop (hipcc counts this load: its wait comes with
+  // the first use, behind every LDS-DMA piece — all of which have landed by then)
+  float bias_v[2] = {0.f, 0.f};
+  if (p.bias && p.splits == 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = tn * PP_BN + wn * 64 + j * 32 + (lane & 31);
+      bias_v[j] = (!EDGE || n < p.N) ? p.bias[n] : 0.f;
+    }
+  }
   int st_off = 0;
   for (int t = 0; t < nk; ++t) {
     // stage t has landed for this wavefront (the six pieces of stage t + 1 may still fly); after the barrier it has landed for
@@ -293,31 +322,136 @@ __global__ __launch_bounds__(256) void gemm_pp_kernel(GemmParams p, PPOperands o
       }
     return;
   }
-  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
+  // bias / ReLU / GELU only (every forward Linear without a residual): nothing to load, the accumulators go out as they are
+  const bool simple = !p.pre && !p.resid && !p.accumulate && !p.rowscale && !p.C2 && p.act <= ACT_GELU;
+  const int act = p.act, ldc = p.ldc;
+  if (simple) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (EDGE && n >= p.N) continue;
+        const int mb = m0 + wm * 64 + i * 32 + 4 * g;
+        float* crow = p.C + (long)mb * ldc + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] + bias_v[j];
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_GELU) v = gelu_f(v);
+          if (!EDGE || mb + (e & 3) + 8 * (e >> 2) < p.M) crow[((e & 3) + 8 * (e >> 2)) * ldc] = v;
+        }
+      }
+    return;
+  }
+  // general epilogue: v += bias; pre; act / act'(aux); row scale; residual / second output; old C — operands staged through LDS
+  // one after the other (most epilogues have one), values read back per 32 x 32 accumulator tile
+  const bool need_aux = act == ACT_RELU_GRAD || act == ACT_GELU_GRAD;
+  const bool staged = p.vecC != 0 && p.N % 4 == 0;
+  auto fetch = [&](const float* T) {  // -> the tile of T at (m0, n0) sits in LDS as [128][128] floats
+    __builtin_amdgcn_s_barrier();     // every wavefront is done with what the LDS held
+    asm volatile("" ::: "memory");
+    pp_stage_tile<EDGE>(p, T, pp_lds, m0, n0, wave, lane);
+    RSCOTR_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // element (i, j, e) of this lane in the staged tile / in a row-major tensor
+  auto lds_at = [&](int i, int j, int e) -> float {
+    return *reinterpret_cast<const float*>(pp_lds + (((wm * 64 + i * 32 + 4 * g + (e & 3) + 8 * (e >> 2)) * 128) + wn * 64 + j * 32 + fr) * 4);
+  };
+  auto row_of = [&](int i, int e) -> int { return m0 + wm * 64 + i * 32 + 4 * g + (e & 3) + 8 * (e >> 2); };
+  auto col_of = [&](int j) -> int { return n0 + wn * 64 + j * 32 + fr; };
+  auto live = [&](int i, int j, int e) -> bool { return !EDGE || (row_of(i, e) < p.M && col_of(j) < p.N); };
+  auto get = [&](const float* T, int i, int j, int e) -> float {
+    return staged ? lds_at(i, j, e) : (live(i, j, e) ? T[(long)row_of(i, e) * ldc + col_of(j)] : 0.f);
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + fr;
-      if (EDGE && n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      const int mb = m0 + wm * 64 + i * 32 + 4 * g;
-      float* crow = p.C + (long)mb * p.ldc + n;
-      if (plain) {
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] += bias_v[j];
+  if (p.pre) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          if (!EDGE || mb + (e & 3) + 8 * (e >> 2) < p.M) crow[(long)((e & 3) + 8 * (e >> 2)) * p.ldc] = acc[i][j][e] + bv;
-      } else {
+          if (live(i, j, e)) p.pre[(long)row_of(i, e) * ldc + col_of(j)] = acc[i][j][e];
+  }
+  if (need_aux) {
+    if (staged) fetch(p.aux);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          float v[4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n);
-          __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float x = get(p.aux, i, j, e);
+          acc[i][j][e] = act == ACT_RELU_GRAD ? (x > 0.f ? acc[i][j][e] : 0.f) : acc[i][j][e] * gelu_grad_f(x);
         }
+  } else if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+  } else if (act == ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = gelu_f(acc[i][j][e]);
+  }
+  if (p.rowscale) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float f = (!EDGE || row_of(i, e) < p.M) ? p.rowscale[row_of(i, e) / p.rows_per] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j][e] *= f;
       }
-    }
+  }
+  if (p.accumulate) {
+    if (staged) fetch(p.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += get(p.C, i, j, e);
+  }
+  if (p.C2) {  // C = value (+ old C), C2 = C + resid
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (live(i, j, e)) p.C[(long)row_of(i, e) * ldc + col_of(j)] = acc[i][j][e];
+  }
+  if (p.resid) {
+    if (staged) fetch(p.resid);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += get(p.resid, i, j, e);
+  }
+  float* dst = p.C2 ? p.C2 : p.C;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (live(i, j, e)) dst[(long)row_of(i, e) * ldc + col_of(j)] = acc[i][j][e];
 }
 
 }  // namespace rscotr
@@ -357,13 +491,15 @@ extern "C" int rscotr_split_planes_group(const int64_t* table, int n, int total_
 }
 
 // k-slices of a product: the grid should hold ~2 workgroups per CU; a slice keeps >= 8 steps of 16 k
+// (measured, scripts/bench_pp.py: a second slice of 10880 x 256 x 256 — 170 tiles — costs 11 us of slab traffic and a combine
+// launch to save 3; 48 tiles x 1536 k in 4-6 slices halve the time): no slices from 192 tiles on, >= 256 k per slice
 static int pp_splits(int M, int N, int K) {
   const long tiles = (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN);
   const int nk = (K + 15) / 16;
-  static const long target = getenv("RSCOTR_PP_SPLIT_TARGET") ? atol(getenv("RSCOTR_PP_SPLIT_TARGET")) : 512;
-  if (tiles >= target * 3 / 4) return 1;
+  static const long target = getenv("RSCOTR_PP_SPLIT_TARGET") ? atol(getenv("RSCOTR_PP_SPLIT_TARGET")) : 384;
+  if (tiles >= target / 2) return 1;
   long sp = (target + tiles - 1) / tiles;
-  sp = std::min<long>(sp, nk / 8);
+  sp = std::min<long>(sp, nk / 16);
   return (int)std::max<long>(1, std::min<long>(sp, 128));
 }
 
@@ -385,6 +521,7 @@ extern "C" int rscotr_gemm_pp(const void* a_planes, int a_ct, int a_col, const v
   if (act < ACT_NONE || act > ACT_GELU_GRAD) return fail(RSCOTR_E_ARG, "rscotr_gemm_pp: unknown act %d", act);
   if ((act == ACT_RELU_GRAD || act == ACT_GELU_GRAD) && !aux) return fail(RSCOTR_E_ARG, "rscotr_gemm_pp: act %d needs aux", act);
   if (ldc < N) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_pp: leading dimension too small");
+  if ((int64_t)M * ldc >= ((int64_t)1 << 31)) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_pp: output of %lld elements (32-bit row offsets in the epilogue)", (long long)M * ldc);
   if (rowscale && rows_per_scale <= 0) return fail(RSCOTR_E_ARG, "rscotr_gemm_pp: rowscale needs rows_per_scale > 0");
   const int need_a = a_col ? (M + 31) / 32 : (K + 31) / 32, need_b = b_col ? (N + 31) / 32 : (K + 31) / 32;
   if (a_ct < need_a || b_ct < need_b)

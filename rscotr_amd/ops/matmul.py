@@ -143,10 +143,12 @@ class _PlaneRoute:
     would cost more to split than the product saves (`max_split`: tensors above it only if their planes exist already)."""
 
     def __init__(self):
-        self.enabled = os.environ.get('RSCOTR_PP', '1') != '0'
+        self.enabled = os.environ.get('RSCOTR_PP', '0') != '0'  # opt-in: in the step it measures no gain yet (class docstring)
         self.min_rows = int(os.environ.get('RSCOTR_PP_MIN_ROWS', 2048))      # rows of the token-side dimension
         self.min_work = float(os.environ.get('RSCOTR_PP_MIN_WORK', 4e8))     # M * N * K
         self.max_split = int(os.environ.get('RSCOTR_PP_MAX_SPLIT', 1 << 23))  # elements of an operand split on the fly
+        self.min_tiles = int(os.environ.get('RSCOTR_PP_MIN_TILES', 512))     # 128 x 128 output tiles (x k-slices for weight gradients)
+        self.min_n = int(os.environ.get('RSCOTR_PP_MIN_N', 1024))            # output columns of a row-major product
         self.cache = {}
         self.wentries, self.wgroups, self.wtables = {}, {}, {}
         self.stats = dict(products=0, splits=0, hits=0)
@@ -217,7 +219,7 @@ class _PlaneRoute:
         rows, cols = (red, rows_op) if kmajor else (rows_op, red)
         if scale is None and not colsum_ptr and STATE.grad_sink is not None and STATE.grad_sink.is_param_ptr(T.data_ptr()):
             return self.weight(T, rows, cols, ld)
-        if rows * cols > self.max_split and not colsum_ptr and self.cached(T, rows, cols, ld, scale, scale_per) is None:
+        if rows * cols > self.max_split and self.cached(T, rows, cols, ld, scale, scale_per) is None:
             return None
         return self.planes(T, rows, cols, ld, scale, scale_per, colsum_ptr)
 
@@ -228,6 +230,16 @@ class _PlaneRoute:
             return False
         tokens = K if (a_kmajor and b_kmajor) else M
         if tokens < self.min_rows or float(M) * N * K < self.min_work or K < 64 or N < 64 or M < 64:
+            return False
+        # Measured in the step (profiles/r4_pp_in_step.txt): with HBM-cold operands and one workgroup per CU the 128 x 128 ring
+        # is latency-bound — short grids and narrow outputs run no faster than the in-kernel split while paying for the split
+        # passes; the wide, tall products (FFN 256 -> 2048 and its dH: 1360 tiles) gain 20 %.
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if a_kmajor and b_kmajor:
+            tiles *= max(1, min(-(-384 // tiles), (K // 16) // 16)) if tiles < 192 else 1
+        elif N < self.min_n:
+            return False
+        if tiles < self.min_tiles:
             return False
         return A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
 
@@ -259,13 +271,19 @@ class _DeferredCombine:
         # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
         # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
         self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
-        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '0'))  # 0: fp32 tiles only, 1: bf16x6 128 x 128 tiles for interior problems
+        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '1'))  # 0: fp32 64 x 64 tiles only, 1 / 2: bf16x6 128 x 128 tiles for interior problems, 3: bf16x6 64 x 64, 4: fp32 128 x 128
+        self.group_big_out = int(os.environ.get('RSCOTR_DW_GROUP_BIG_OUT', 32768))  # (variant 4: outputs from this many elements on)
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.pinned_pool, self.pinned_live = [], []
         self.wattn_entries, self.wattn_cache = [], {}
 
     MAX_TABLES = 64
     GROUP_MAX_OUT = int(os.environ.get('RSCOTR_DW_GROUP_MAX', 160000))     # M * N of a grouped problem
+    GROUP_MAX_OUT_SHORT = int(os.environ.get('RSCOTR_DW_GROUP_MAX_SHORT', 2500000))  # ... with a short reduction (K <= GROUP_SHORT_K)
+    GROUP_SHORT_K = int(os.environ.get('RSCOTR_DW_GROUP_SHORT_K', 4096))
+
+    def grouped_size(self, M, N, K):
+        return M * N <= self.GROUP_MAX_OUT or (K <= self.GROUP_SHORT_K and M * N <= self.GROUP_MAX_OUT_SHORT)
     GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 3072))    # workgroups a grouped launch aims at
 
     def _plan_group(self):
@@ -277,24 +295,31 @@ class _DeferredCombine:
 
         def kind(p):
             a, b, _, _, _, M, N, K, lda, ldb, _ = p
+            if self.group_x6 == 4:  # fp32 pipe on 128 x 128 tiles where the output holds at least a few of them
+                return 4 if min(M, N) >= 96 and M * N >= self.group_big_out else 0
             ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
             if self.group_x6 == 3:  # bf16x6 on 64 x 64 tiles, 32 k per step
                 return 3 if ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512 else 0
-            return 2 if ok and M % 128 == 0 and N % 128 == 0 else 0
+            if ok and M % 128 == 0 and N % 128 == 0:
+                return 2
+            if self.group_x6 == 5 and ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512:
+                return 3
+            return 0
         kinds = [kind(p) for p in probs]
-        tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else ((M + 63) // 64) * ((N + 63) // 64)
+        tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else
+                 ((M + 127) // 128) * ((N + 127) // 128) if k == 4 else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
-        work = sum(t * p[7] * (4 if k == 2 else 1) for t, k, p in zip(tiles, kinds, probs))
+        work = sum(t * p[7] * (4 if k in (2, 4) else 1) for t, k, p in zip(tiles, kinds, probs))
         klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
         dev = self.group_keep[0].device
         launches, ents = [], []
-        for variant in (0, 2, 3):
+        for variant in (0, 2, 3, 4):
             rows = []
             for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
                 if x6 != variant:
                     continue
-                sp = max(1, -(-K // max(256, klen_t // (4 if x6 == 2 else 1))))
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4) else 1))))
                 kq = 32 if x6 == 3 else 16
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
@@ -498,7 +523,7 @@ def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
     lo = fg.data_ptr()
     if not (lo <= out.data_ptr() < lo + fg.numel() * 4):
         return False
-    if DEFER.group_enabled and M * N <= DEFER.GROUP_MAX_OUT and K >= 16:
+    if DEFER.group_enabled and DEFER.grouped_size(M, N, K) and K >= 16:
         # small output: joins the grouped launch at the end of backward (operands stay alive until then)
         DEFER.group.append((A.data_ptr(), B.data_ptr(), out.data_ptr(), _ptr(rowsum), _ptr(kscale), M, N, K, lda, ldb,
                             int(krows_per)))
@@ -598,7 +623,7 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
     if PP.wanted(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
         # grouped weight gradients (small outputs) keep their one launch per backward pass
-        grouped = (a_kmajor and b_kmajor and accumulate and DEFER.enabled and DEFER.group_enabled and M * N <= DEFER.GROUP_MAX_OUT
+        grouped = (a_kmajor and b_kmajor and accumulate and DEFER.enabled and DEFER.group_enabled and DEFER.grouped_size(M, N, K)
                    and _in_arena(out))
         if not grouped:
             r = _gemm_pp_route(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out, bias, act, aux, pre, resid, accumulate, rowsum,

@@ -6,6 +6,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
-timeout 600 ./scripts/lab/pp_lab ${2:-all} > $out/pp_lab.txt 2>&1
+timeout 600 ./scripts/lab/pp_lab ${2:-all} ${3:-} > $out/pp_lab.txt 2>&1
 echo "rc=$?" >> $out/pp_lab.txt
 tail -120 $out/pp_lab.txt

@@ -42,7 +42,7 @@ def _product_state():
               hooks=(ops.STATE.side is None, ops.STATE.profile is None),
               defer=(ops.DEFER.enabled, ops.DEFER.group_enabled, ops.DEFER.group_x6, ops.DEFER.pin),
               wplanes=(ops.WPLANES.enabled, ops.WPLANES.min_m, ops.WPLANES.min_k),
-              pp=(ops.PP.enabled, ops.PP.min_rows, ops.PP.min_work, ops.PP.max_split),
+              pp=(ops.PP.enabled, ops.PP.min_rows, ops.PP.min_work, ops.PP.max_split, ops.PP.min_tiles, ops.PP.min_n),
               env=tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('RSCOTR_'))))
     if os.path.exists(LIB_PATH):
         st['gemm_precision'] = int(lib.rscotr_gemm_get_precision())

@@ -72,6 +72,25 @@ def test_split_planes_rowscale_and_column_sums(cuda):
         assert _rel(parts[gidx], xs[gidx * 256:(gidx + 1) * 256].double().sum(0)) < 1e-6
 
 
+class _route:
+    """The planes x planes route inside ops.gemm for the duration of a test (it is opt-in: RSCOTR_PP=1), with its size rules
+    opened up so that test-sized problems take it; everything is put back on exit (tests/conftest.py checks)."""
+
+    def __enter__(self):
+        from rscotr_amd import ops
+        self.keep = {k: getattr(ops.PP, k) for k in ('enabled', 'min_tiles', 'min_n', 'max_split', 'min_rows', 'min_work')}
+        ops.PP.enabled, ops.PP.min_tiles, ops.PP.min_n, ops.PP.max_split = True, 1, 64, 1 << 30
+        ops.PP.clear()
+        return ops.PP
+
+    def __exit__(self, *exc):
+        from rscotr_amd import ops
+        for k, v in self.keep.items():
+            setattr(ops.PP, k, v)
+        ops.PP.clear()
+        return False
+
+
 def _operands(M, N, K, ac, bc, seed, cuda):
     g = torch.Generator().manual_seed(seed)
     A = torch.randn((K, M) if ac else (M, K), generator=g)
@@ -159,15 +178,10 @@ def test_weight_gradient_route_with_bias_gradient_and_sample_scale(cuda, M, N, K
     ref_w, ref_b = dys.t() @ x.double(), dys.sum(0)
     before = dict(ops.PP.stats)
     rs = torch.zeros(M, device=cuda)
-    keep = ops.PP.max_split
-    ops.PP.max_split = 1 << 30  # (on the product path an operand this large is split only by its producer)
-    try:
+    with _route():
         out = ops.gemm(dy.to(cuda), x.to(cuda), M, N, K, M, N, 1, 1, rowsum=rs, kscale=s.to(cuda), krows_per=per)
-    finally:
-        ops.PP.max_split = keep
     assert ops.PP.stats['products'] == before['products'] + 1, 'the product did not take the planes x planes route'
     assert _rel(out, ref_w) < 1e-5 and _rel(rs, ref_b) < 1e-5
-    ops.PP.clear()
 
 
 def test_route_shares_plane_sets_between_the_products_of_a_linear(cuda):
@@ -178,18 +192,17 @@ def test_route_shares_plane_sets_between_the_products_of_a_linear(cuda):
     g = torch.Generator().manual_seed(3)
     x, W, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
     xd, Wd, dyd = x.to(cuda), W.to(cuda), dy.to(cuda)
-    ops.PP.clear()
-    s0 = dict(ops.PP.stats)
-    y = ops.gemm(xd, Wd, M, N, K, K, K, 0, 0)
-    dx = ops.gemm(dyd, Wd, M, K, N, N, K, 0, 1)
-    dW = ops.gemm(dyd, xd, N, K, M, N, K, 1, 1)
-    s1 = ops.PP.stats
-    assert s1['products'] - s0['products'] == 3 and s1['splits'] - s0['splits'] == 3 and s1['hits'] - s0['hits'] == 3
-    assert _rel(y, x.double() @ W.double().t()) < 1e-5
-    assert _rel(dx, dy.double() @ W.double()) < 1e-5
-    assert _rel(dW, dy.double().t() @ x.double()) < 1e-5
-    # an in-place change of an operand is seen (tensor version): no stale planes
-    xd.mul_(2.0)
-    y2 = ops.gemm(xd, Wd, M, N, K, K, K, 0, 0)
-    assert _rel(y2, 2.0 * x.double() @ W.double().t()) < 1e-5
-    ops.PP.clear()
+    with _route():
+        s0 = dict(ops.PP.stats)
+        y = ops.gemm(xd, Wd, M, N, K, K, K, 0, 0)
+        dx = ops.gemm(dyd, Wd, M, K, N, N, K, 0, 1)
+        dW = ops.gemm(dyd, xd, N, K, M, N, K, 1, 1)
+        s1 = ops.PP.stats
+        assert s1['products'] - s0['products'] == 3 and s1['splits'] - s0['splits'] == 3 and s1['hits'] - s0['hits'] == 3
+        assert _rel(y, x.double() @ W.double().t()) < 1e-5
+        assert _rel(dx, dy.double() @ W.double()) < 1e-5
+        assert _rel(dW, dy.double().t() @ x.double()) < 1e-5
+        # an in-place change of an operand is seen (tensor version): no stale planes
+        xd.mul_(2.0)
+        y2 = ops.gemm(xd, Wd, M, N, K, K, K, 0, 0)
+        assert _rel(y2, 2.0 * x.double() @ W.double().t()) < 1e-5
