@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   p.vecC = 0;
   p.nb1 = 0; p.nb2 = 1;
   p.tiles = VAR == 2 ? (p.M / 128) * (p.N / 128) : VAR == 3 ? (p.M / 64) * (p.N / 64)
-            : VAR == 4 ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+            : (VAR == 4 || VAR == 6) ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // the bodies decode (tile, k-slice) from a workgroup id laid out for XCD runs (x = id & 7 owns a run of tiles, id >> 3 =
   // slice * run + position in the run): build the id whose decoding is (tile = jwg % tiles, slice = jwg / tiles)
   const int tl_ = jwg % p.tiles, sl_ = jwg / p.tiles;
@@ -1418,6 +1418,10 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
     gemm_bf16x6_body<128, 128, true, true, 0, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else if constexpr (VAR == 3) {
     gemm_bf16x6_body<64, 64, true, true, 2, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  } else if constexpr (VAR == 6) {
+    // bf16x6 on 128 x 128 tiles with edge handling: the ragged members (Swin stage 1 / 2: 96, 192, 288, 576 rows or columns) —
+    // on the fp32 pipe of variant 0 they ran at 41 TFLOP/s
+    gemm_bf16x6_body<128, 128, true, true, 0, true, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else if constexpr (VAR == 4) {
     // fp32 pipe on 128 x 128 tiles: a 256 x 256 output is 4 tiles instead of 16 — each k-major operand panel is read twice
     // instead of four times (the 64 x 64 launch moved 2.1 GB of HBM traffic for 0.7 GB of operands)
@@ -1436,7 +1440,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   Split6Cfg c{0, 1, p.K};
   static const int on = getenv("RSCOTR_BF16X6") ? atoi(getenv("RSCOTR_BF16X6")) : 1;
   static const long t128_min = getenv("RSCOTR_BF16X6_T128") ? atol(getenv("RSCOTR_BF16X6_T128")) : 512;
-  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 512;
+  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 256;  // (round 4: 512 -> 256, Swin stage 4 / 2304-, 3072-column products: -0.3 ms per round; 192 and 128 lose 0.7)
   static const long dw_t128_min = getenv("RSCOTR_BF16X6_DW_T128") ? atol(getenv("RSCOTR_BF16X6_DW_T128")) : 24;
   static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
   static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;
@@ -2466,10 +2470,12 @@ extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, 
     gemm_f32_group_kernel<2><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
   } else if (variant == 3) {
     gemm_f32_group_kernel<3><<<dim3((unsigned)total_wgs), 256, 4 * (size_t)bf16x6_lds_words<64, 64, true, true, 2>(), (hipStream_t)stream>>>(table, n);
+  } else if (variant == 6) {
+    gemm_f32_group_kernel<6><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
   } else if (variant == 4) {
     gemm_f32_group_kernel<4><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<128, 128, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else {
-    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128), 3 (bf16x6 64 x 64) or 4 (fp32 128 x 128)");
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128), 3 (bf16x6 64 x 64), 4 (fp32 128 x 128) or 6 (bf16x6 128 x 128 with edges)");
   }
   return check_launch("rscotr_gemm_dw_group");
 }

@@ -272,6 +272,7 @@ class _DeferredCombine:
         # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
         self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
         self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '1'))  # 0: fp32 64 x 64 tiles only, 1 / 2: bf16x6 128 x 128 tiles for interior problems, 3: bf16x6 64 x 64, 4: fp32 128 x 128
+        self.group_edge = int(os.environ.get('RSCOTR_DW_GROUP_EDGE', -48))  # members with min(M, N) >= |this| on the bf16x6 edge body: > 0 only the ragged ones (interior ones in a launch of their own), < 0 all of them in one launch, 0 none
         self.group_big_out = int(os.environ.get('RSCOTR_DW_GROUP_BIG_OUT', 32768))  # (variant 4: outputs from this many elements on)
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.pinned_pool, self.pinned_live = [], []
@@ -284,7 +285,7 @@ class _DeferredCombine:
 
     def grouped_size(self, M, N, K):
         return M * N <= self.GROUP_MAX_OUT or (K <= self.GROUP_SHORT_K and M * N <= self.GROUP_MAX_OUT_SHORT)
-    GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 3072))    # workgroups a grouped launch aims at
+    GROUP_TARGET_WGS = int(os.environ.get('RSCOTR_DW_GROUP_WGS', 4608))    # workgroups a grouped launch aims at
 
     def _plan_group(self):
         """Slices and slab regions of the pending grouped problems -> ([(device table, problems, workgroups, variant)],
@@ -300,6 +301,9 @@ class _DeferredCombine:
             ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
             if self.group_x6 == 3:  # bf16x6 on 64 x 64 tiles, 32 k per step
                 return 3 if ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512 else 0
+            if self.group_edge and ok and M % 4 == 0 and N % 4 == 0 and min(M, N) >= abs(self.group_edge) and K >= 512:
+                if self.group_edge < 0 or M % 128 or N % 128:
+                    return 6  # ragged (< 0: every member, one launch): the edge instantiation of the same body
             if ok and M % 128 == 0 and N % 128 == 0:
                 return 2
             if self.group_x6 == 5 and ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512:
@@ -307,19 +311,19 @@ class _DeferredCombine:
             return 0
         kinds = [kind(p) for p in probs]
         tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else
-                 ((M + 127) // 128) * ((N + 127) // 128) if k == 4 else ((M + 63) // 64) * ((N + 63) // 64)
+                 ((M + 127) // 128) * ((N + 127) // 128) if k in (4, 6) else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
-        work = sum(t * p[7] * (4 if k in (2, 4) else 1) for t, k, p in zip(tiles, kinds, probs))
+        work = sum(t * p[7] * (4 if k in (2, 4, 6) else 1) for t, k, p in zip(tiles, kinds, probs))
         klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
         dev = self.group_keep[0].device
         launches, ents = [], []
-        for variant in (0, 2, 3, 4):
+        for variant in (0, 2, 3, 4, 6):
             rows = []
             for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
                 if x6 != variant:
                     continue
-                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4) else 1))))
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4, 6) else 1))))
                 kq = 32 if x6 == 3 else 16
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
