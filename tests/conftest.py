@@ -79,4 +79,7 @@ def pytest_terminal_summary(terminalreporter):
         tr.write_line(f"{r['test']}: {r['tensors'] - r['over_tight']}/{r['tensors']} tensors within 1e-3 of the fp32 oracle; "
                       f"decided_by_fp64_anchor={r['decided_by_fp64_anchor']}"
                       + ('' if a is None else f"; anchor {a['within']}/{a['of']} within bound, worst ratio {a['worst_ratio']} "
-                                               f"({a['worst_tensor']}), median ep {a['ep_med']} / eo {a['eo_med']}"))
+                                               f"({a['worst_tensor']}), median ep {a['ep_med']} / eo {a['eo_med']}"
+                                               + ('' if not a.get('loose_explained') else
+                                                  f"; tensors outside the 1e-3 tier explained by the fp64 evaluation / coin-toss "
+                                                  f"band: {a['loose_explained'][0]}/{a['loose_explained'][1]}")))

@@ -205,6 +205,11 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
                               worst=sorted(loose, key=lambda r: -r[1])[:8])
     bad = [r for r in loose if r[3] > LOOSE_L2 or (loose_max is not None and r[1] > loose_max)]
     fp32_tiers_ok = len(rows) - len(loose) >= TIGHT_FRACTION * len(rows) and not bad
+    on_gpu = next(model.parameters()).is_cuda  # (the CPU runs patch the HIP ops with the oracle: host-logic tests, old gate)
+    if loose and on_gpu and 'P64' not in orec and '_fp64_anchor' in orec:
+        #  no tensor enters the loose tier unexplained: the fp64 anchor is evaluated whenever ANY tensor
+        # misses the 1e-3 tier, and each such tensor must then be accounted for below (EXPLAINED)
+        orec['_fp64_anchor']()
     if not fp32_tiers_ok:
         # product and fp32 oracle disagree beyond the two tiers: decided by the fp64 anchor below (which of the two fp32
         # evaluations is away from the fp64 one under the same decisions, and can a coin-toss ReLU gate explain it?)
@@ -228,6 +233,23 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
             within = sum(1 for x, _ in ratio if x <= ANCHOR_K)
         out['anchor_report'] = dict(tensors=len(rep), within_k=within, worst=ratio[:5], ep_med=ep_med, eo_med=eo_med,
                                     decided=decided)
+        # every tensor outside the 1e-3 tier of the fp32 oracle needs a REASON: either the product is within 1e-3 of the fp64
+        # evaluation (then the fp32 oracle is the one that moved), or the coin-toss ambiguity of that very tensor (the fp64
+        # evaluation with the borderline ReLU gates flipped) covers the product's distance, or — an ill-conditioned sum whose
+        # two fp32 evaluations carry the same noise (eo > 10 amb) — the product is as close to fp64 as the fp32 oracle is
+        by_name = {r['name']: r for r in rep}
+        unexplained = []
+        for r in loose:
+            a = by_name.get(r[0])
+            if a is None:
+                continue
+            ok = (a['ep'] <= RTOL or a['ep'] <= ANCHOR_K_ALL * max(a['amb'], ANCHOR_FLOOR)
+                  or (a['eo'] > ANCHOR_EO_CLEAN * a['amb'] and a['ep'] <= ANCHOR_K * a['eo']))
+            if not ok:
+                unexplained.append((r[0], dict(ep=a['ep'], eo=a['eo'], amb=a['amb'], elementwise=r[1], l2=r[3])))
+        out['anchor_report']['loose_explained'] = (len(loose) - len(unexplained), len(loose))
+        assert not unexplained, ('tensors outside the 1e-3 tier that neither the fp64 evaluation nor the coin-toss band explains',
+                                 unexplained[:5])
         assert within >= ANCHOR_FRACTION * len(rep), out['anchor_report']
         assert ratio[0][0] <= (1.0 if decided else ANCHOR_K_ALL), out['anchor_report']
         assert ep_med <= ANCHOR_EP_MEDIAN, out['anchor_report']
@@ -236,6 +258,7 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
                            over_tight=len(loose), decided_by_fp64_anchor=decided,
                            anchor=None if 'anchor_report' not in out else dict(
                                within=out['anchor_report']['within_k'], of=out['anchor_report']['tensors'],
+                               loose_explained=out['anchor_report'].get('loose_explained'),
                                worst_ratio=round(out['anchor_report']['worst'][0][0], 3),
                                worst_tensor=out['anchor_report']['worst'][0][1],
                                ep_med=float(f"{out['anchor_report']['ep_med']:.3g}"),

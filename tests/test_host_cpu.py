@@ -351,3 +351,44 @@ def test_c_abi_library_exports_every_declared_symbol():
     dll.rscotr_gemm_f32_workspace.restype = ctypes.c_int64
     assert dll.rscotr_gemm_f32_workspace(-1, 4, 4) == 0
     assert dll.rscotr_gemm_f32_workspace(256, 256, 10880) > 0
+
+
+def test_state_dict_key_families_the_reference_defines_itself(main_model):
+    """The part of SURVEY A.8 that needs no memory of mmcv / mmdet: the attribute names under which the reference's OWN classes
+    register their parameter-carrying members (`self.<name> = <constructor>(...)`, collected with `ast` by
+    tests/golden/make_reference_golden.py).  Every such member that this configuration builds must own state-dict keys under
+    exactly that name at the class's place in the model."""
+    import numpy as np
+    cfg, mcfg, model = main_model
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_static.npz'))
+    fam = [r.split(':') for r in z['attr_families'].tolist()]
+    place = {'MTL': '', 'DINOHead': 'bbox_head.', 'DeformableDETRHead': 'bbox_head.', 'DETRHead': 'bbox_head.',
+             'DinoTransformer': 'bbox_head.transformer.', 'DinoTransformerDecoder': 'bbox_head.transformer.decoder.',
+             'Mask2FormerHead': 'seg_head.', 'MlvlSegPixelDecoder': 'seg_head.pixel_decoder.', 'SlvlClsHead': 'cls_head.'}
+    carriers = ('nn.Embedding', 'nn.Parameter', 'nn.Linear', 'nn.LayerNorm', 'nn.Sequential', 'Conv2d', 'Linear', 'build_MLP',
+                'build_transformer_layer_sequence', 'build_transformer', 'build_backbone', 'build_neck', 'build_head', '_get_clones')
+    # members the reference builds only under another configuration: one-stage queries (deformable_detr_head.py:78-80), the
+    # class branch of scheme 1 (mask2former_head.py:78-79), DETRHead's own layers (its _init_layers is overridden)
+    not_built = {('DeformableDETRHead', 'query_embedding'), ('DETRHead', 'query_embedding'), ('Mask2FormerHead', 'cls_embed'),
+                 ('DETRHead', 'input_proj'), ('DETRHead', 'fc_cls'), ('DETRHead', 'fc_reg'), ('DETRHead', 'reg_ffn')}
+    keys = list(model.state_dict())
+    checked = 0
+    for cls, attr, ctor in fam:
+        if cls not in place or ctor not in carriers or (cls, attr) in not_built:
+            continue
+        prefix = place[cls] + attr
+        assert any(k == prefix or k.startswith(prefix + '.') for k in keys), f'{cls}.{attr} ({ctor}): no state-dict key under {prefix!r}'
+        checked += 1
+    assert checked >= 20, checked
+    # and nothing at those places that the reference's classes do not name
+    named = {place[c] + a for c, a, _ in fam if c in place}
+    for k in keys:
+        for cls_place in ('bbox_head.transformer.decoder.', 'bbox_head.transformer.', 'seg_head.pixel_decoder.', 'seg_head.', 'bbox_head.', 'cls_head.'):
+            if k.startswith(cls_place):
+                member = cls_place + k[len(cls_place):].split('.')[0]
+                if cls_place == 'bbox_head.transformer.decoder.' and member.endswith('.layers'):
+                    break  # (TransformerLayerSequence.layers: mmcv's name)
+                if cls_place == 'cls_head.' and member == 'cls_head.fc':
+                    break  # (mmcls LinearClsHead.fc)
+                assert member in named, f'{k}: {member} is not an attribute the reference classes assign'
+                break
