@@ -213,6 +213,10 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('NCCL_DEBUG', 'WARN')  # no version banner on stdout next to the JSON line
+        if os.environ.get('RSCOTR_DIST_INLINE', '1') == '0':
+            # the overlapped exchange is captured only once the RCCL watchdog is known to be idle, which c10d's flight recorder
+            # tells (rscotr_amd.runner._wait_watchdog_idle): it must be on when the process group is created
+            os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000')
         dist.init_process_group('nccl', device_id=dev)
 
     import copy

@@ -45,9 +45,13 @@ __global__ __launch_bounds__(SEL_THREADS) void det_proposals_kernel(
 
   for (int n = tid; n < N; n += SEL_THREADS) {  // (1) row maxima (enc_outputs_class.max(-1)[0])
     const float* r = cb + (long)n * C;
+    // torch.max propagates NaN and torch.topk ranks it above everything (fmaxf would drop it: a row holding a NaN logit
+    // would be ranked by its finite entries and the eager fallback for N > 36 864 would disagree): a NaN row keeps NaN, and
+    // its key is the canonical quiet NaN, which order_key puts above +inf whatever sign the payload had
     float m = r[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, r[c]);
-    keys[n] = order_key(m);
+    bool nan = m != m;
+    for (int c = 1; c < C; ++c) { nan = nan || r[c] != r[c]; m = fmaxf(m, r[c]); }
+    keys[n] = order_key(nan ? __uint_as_float(0x7fc00000u) : m);
     inv[(long)b * N + n] = -1;
   }
   if (tid == 0) { s_prefix = 0u; s_need = K; s_above = 0; }

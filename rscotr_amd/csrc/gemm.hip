@@ -1440,7 +1440,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   Split6Cfg c{0, 1, p.K};
   static const int on = getenv("RSCOTR_BF16X6") ? atoi(getenv("RSCOTR_BF16X6")) : 1;
   static const long t128_min = getenv("RSCOTR_BF16X6_T128") ? atol(getenv("RSCOTR_BF16X6_T128")) : 512;
-  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 256;  // (round 4: 512 -> 256, Swin stage 4 / 2304-, 3072-column products: -0.3 ms per round; 192 and 128 lose 0.7)
+  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 512;  // (round 4: 256 measures -0.3 ms per round on mtl512 (192 and 128 lose 0.7) but re-routes the 2500-row stage-4 products of the 800 x 800 det step, whose parity run then lands on another side of its near-tie decisions: kept at 512)
   static const long dw_t128_min = getenv("RSCOTR_BF16X6_DW_T128") ? atol(getenv("RSCOTR_BF16X6_DW_T128")) : 24;
   static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
   static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;

@@ -39,10 +39,16 @@ struct Bilinear {
   int h_low, w_low;         // top-left tap (-1 .. size - 1 when `in`)
 };
 
+// Pixel coordinate of a normalised sampling location: loc * extent - 0.5 as ONE explicitly fused multiply-add.  Every kernel that
+// derives a bin (floor) or a fractional weight from a location calls this: the bin written by the sample kernel and the
+// weights re-derived by the tile kernel must come from the same float, whatever the compiler would contract on its own (a
+// sample within one ulp of an integer coordinate would otherwise land in bin n with a weight of ~0 instead of ~1: ADVICE r3)
+__device__ __forceinline__ float msda_pix(float loc, int extent) { return __fmaf_rn(loc, (float)extent, -0.5f); }
+
 __device__ __forceinline__ Bilinear bilinear_setup(float lx, float ly, int Hl, int Wl) {
   Bilinear t;
-  const float h_im = ly * (float)Hl - 0.5f;
-  const float w_im = lx * (float)Wl - 0.5f;
+  const float h_im = msda_pix(ly, Hl);
+  const float w_im = msda_pix(lx, Wl);
   t.in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
   const float hf = floorf(h_im), wf = floorf(w_im);
   const int h_low = t.in ? (int)hf : 0, w_low = t.in ? (int)wf : 0;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(64) void msda_hist_kernel(const int64_t* __restrict
       if (sid >= s1) continue;
       const int lp = (int)(sid % LP), l = lp / P;
       const int Hl = g.Hl[l], Wl = g.Wl[l];
-      const float h_im = xy[u].y * (float)Hl - 0.5f, w_im = xy[u].x * (float)Wl - 0.5f;
+      const float h_im = msda_pix(xy[u].y, Hl), w_im = msda_pix(xy[u].x, Wl);
       const bool in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
       int key = -1, rank = 0;
       if (in) {
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(256) void msda_fill_kernel(const int64_t* __restric
     const long so = (((long)b * Nq + q) * H + h) * LP + lp;
     const float2 xy = *reinterpret_cast<const float2*>(loc + so * 2);
     const float a = attn[so];
-    const float h_im = xy.y * (float)g.Hl[l] - 0.5f, w_im = xy.x * (float)g.Wl[l] - 0.5f;
+    const float h_im = msda_pix(xy.y, g.Hl[l]), w_im = msda_pix(xy.x, g.Wl[l]);
     const float lh = h_im - floorf(h_im), lw = w_im - floorf(w_im);
     rec[base[W.start + kr.x] + cbase[kr.x] + kr.y] = make_int4(q, __float_as_int(a), __float_as_int(lh), __float_as_int(lw));
   }
@@ -1047,7 +1053,7 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
       for (int u = 0; u < U; ++u) {
         if (i + u < s1) {
           const float aw = aws[u];  // (bilinear_setup's arithmetic)
-          const float h_im = xy[u].y * (float)Hl - 0.5f, w_im = xy[u].x * (float)Wl - 0.5f;
+          const float h_im = msda_pix(xy[u].y, Hl), w_im = msda_pix(xy[u].x, Wl);
           const float lh = h_im - floorf(h_im), lw = w_im - floorf(w_im);
           const float hw = 1.f - lw, hh = 1.f - lh;
           const float ah = aw * hh, al = aw * lh;  // the tap weights carry the attention weight

@@ -211,7 +211,8 @@ class DetStatic:
     KEYS = ('gt_box', 'gt_lab', 'gt_boxn', 'gcount', 'gcount_s', 'factors', 'slot_src', 'slot_valid', 'slot_neg', 'slot_inpad',
             'slot_pos', 'slot_k', 'attn_mask', 'norms', 'norms_r', 'scales', 'dn_lab', 'dn_bt', 'dn_bw', 'dn_cw')
 
-    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None, gt_host=None):
+    def __init__(self, head, gt_bboxes, gt_labels, img_metas, device, gcap=None, padcap=None, pinned=None, gt_host=None,
+                 norms_r_host=None):
         gen = head.dn_generator
         B = len(gt_bboxes)
         Q = head.num_query
@@ -260,11 +261,7 @@ class DetStatic:
         fake = np.arange(self.pad_size, PC)
         am[fake, :] = True                      # extra slots see only themselves
         am[fake, fake] = False
-        num_pos = sum(min(Q, g) for g in counts)
-        num_neg = B * Q - num_pos
-        npos_dn = ng * nb
-        bgw = head.bg_cls_weight
-        norms = np.array([num_pos * 1.0 + num_neg * bgw, num_pos, npos_dn * 1.0 + npos_dn * bgw, npos_dn], dtype=np.float32)
+        norms = self.host_norms(head, counts)
         host = dict(gcount=np.asarray(counts, dtype=np.int32), factors=factors_np, slot_src=slot_src,
                     slot_valid=slot_valid, slot_neg=slot_neg, slot_inpad=slot_inpad, slot_pos=slot_pos, slot_k=slot_k,
                     attn_mask=am, norms=norms)
@@ -273,15 +270,23 @@ class DetStatic:
         # host with the fp32 operations torch would run (clamp, add, reciprocal, multiply) and ride the upload
         w3 = (head.loss_cls.loss_weight, head.loss_bbox.loss_weight, head.loss_iou.loss_weight)
         one_rank = ops.dist_world() == 1
-        if one_rank:
+        if not one_rank and norms_r_host is None:
+            # several ranks: the rank-averaged normalisers come through the HOST control group when the runner made one (the
+            # counts are host data: no device collective, no clone, and the batch stays ONE uploaded block as on one rank)
+            r = self.reduce_norms_host(norms)
+            norms_r_host = None if r is None else r[:4]
+        host_scales = one_rank or norms_r_host is not None
+        if host_scales:
             f32 = np.float32
+            nr = norms if one_rank else np.asarray(norms_r_host, dtype=np.float32)  # (reduce_mean is the identity on one rank)
+            cavg = nr if (one_rank or head.sync_cls_avg_factor) else norms
             rows = []
             for ci, pi in ((0, 1), (2, 3)):
-                rc = f32(1.0) / (np.maximum(norms[ci], f32(1.0)) + f32(FP32_EPS))
-                rp = f32(1.0) / (np.maximum(norms[pi], f32(1.0)) + f32(FP32_EPS))
+                rc = f32(1.0) / (np.maximum(cavg[ci], f32(1.0)) + f32(FP32_EPS))
+                rp = f32(1.0) / (np.maximum(nr[pi], f32(1.0)) + f32(FP32_EPS))
                 rows.append([rc * f32(w3[0]), rp * f32(w3[1]), rp * f32(w3[2])])
             host['scales'] = np.asarray(rows, dtype=np.float32)
-            host['norms_r'] = norms.copy()  # (every reduce_mean of the det losses is the identity on one rank)
+            host['norms_r'] = nr.copy()
         # ground truth, padded with a harmless dummy box.  When the caller hands over host copies of the ground truth
         # (`gt_host` = (boxes, labels) as lists of NumPy arrays: batch['gt_bboxes_host'] / ['gt_labels_host'] of
         # rscotr_amd.synth / rscotr_amd.pipeline, which build them on the host anyway) the padded tensors are laid out on the
@@ -349,8 +354,8 @@ class DetStatic:
             t['dn_bw'] = rep(pos.unsqueeze(-1).expand(-1, -1, 4))
             t['dn_cw'] = rep(t['slot_inpad'])
             t['gcount_s'] = t['gcount'].repeat(nl + 1)
-        if not one_rank:
-            # every reduce_mean of the reference's det losses (detr_head.py:379-381,389-390; dino_head.py:266-268,
+        if not host_scales:
+            # (no host control group: a bare process group without the runner) every reduce_mean of the reference's det losses (detr_head.py:379-381,389-390; dino_head.py:266-268,
             # 282-283) averages one of these four numbers over the ranks: one small all-reduce, here, outside
             # any captured region
             if 'norms' not in self.t:  # (staging-only block: the rank-local normalisers go up on their own)
@@ -364,6 +369,31 @@ class DetStatic:
                 rp = 1.0 / (nr[pi].clamp(min=1.0) + FP32_EPS)
                 rows.append(torch.stack([rc * w3[0], rp * w3[1], rp * w3[2]]))
             self.t['scales'] = torch.stack(rows)
+
+    @staticmethod
+    def host_norms(head, counts):
+        """The four loss normalisers of a det batch (detr_head.py:379-390, dino_head.py:266-283: cls_avg_factor and num_total_pos
+        of the matching part and of the denoising part) — functions of the ground-truth COUNTS alone."""
+        Q, B = head.num_query, len(counts)
+        max_gt = max(counts) if counts else 0
+        ng = head.dn_generator.get_num_groups(max_gt)
+        nb = int(sum(counts))
+        num_pos = sum(min(Q, g) for g in counts)
+        num_neg = B * Q - num_pos
+        npos_dn = ng * nb
+        bgw = head.bg_cls_weight
+        return np.array([num_pos * 1.0 + num_neg * bgw, num_pos, npos_dn * 1.0 + npos_dn * bgw, npos_dn], dtype=np.float32)
+
+    @staticmethod
+    def reduce_norms_host(norms, extra=None):
+        """reduce_mean of the normalisers over the ranks THROUGH THE HOST control group (one gloo all-reduce; `extra`: more
+        floats to SUM in the same message, returned after the four means) — or None where no such group exists."""
+        if ops.host_group() is None:
+            return None
+        import torch.distributed as dist
+        w = np.float32(dist.get_world_size())
+        vec = np.concatenate([np.asarray(norms, dtype=np.float32) / w, np.asarray(extra if extra is not None else [], dtype=np.float32)])
+        return ops.host_allreduce_sum(vec)
 
     def _pack(self, host, device, pinned=None):
         """All host arrays of the batch in ONE byte block (16-byte aligned fields, KEYS order): `self.t` = typed views of
@@ -770,11 +800,13 @@ class DINOHead(nn.Module):
         return d
 
     def forward_train(self, mlvl_feats, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
-                      shared_encoder=None, proposal_cfg=None, rnd=None, record=None, static=None, gt_host=None, **kwargs):
+                      shared_encoder=None, proposal_cfg=None, rnd=None, record=None, static=None, gt_host=None,
+                      norms_r_host=None, **kwargs):
         assert proposal_cfg is None, '"proposal_cfg" must be None'
         assert self.dn_generator is not None, '"dn_cfg" must be set'
         if static is None and self.static_path and max([int(l.shape[0]) for l in gt_labels] + [0]) <= min(self.num_query, 256):
-            static = DetStatic(self, gt_bboxes, gt_labels, img_metas, mlvl_feats[0].device, gt_host=gt_host)
+            static = DetStatic(self, gt_bboxes, gt_labels, img_metas, mlvl_feats[0].device, gt_host=gt_host,
+                               norms_r_host=norms_r_host)
         if static is not None:
             return self.forward_train_static(mlvl_feats, img_metas, static, shared_encoder, rnd=rnd, record=record)
         dn_label_query, dn_bbox_query, attn_mask, dn_meta = self.dn_generator(

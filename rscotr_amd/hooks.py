@@ -63,7 +63,8 @@ class CheckpointHook:
         from .checkpoint import save_checkpoint
         os.makedirs(self.out_dir, exist_ok=True)
         path = os.path.join(self.out_dir, f'iter_{runner.iter}.pth')
-        meta = dict(getattr(runner, 'meta', None) or {}, iter=runner.iter, epoch=getattr(runner, 'epoch', 0))
+        # (mmcv IterBasedRunner.save_checkpoint stores `epoch + 1` and `iter`; its resume reads both back as they are)
+        meta = dict(getattr(runner, 'meta', None) or {}, iter=runner.iter, epoch=getattr(runner, 'epoch', 0) + 1)
         if _is_rank0():
             save_checkpoint(path, runner.model, runner.optimizer if self.save_optimizer else None, meta=meta)
             latest = os.path.join(self.out_dir, 'latest.pth')
@@ -75,11 +76,14 @@ class CheckpointHook:
                 import shutil
                 shutil.copy(path, latest)
             self.saved.append(path)
-            if self.max_keep_ckpts > 0:
-                while len(self.saved) > self.max_keep_ckpts:
-                    old = self.saved.pop(0)
-                    if os.path.isfile(old):
-                        os.remove(old)
+            if self.max_keep_ckpts > 0 and self.interval > 0:
+                # mmcv derives the redundant names from the iteration number (so checkpoints written before a resume are
+                # pruned too): iter_{it - k * interval}.pth for k = max_keep_ckpts, max_keep_ckpts + 1, ... until one is missing
+                for step in range(runner.iter - self.max_keep_ckpts * self.interval, 0, -self.interval):
+                    old = os.path.join(self.out_dir, f'iter_{step}.pth')
+                    if not os.path.isfile(old):
+                        break
+                    os.remove(old)
         runner.meta = getattr(runner, 'meta', None) or {}
         runner.meta.setdefault('hook_msgs', {})['last_ckpt'] = path
 
@@ -89,20 +93,23 @@ class _LogHistory:
     entries of every key.  Values stay device-side (LazyLogVars) until an average is asked for."""
 
     def __init__(self):
-        self.pending = []
+        self.pending = []          # (log_vars, count) of the iterations since the last report: read back (one device ->
+        self.hist = OrderedDict()  # host copy each) only when a report is due; per key the (value, count) history
 
     def update(self, log_vars, count):
         self.pending.append((log_vars, count))
 
     def average(self, n):
-        hist = OrderedDict()
+        """mmcv LogBuffer.average(n): per KEY the sample-weighted mean of its last n entries — with the tasks alternating a
+        key appears once per round, so its window reaches back n of ITS iterations, across reports (the history is kept)."""
         for lv, c in self.pending:
             for k in lv:
-                hist.setdefault(k, []).append((float(lv[k]), c))
+                self.hist.setdefault(k, []).append((float(lv[k]), c))
         self.pending = []
         out = OrderedDict()
-        for k, vs in hist.items():
-            vs = vs[-n:] if n > 0 else vs
+        for k, vs in self.hist.items():
+            if n > 0 and len(vs) > n:
+                del vs[:-n]      # (nothing older than the window is ever read again)
             tot = sum(c for _, c in vs)
             out[k] = sum(v * c for v, c in vs) / max(tot, 1)
         return out
@@ -140,6 +147,10 @@ class _LoggerHook:
                 tags['time'] = (now - (self.t_last or now)) / n
                 self.t_last, self.it_last = now, runner.iter
                 self.log(runner, tags, mode='train')
+
+    def after_resume(self, runner):
+        """The iteration counter jumped (runner.resume): time / eta are measured from here."""
+        self.t_last, self.it_last = time.time(), runner.iter
 
     def after_run(self, runner):
         pass
@@ -190,6 +201,11 @@ class TextLoggerHook(_LoggerHook):
             head = f'Iter({mode}) [{runner.iter}]\t'
         items = []
         for k, v in tags.items():
+            if hasattr(v, 'item'):  # NumPy scalars / 0-d arrays / one-element tensors returned by dataset.evaluate()
+                try:
+                    v = v.item()
+                except (ValueError, RuntimeError):
+                    v = str(v)
             rec[k] = round(float(v), 5) if isinstance(v, (int, float)) else v
             if k != 'time':
                 items.append(f'{k}: {v:.4f}' if isinstance(v, float) else f'{k}: {v}')

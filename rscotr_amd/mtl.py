@@ -165,7 +165,7 @@ class MTL(nn.Module):
         return losses
 
     def forward_train_det(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, rnd=None, record=None,
-                          static=None, gt_bboxes_host=None, gt_labels_host=None):
+                          static=None, gt_bboxes_host=None, gt_labels_host=None, det_norms_r_host=None):
         batch_input_shape = tuple(img[0].size()[-2:])
         for img_meta in img_metas:
             img_meta['batch_input_shape'] = batch_input_shape
@@ -175,7 +175,7 @@ class MTL(nn.Module):
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, self.shared_encoder,
                                             rnd=None if rnd is None else rnd.get('cdn'), record=record, static=static,
                                             gt_host=None if gt_bboxes_host is None or gt_labels_host is None
-                                            else (gt_bboxes_host, gt_labels_host))
+                                            else (gt_bboxes_host, gt_labels_host), norms_r_host=det_norms_r_host)
 
     def forward_train_seg(self, img, img_metas, gt_semantic_seg, rnd=None, record=None):
         neck_feature, backbone_feature = self.extract_feat(img, self._drop_keep(img.shape[0], img.device, rnd))

@@ -30,5 +30,28 @@ def dist_mean_vec(values, device):
     return list(t.unbind(0))
 
 
+# Host-side control group (gloo, created by the runner): small HOST vectors every rank must agree on or average — the det
+# normalisers (functions of ground-truth counts, known on the host without a device sync) and the graph-or-eager flag of a det
+# batch — travel through it in one all-reduce and never touch the device queue.
+_HOST_GROUP = [None]
+
+
+def set_host_group(group):
+    _HOST_GROUP[0] = group
+
+
+def host_group():
+    return _HOST_GROUP[0]
+
+
+def host_allreduce_sum(vec):
+    """SUM over the ranks of a small float32 NumPy vector through the host control group (in place, returned)."""
+    import numpy as np
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float32))
+    dist.all_reduce(t, group=_HOST_GROUP[0])
+    return t.numpy()
+
+
 def clamp_min(x, lo):
     return x.clamp(min=lo) if torch.is_tensor(x) else max(x, lo)

@@ -57,8 +57,8 @@ def _wait_watchdog_idle(limit=2.0):
     was recorded on is capturing — which aborts the process from the watchdog thread.  The works are complete after the
     synchronise, but the watchdog drops them only on its next pass; c10d's flight recorder marks an entry retired in that
     same pass, so "no active entries" = "the watchdog holds no event of ours".  -> ('recorder', seconds waited).  Where the
-    recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0) or its dump is not readable this falls back to waiting three
-    watchdog periods (3 x 100 ms + margin) -> ('sleep', 0.35)."""
+    recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0) or its dump is not readable: the inline exchange (synchronous works only)
+    waits three watchdog periods (3 x 100 ms + margin) -> ('sleep', 0.35); the overlapped exchange refuses to capture."""
     import pickle
     dump = getattr(torch._C._distributed_c10d, '_dump_nccl_trace', None)
     t0 = time.perf_counter()
@@ -71,9 +71,19 @@ def _wait_watchdog_idle(limit=2.0):
                     if not (act and act.get('entries')):
                         return 'recorder', time.perf_counter() - t0
                     time.sleep(0.01)
-    except Exception:  # noqa: BLE001 — a diagnostic API: any surprise means "use the fixed wait"
-        pass
-    time.sleep(0.35)
+    except (RuntimeError, pickle.UnpicklingError, KeyError, TypeError, AttributeError) as e:  # a diagnostic API of c10d
+        cause = e
+    else:
+        cause = None
+    from .dist import INLINE
+    if not INLINE:
+        # the overlapped exchange leaves asynchronous works with the watchdog: guessing when it has dropped their events is
+        # not good enough (a wrong guess aborts the process from the watchdog thread in the middle of a capture)
+        raise RuntimeError('capturing the overlapped gradient exchange (RSCOTR_DIST_INLINE=0) needs c10d\'s flight recorder to '
+                           'tell when the RCCL watchdog is idle, and it is not available (TORCH_NCCL_TRACE_BUFFER_SIZE=0?'
+                           + (f' {type(cause).__name__}: {cause}' if cause is not None else ' no entries recorded')
+                           + '); enable it or use the inline exchange')
+    time.sleep(0.35)  # (inline exchange: synchronous works only — three watchdog periods are ample)
     return 'sleep', 0.35
 
 
@@ -94,7 +104,7 @@ class GraphedTask:
         self.runner, self.task = runner, task
         self.model, self.opt = runner.model, runner.optimizer
         self.static = {k: batch[k].clone() for k in self.TENSOR_KEYS if k in batch}
-        self.meta = {k: v for k, v in batch.items() if k not in self.static and not k.endswith('_host')}
+        self.meta = {k: v for k, v in batch.items() if k not in self.static and not k.endswith('_host')}  # (host copies / host-reduced normalisers: per batch)
         self.aug = None
         self.det_static = None
         if task == 'det':
@@ -314,7 +324,8 @@ class GraphedTask:
             from .det_head import DetStatic
             DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
                       batch['img'].device, gcap=self.det_static.gcap, padcap=self.det_static.padcap,
-                      pinned=self.det_pinned, gt_host=_gt_host(batch)).update_into(self.det_static)
+                      pinned=self.det_pinned, gt_host=_gt_host(batch),
+                      norms_r_host=batch.get('det_norms_r_host')).update_into(self.det_static)
         for k, t in self.static.items():
             t.copy_(batch[k], non_blocking=True)
         if self.aug is not None:
@@ -356,6 +367,7 @@ class IterBasedRunner:
             import torch.distributed as dist
             if dist.get_world_size() > 1:
                 self.ctrl = dist.new_group(backend='gloo')
+                ops.set_host_group(self.ctrl)  # (the det normalisers are averaged through it too: rscotr_amd.det_head.DetStatic)
         self.rnd_fn = rnd_fn
         # tasks whose iteration is replayed from a hipGraph (RSCOTR_GRAPHS=0 disables)
         if graph_tasks is None:
@@ -475,7 +487,18 @@ class IterBasedRunner:
             return None
         ok = g.accepts(batch)
         if g.det_static is not None:
-            ok = self._agree(ok)
+            if self.ctrl is not None:
+                # ONE host message per det iteration carries both things the ranks must share before it starts: the four loss
+                # normalisers (reduce_mean of detr_head.py:379-390 / dino_head.py:266-283 — functions of the ground-truth counts,
+                # host data) and this rank's "my batch does not fit the captured capacities" flag.  Nothing of it touches the
+                # device queue: the iteration's device work is the one-rank iteration's plus the gradient exchange
+                from .det_head import DetStatic
+                counts = [int(l.shape[0]) for l in batch['gt_labels']]
+                r = DetStatic.reduce_norms_host(DetStatic.host_norms(self.model.bbox_head, counts), extra=[0.0 if ok else 1.0])
+                batch['det_norms_r_host'] = r[:4].copy()
+                ok = float(r[4]) == 0.0
+            else:
+                ok = self._agree(ok)
         return g if ok else None
 
     @contextlib.contextmanager
@@ -523,6 +546,9 @@ class IterBasedRunner:
             self.meta = dict(self.meta or {}, hook_msgs=ckpt['meta']['hook_msgs'])
         # graphs captured before the resume replay the OLD step counts' bias corrections only through the per-iteration
         # table (prepare_step), so they stay valid; the captured det capacities do too
+        for h in self.hooks:
+            if hasattr(h, 'after_resume'):
+                h.after_resume(self)
         self.logger(f'resumed from {path}: iter {self.iter}')
         return ckpt
 

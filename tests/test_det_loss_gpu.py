@@ -205,3 +205,23 @@ def test_det_targets_matches_the_scatter_formulation(cuda, S, B, Q, G):
     want_t = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, gt_boxn[None].expand(S, -1, -1, -1))[:, :, :Q]
     want_w = torch.zeros((S, B, Q + 1, 4)).scatter_(2, idx4, torch.ones((S, B, G, 4)))[:, :, :Q]
     assert torch.equal(labels.cpu(), want_l) and torch.equal(bt.cpu(), want_t) and torch.equal(bw.cpu(), want_w)
+
+
+def test_det_proposals_rank_nan_rows_first_like_torch(cuda):
+    """a row holding a NaN logit (a diverged run) — torch.max propagates the NaN and torch.topk ranks it above every
+    finite score; the kernel must select the same rows first (either NaN sign), not rank the row by its finite entries."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, N, C, K = 2, 900, 6, 50
+    cls = torch.randn(B, N, C, generator=g)
+    bad = {0: [17, 400], 1: [3]}
+    cls[0, 17, 2] = float('nan')
+    cls[0, 400, 5] = -float('nan')
+    cls[1, 3, 0] = float('nan')
+    reg, prop = torch.randn(B, N, 4, generator=g), torch.zeros(1, N, 4)
+    idx = ops.det_proposals(cls.to(cuda), reg.to(cuda), prop.to(cuda), K)[0].cpu()
+    idx_r = torch.topk(cls.max(-1)[0], K, dim=1)[1]
+    for b in range(B):
+        n = len(bad[b])
+        assert sorted(idx[b, :n].tolist()) == sorted(bad[b]) == sorted(idx_r[b, :n].tolist())
+        assert torch.equal(idx[b, n:], idx_r[b, n:])

@@ -140,6 +140,39 @@ def _worker(rank, world, port, q):
         sync.finish_step('c')
         sync._launch = real_launch
         assert launched == [b['lo'] for b in reversed(sync.plans['c'])], launched
+        # The INLINE exchange (RSCOTR_DIST_INLINE=1: buckets on the compute stream after backward, the default on RCCL) and the
+        # OVERLAPPED one (buckets launched from backward hooks as they complete) must put the SAME collectives on the wire in the
+        # SAME order — a job may mix the forms across iterations (eager / captured / fallback), never across ranks, and a
+        # recorded sequence is what a rank-divergence would show up in.  Both forms are driven here on the RCCL branch of
+        # GradSync (backend query patched, launches recorded instead of issued) with rank-dependent completion orders.
+        import rscotr_amd.dist as D
+        real_backend, real_inline = D.dist.get_backend, D.INLINE
+        seqs = {}
+        try:
+            D.dist.get_backend = lambda *a, **k: 'nccl'
+            for form, inline in (('inline', True), ('overlap', False)):
+                D.INLINE = inline
+                rec_launch = []
+                sync._launch = lambda b: rec_launch.append((b['lo'], b['hi']))
+                for task_ in ('a', 'b'):
+                    plan_ = sync.plans[task_]
+                    sync.begin_step(task_)
+                    before_ = len(rec_launch)
+                    fire_ = [i for b in (plan_ if rank == 0 else list(reversed(plan_))) for i in b['params']]
+                    for i in fire_:
+                        for _ in range(sync.fires[task_][i]):
+                            sync._on_ready(i)
+                    if inline:
+                        assert len(rec_launch) == before_, 'the inline form launched a bucket during backward'
+                    sync.finish_step(task_)
+                seqs[form] = list(rec_launch)
+        finally:
+            D.dist.get_backend, D.INLINE = real_backend, real_inline
+            sync._launch = real_launch
+        assert seqs['inline'] == seqs['overlap'] and len(seqs['inline']) == len(sync.plans['a']) + len(sync.plans['b']), seqs
+        both = [None, None]
+        dist.all_gather_object(both, seqs['inline'])
+        assert both[0] == both[1], 'the ranks would issue different collective sequences'
         # reduce_mean of a small device vector (det loss normalisers)
         from rscotr_amd import ops
         assert torch.allclose(ops.dist_mean_tensor(torch.tensor([2.0 * rank, 4.0])), torch.tensor([1.0, 4.0]))
@@ -170,10 +203,29 @@ def _worker(rank, world, port, q):
             def accepts(self, batch):
                 self.asked += 1
                 return self.fits
+        # ... and the SAME host message carries the four det loss normalisers (reduce_mean of detr_head.py:379-390 /
+        # dino_head.py:266-283): every rank leaves _graph_for with their rank average, and no device collective is needed for them
+        import time
+        import types
+        import numpy as np
+        from rscotr_amd.det_head import DetStatic
+        head = types.SimpleNamespace(num_query=600, bg_cls_weight=0.0,
+                                     dn_generator=types.SimpleNamespace(get_num_groups=lambda mx: max(1, 100 // max(mx, 1))))
+        real_model, runner.model = runner.model, types.SimpleNamespace(bbox_head=head)
+        counts = {0: [3, 5], 1: [7, 1]}
+        want_norms = (DetStatic.host_norms(head, counts[0]) / np.float32(2) + DetStatic.host_norms(head, counts[1]) / np.float32(2))
+        lat = []
         for fits_here, want in (((rank == 0), False), (True, True), (False, False)):
             runner.graphed['det'] = FakeGraph(fits_here)
-            got = runner._graph_for('det', {})
+            batch = dict(gt_labels=[torch.zeros(n, dtype=torch.long) for n in counts[rank]])
+            t0 = time.perf_counter()
+            got = runner._graph_for('det', batch)
+            lat.append(time.perf_counter() - t0)
             assert (got is not None) == want and runner.graphed['det'].asked == 1, (rank, fits_here, want)
+            assert np.array_equal(batch['det_norms_r_host'], want_norms), (batch['det_norms_r_host'], want_norms)
+        if rank == 0:
+            print(f'[test_dist_cpu] graph-or-eager + normaliser message, world 2 over gloo on this host: {min(lat) * 1e6:.0f} us')
+        runner.model = real_model
         shape_static = FakeGraph(rank == 0)
         shape_static.det_static = None          # cls / seg graphs accept every batch of their shape: no exchange needed
         runner.graphed['seg'] = shape_static

@@ -21,6 +21,8 @@ import torch.distributed as dist
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 if os.environ.get('RSCOTR_DIST_SINGLE') == '1':
+    if os.environ.get('RSCOTR_DIST_INLINE') == '0':  # the overlapped form needs c10d's flight recorder (runner._wait_watchdog_idle)
+        os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', sys.argv[2])
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('NCCL_DEBUG', 'WARN')
     dist.init_process_group('nccl', device_id=dev)
@@ -81,8 +83,8 @@ def test_capture_fallback_keeps_the_step_counts(cuda):
     # off by one moves the Adam bias corrections of the first steps by tens of percent)
     assert abs(got['param_norm'] - want['param_norm']) <= 1e-6 * want['param_norm'], (got, want)
     for k, v in want['losses'].items():
-        if k.startswith('cls.'):
-            continue  # (the second capture attempt consumes one more Mixup / CutMix draw of the NumPy stream: another batch mix)
+        if not k.startswith('seg.'):
+            continue  # (the second capture attempt consumes more draws of the Mixup / CutMix and denoising-noise streams)
         assert abs(got['losses'][k] - v) <= 2e-3 * max(abs(v), 1e-3), (k, got['losses'][k], v)
 
 

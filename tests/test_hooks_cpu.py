@@ -189,3 +189,41 @@ def test_find_latest_checkpoint(tmp_path):
     assert find_latest_checkpoint(str(tmp_path)).endswith('iter_10.pth')
     open(tmp_path / 'latest.pth', 'w').close()
     assert find_latest_checkpoint(str(tmp_path)).endswith('latest.pth')
+
+
+def test_hook_details_follow_mmcv(tmp_path, cpu_optimizer):
+    """ADVICE r3 (low), against mmcv 1.6's hooks: (a) a NumPy scalar metric goes into the JSON log; (b) the log window of a key
+    is the last n entries OF THAT KEY (LogBuffer.average), also across reports; (c) max_keep_ckpts prunes by iteration number,
+    so checkpoints written before a resume go too; (d) time / eta restart at the resumed iteration; (e) the checkpoint's
+    meta.epoch is epoch + 1 (IterBasedRunner.save_checkpoint)."""
+    import types
+    import numpy as np
+    from rscotr_amd.hooks import CheckpointHook, TextLoggerHook, _LogHistory
+    # (b)
+    h = _LogHistory()
+    for i, (k, v) in enumerate([('a', 1.0), ('b', 10.0), ('a', 3.0), ('b', 30.0), ('a', 5.0), ('b', 50.0)]):
+        h.update({k: v}, 1)
+    assert h.average(2) == {'a': 4.0, 'b': 40.0}
+    h.update({'a': 7.0}, 1)
+    assert h.average(2) == {'a': 6.0, 'b': 40.0}          # 'b' keeps its last two entries across the report
+    # (a)
+    lines = []
+    runner = types.SimpleNamespace(iter=3, max_iters=9, work_dir=str(tmp_path), timestamp='t1', logger=lines.append, epoch=0,
+                                   optimizer=types.SimpleNamespace())
+    tl = TextLoggerHook(interval=3)
+    tl.before_run(runner)
+    tl.log(runner, {'dior.bbox_mAP': np.float32(0.25), 'potsdam.mIoU': np.array(0.5), 'note': 'x'}, mode='val')
+    rec = json.loads(open(os.path.join(tmp_path, 't1.log.json')).read().strip())
+    assert rec['dior.bbox_mAP'] == 0.25 and rec['potsdam.mIoU'] == 0.5 and rec['note'] == 'x'
+    # (d)
+    runner.iter = 400
+    tl.after_resume(runner)
+    assert tl.it_last == 400
+    # (c) + (e): iter_2 .. iter_6 exist from "before the resume"; the hook of the resumed run writes iter_8 and prunes by name
+    run1, _, _ = _run(tmp_path / 'r', upto=6, checkpoint_config=dict(interval=2, max_keep_ckpts=10))
+    assert sorted(f for f in os.listdir(tmp_path / 'r') if f.startswith('iter_')) == ['iter_2.pth', 'iter_4.pth', 'iter_6.pth']
+    assert torch.load(os.path.join(tmp_path / 'r', 'iter_6.pth'), weights_only=True)['meta']['epoch'] == run1.epoch + 1
+    ck = CheckpointHook(interval=2, max_keep_ckpts=2, out_dir=str(tmp_path / 'r'))
+    run1.iter = 8
+    ck.after_train_iter(run1)
+    assert sorted(f for f in os.listdir(tmp_path / 'r') if f.startswith('iter_')) == ['iter_6.pth', 'iter_8.pth']
