@@ -363,10 +363,14 @@ def main():
         # most time, the whole family next to it
         gg = group('gemm')
         r_gemm, fam = None, None
+
+        def is_x6(k):  # kernels whose inner product is the six-term bf16 split (priced against 2500 / 6)
+            return ('bf16x6' in k or 'wplanes' in k or 'gemm_pp' in k
+                    or any(f'gemm_f32_group_kernel<{v}>' in k for v in (2, 3, 6)))
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12
-            x6 = 'bf16x6' in name or 'wplanes' in name  # (pre-split weight planes: the same six-term product)
+            x6 = is_x6(name)  # (pre-split weight planes, planes x planes, the grouped launch's bf16x6 bodies: the same six-term product)
             split = 'bf16x3' in name or x6
             peak = BF16X6_PEAK_TF if x6 else (BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF)
             r_gemm = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
@@ -383,6 +387,10 @@ def main():
                                    '(the timed region replays hipGraphs), each iteration queued behind a '
                                    f'{a.roofline_hold_ms:.0f} ms stream hold so that its kernels run back to back'
                                    if runner.graphed else 'sampled inside the timed region'))
+            if 'group_kernel' in name:
+                r_gemm['note'] = ('ONE launch = every deferred weight gradient dW = A^T B of a backward pass with a small output or a '
+                                  'short reduction (~100 problems, cut into 128 x 128 tiles x k-slices; flops_per_launch = sum of '
+                                  '2 M N K over the problems of the launch, stated by the host that built the table); ') + r_gemm['note']
             # HBM traffic of that kernel: rocprofv3 PMC passes over this same command (scripts/gpu_pmc.sh), summary
             # committed under profiles/; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
             try:
@@ -397,15 +405,15 @@ def main():
                 pass
             tf, tt = sum(v[0] for v in gg.values()), sum(v[1] for v in gg.values())
             sf3 = sum(v[0] for k, v in gg.items() if 'bf16x3' in k)
-            sf6 = sum(v[0] for k, v in gg.items() if 'bf16x6' in k or 'wplanes' in k)
+            sf6 = sum(v[0] for k, v in gg.items() if is_x6(k))
             sf = sf3 + sf6
-            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or 'bf16x6' in k or 'wplanes' in k)
+            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or is_x6(k))
             # the family mixes the matrix pipes: its peak is the time the same flops would take at each kernel's own peak
             fam_peak = tf / (sf3 / BF16X3_PEAK_TF + sf6 / BF16X6_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
                        kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_bf16x3_big_kernel<*>, '
-                              'gemm_small_kernel<*>, gemm_dw_direct_kernel<*>',
+                              'gemm_small_kernel<*>, gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> (the grouped weight-gradient launch), gemm_pp_kernel<*>',
                        launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '

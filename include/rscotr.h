@@ -205,9 +205,10 @@ int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, voi
  * splits}, tiles = ceil(M / 64) * ceil(N / 64) (variant 2: (M / 128) * (N / 128)), n a multiple of 8: rows come in bundles of
  * 8 (padded with all-zero rows) that occupy 8 * max(workgroups of the bundle's rows) consecutive workgroup ids, row x of a
  * bundle taking the ids = x mod 8 — one problem per XCD, so that its operands enter one L2 once; total_wgs = the sum over
- * the bundles.  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient GEMMs behind
+ * the bundles; flops = sum of 2 M N K over the problems (the table is device data: the caller states the launch's algorithmic
+ * work for the launch-site profiler, rscotr_prof_*; 0 = not stated).  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient GEMMs behind
  * mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules). */
-int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, void* stream);
+int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops, void* stream);
 
 /* nb0 * nb1 independent products of one shape, problem (b0, b1) at element offsets b0*s?0 + b1*s?1 of A, B, C
  * (b0 = image, b1 = head: the per-head slices of (B, L, heads*32) tensors are addressed in place).  No bias /

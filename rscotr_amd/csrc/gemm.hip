@@ -2459,11 +2459,13 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
 }
 
 // Grouped launch of deferred weight gradients: see gemm_f32_group_kernel.  table: device (n, 16) int64 (layout there),
-// total_wgs = sum of the problems' workgroup counts.
-extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, void* stream) {
+// total_wgs = sum of the problems' workgroup counts; flops = sum of 2 M N K over the problems (the table lives on the device:
+// the caller, who built it, states the algorithmic work of the launch for the launch-site profiler; 0 = not stated).
+extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops, void* stream) {
   if (n < 0 || total_wgs < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_dw_group: negative count");
   if (n == 0 || total_wgs == 0) return RSCOTR_OK;
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
+  ProfScope prof(PROF_GEMM, flops, (hipStream_t)stream, "rscotr::gemm_f32_group_kernel<%d>", variant);  // (2 / 3 / 6: bf16x6 bodies)
   if (variant == 0) {
     gemm_f32_group_kernel<0><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else if (variant == 2) {

@@ -342,7 +342,8 @@ class _DeferredCombine:
                     for r in rows[b0:b0 + 8]:
                         r[12] = first
                     first += 8 * rows[b0][15]
-                launches.append((self._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first, variant))
+                launches.append((self._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first, variant,
+                                 float(sum(2.0 * r[5] * r[6] * r[7] for r in rows))))
                 if os.environ.get('RSCOTR_DW_GROUP_DUMP'):  # (tuning aid: the problems of one grouped launch)
                     print(f'[dw group] variant {variant}: {len(rows)} problems, {first} workgroups, k-slice target {klen_t}')
                     for r in rows:
@@ -441,8 +442,8 @@ class _DeferredCombine:
         else:
             self.cur, self.off = hit[2], hit[3]
         self._remember(self.group_cache, sig, hit)
-        for table, n, total, variant in hit[0]:
-            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, _stream())
+        for table, n, total, variant, flops in hit[0]:
+            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, flops, _stream())
         self.entries.extend(hit[1])
         self.group, self.group_keep = [], []
 
