@@ -938,6 +938,20 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int
   return before + inc - v;
 }
 
+// (lab builds only — scripts/lab/msda_lab.hip defines MSDA_T_PROFILE: shader-clock cycles per phase of every tile workgroup)
+#ifdef MSDA_T_PROFILE
+__device__ long long g_msda_tprof[1 << 16][8];
+#define MSDA_TP_INIT long long tp_last_ = clock64(), tp_acc_[5] = {0, 0, 0, 0, 0}; int tp_n_ = 0;
+#define MSDA_TP(i) { const long long t_ = clock64(); tp_acc_[i] += t_ - tp_last_; tp_last_ = t_; }
+#define MSDA_TP_N(n) tp_n_ += (n);
+#define MSDA_TP_DONE(level) if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) { for (int i_ = 0; i_ < 5; ++i_) g_msda_tprof[blockIdx.x][i_] = tp_acc_[i_]; g_msda_tprof[blockIdx.x][5] = (level); g_msda_tprof[blockIdx.x][6] = tp_n_; g_msda_tprof[blockIdx.x][7] = 1; }
+#else
+#define MSDA_TP_INIT
+#define MSDA_TP(i)
+#define MSDA_TP_N(n)
+#define MSDA_TP_DONE(level)
+#endif
+
 // One 256-thread workgroup per (b, h, level, tile, chunk): see the header of this section.  A thread keeps the four tap
 // rows of ITS bin (its CH channels) in registers for the whole life of the workgroup: the walk over the sorted list needs
 // no barrier and no LDS accumulator — a thread reads the records of its bin in order, gathers each sample's grad_out row
@@ -982,14 +996,15 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   const int c0 = (int)((long)SP * chunk / nch) & ~(BS - 1), c1 = chunk + 1 == nch ? SP : (int)((long)SP * (chunk + 1) / nch) & ~(BS - 1);
   const int* bsrc = binw + ((long)bh * T.L + l) * ((SP + 3) & ~3);
 
-  // this thread's bin, channel part, and — tiles with few bins (the coarse levels, whose bins hold long runs) — its share of
-  // the bin's run: SF threads (pairs) per bin take consecutive parts of the run, their rows are added in part order
-  const int tsx = T.tsx[l], tsy = T.tsy[l], nbt = tsx * tsy;
-  const int SF = max(1, min(4, (256 / TB) / nbt));
+  // Work ITEMS of the walk: after the sort every bin's run is cut into parts of at most R0 records, R0 chosen per sort so
+  // that the parts number at most NPAIR (the thread pairs of the workgroup): pair j takes item j.  A bin that collects far
+  // more samples than its neighbours (the coarse levels; the padded denoising slots of a DINO decoder call, which all carry
+  // the SAME reference box and so put hundreds of samples into one bin: a 150-sample run walked by one pair was a chain of
+  // 75 dependent gathers, 80 us for a decoder call against 33 with well-spread queries) is walked by as many pairs as the
+  // tile has to spare; the parts of a bin meet in its cells in part order (below), so the sums stay fixed by the data alone
+  constexpr int NPAIR = 256 / TB;
+  constexpr int RMIN = 16;
   const int pair = tid / TB, sub = tid % TB;
-  const bool active = pair < nbt * SF;
-  const int bidx = active ? pair / SF : 0, seg = pair % SF;
-  const int bin = (bidx / tsx) * MSDA_T_TS + bidx % tsx;
   const float* gob = go + ((long)b * Nq * H + h) * D + sub * CH;  // + q * H * D
   const int qstride = H * D;
   // the walk re-derives a sample's tap weights from its sampling location and attention weight (12 algorithmic bytes per
@@ -1002,11 +1017,12 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   const long lstride = (long)H * LP * 2, astride = (long)H * LP;
   typedef float v2f __attribute__((ext_vector_type(2)));  // (pairs: v_pk_fma_f32 does two channels per instruction)
   v2f a1[2 * V], a2[2 * V], a3[2 * V], a4[2 * V];  // the bin's four tap rows (this thread's channels)
-#pragma unroll
-  for (int v = 0; v < 2 * V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = v2f{0.f, 0.f};
+  for (int i = tid; i < NCELL * D / 4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // (ordered before the first add by the barriers of the scan)
 
+  MSDA_TP_INIT
   // sort the n kept records by bin (stable), then every thread adds the records of its bin to its accumulators
   auto flush = [&](int n) {
+    MSDA_TP(1) MSDA_TP_N(n)
     for (int i = tid; i < 4 * NBIN; i += 256) hist[i] = 0;
     __syncthreads();
     const int nw = ((n + 3) / 4 + 63) & ~63;  // records per wavefront (whole rounds of 64)
@@ -1028,12 +1044,24 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
     __syncthreads();
     for (int i = i0 + lane; i < i1; i += 64) order[hist[w * NBIN + (lrec[i] & 255)] + rank[i]] = (unsigned short)i;
     __syncthreads();
-    int s0 = binstart[bin], s1 = binstart[bin + 1];
-    {
-      const int per = (s1 - s0 + SF - 1) / SF;
-      s0 = active ? s0 + seg * per : s1;
-      s1 = min(s1, s0 + per);
-    }
+    MSDA_TP(2)
+    // items: parts of at most R0 records per bin, at most NPAIR in all (n / R0 + non-empty bins <= NPAIR)
+    const int runlen = tid < NBIN ? binstart[tid + 1] - binstart[tid] : 0;
+    const int spare = max(NPAIR - __syncthreads_count(runlen > 0), 1);
+    const int R0 = max(RMIN, (n + spare - 1) / spare);
+    const int nit = (runlen + R0 - 1) / R0;
+    int* itab = hist;  // (the histogram is dead once `order` is written)
+    int nitems;
+    const int istart = block_exclusive_scan_256(nit, scratch, &nitems);
+    for (int k = 0; k < nit; ++k) itab[istart + k] = tid | (k << 8);
+    __syncthreads();
+    const bool active = pair < nitems;
+    const int item = active ? itab[pair] : 0;
+    const int bin = item & 255, part_k = item >> 8;
+    int s0 = binstart[bin] + part_k * R0, s1 = min(binstart[bin + 1], s0 + R0);
+    if (!active) s0 = s1 = 0;
+#pragma unroll
+    for (int v = 0; v < 2 * V; ++v) a1[v] = a2[v] = a3[v] = a4[v] = v2f{0.f, 0.f};
 #pragma unroll 1
     for (int i = s0; i < s1; i += U) {  // U samples in flight per thread, applied in list (= sample) order
       float2 xy[U];
@@ -1070,7 +1098,65 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
         }
       }
     }
-    __syncthreads();  // (the lists are rewritten by the scan that follows)
+    MSDA_TP(3)
+    // The parts of one bin are consecutive items, i.e. neighbouring pairs.  (1) Inside a wavefront their rows are summed by a
+    // suffix scan over the pairs (Hillis-Steele, shuffles; a fixed tree): the FIRST pair of a bin in each wavefront ends up
+    // with the sum of the bin's parts in that wavefront.  (2) Those heads add their rows to the tile's cells — tap k of bin
+    // (x, y) belongs to cell (x + (k & 1), y + (k >> 1)) — one tap at a time and, for a bin whose parts straddle wavefronts,
+    // one wavefront after the other (at most four rounds): no two threads touch a cell together, and every sum runs in an
+    // order the data alone fixes
+    {
+      constexpr int PPW = 64 / TB;  // pairs per wavefront
+      const int pl = lane / TB;
+      const int segid = active ? bin : -1 - pl;  // (idle pairs: segments of their own)
+      int maxk = active ? part_k : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) maxk = max(maxk, __shfl_xor(maxk, o, 64));
+      for (int d = 1; d <= maxk && d < PPW; d <<= 1) {  // (wave-uniform: a segment is at most maxk + 1 pairs long)
+        const int seg_there = __shfl_down(segid, d * TB, 64);  // (by every lane: a shuffle inside `a && b` would run with the top lanes — the partners — switched off)
+        const bool take = (pl + d < PPW) && seg_there == segid;
+#pragma unroll
+        for (int v = 0; v < 2 * V; ++v) {
+          const float x1 = __shfl_down(a1[v].x, d * TB, 64), y1 = __shfl_down(a1[v].y, d * TB, 64);
+          const float x2 = __shfl_down(a2[v].x, d * TB, 64), y2 = __shfl_down(a2[v].y, d * TB, 64);
+          const float x3 = __shfl_down(a3[v].x, d * TB, 64), y3 = __shfl_down(a3[v].y, d * TB, 64);
+          const float x4 = __shfl_down(a4[v].x, d * TB, 64), y4 = __shfl_down(a4[v].y, d * TB, 64);
+          if (take) {
+            a1[v] += v2f{x1, y1}; a2[v] += v2f{x2, y2}; a3[v] += v2f{x3, y3}; a4[v] += v2f{x4, y4};
+          }
+        }
+      }
+      const bool head = active && (part_k == 0 || pl == 0);
+      const int round = head ? pair / PPW - (pair - part_k) / PPW : 0;  // wavefronts between the bin's first item and this one
+      const int lbx = bin & (MSDA_T_TS - 1), lby = bin / MSDA_T_TS;
+      float4* c = reinterpret_cast<float4*>(acc + (lby * MSDA_T_CW + lbx) * D + sub * CH);
+      constexpr int CS = D / 4;  // float4 per cell
+      auto add = [](float4* p, const float4& v) { float4 o = *p; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *p = o; };
+      for (int k = 0; __syncthreads_or(head && round >= k); ++k) {
+        const bool mine = head && round == k;
+        if (mine) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) add(c + v, make_float4(a1[2 * v].x, a1[2 * v].y, a1[2 * v + 1].x, a1[2 * v + 1].y));
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) add(c + CS + v, make_float4(a2[2 * v].x, a2[2 * v].y, a2[2 * v + 1].x, a2[2 * v + 1].y));
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, make_float4(a3[2 * v].x, a3[2 * v].y, a3[2 * v + 1].x, a3[2 * v + 1].y));
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, make_float4(a4[2 * v].x, a4[2 * v].y, a4[2 * v + 1].x, a4[2 * v + 1].y));
+        }
+        __syncthreads();
+      }
+    }
+    MSDA_TP(4)
   };
 
   // scan: only the blocks whose mask names this tile (kept in order in `blist`, a segment of MSDA_T_SEGB blocks at a
@@ -1097,6 +1183,7 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
       cnt += t0 + t1 + t2 + t3;
     }
     __syncthreads();
+    MSDA_TP(0)
     auto index = [&](int rb) {  // first record of this thread in the round that starts at list position rb (-1: none)
       const int k = rb + slot;
       return k < cnt ? ((blk0 + seg + (int)blist[k]) << bshift) + off : -1;
@@ -1144,50 +1231,10 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
   }
   __syncthreads();
   if (n > 0) flush(n);
-  // the bins' tap rows meet in the tile's cells: tap k of bin (x, y) belongs to cell (x + (k & 1), y + (k >> 1)); one tap
-  // at a time, so that no two threads touch a cell together and every cell sums its (at most four) rows in tap order
-  for (int i = tid; i < NCELL * D / 4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  {
-    const int lbx = bin & (MSDA_T_TS - 1), lby = bin / MSDA_T_TS;
-    float4* c = reinterpret_cast<float4*>(acc + (lby * MSDA_T_CW + lbx) * D + sub * CH);
-    constexpr int CS = D / 4;  // float4 per cell
-    auto add = [](float4* p, const float4& v) { float4 o = *p; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *p = o; };
-    for (int sg = 0; sg < SF; ++sg) {
-      const bool mine = active && seg == sg;
-      if (mine) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + v, make_float4(a1[2 * v].x, a1[2 * v].y, a1[2 * v + 1].x, a1[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      const bool mine = active && seg == sg;
-      if (mine) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + CS + v, make_float4(a2[2 * v].x, a2[2 * v].y, a2[2 * v + 1].x, a2[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      const bool mine = active && seg == sg;
-      if (mine) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + MSDA_T_CW * CS + v, make_float4(a3[2 * v].x, a3[2 * v].y, a3[2 * v + 1].x, a3[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-    for (int sg = 0; sg < SF; ++sg) {
-      const bool mine = active && seg == sg;
-      if (mine) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) add(c + (MSDA_T_CW + 1) * CS + v, make_float4(a4[2 * v].x, a4[2 * v].y, a4[2 * v + 1].x, a4[2 * v + 1].y));
-      }
-      __syncthreads();
-    }
-  }
+  MSDA_TP(1)
   float4* dst = reinterpret_cast<float4*>(part + ((long)bh * T.NW + e) * NCELL * D);
   for (int i = tid; i < NCELL * D / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(acc)[i];
+  MSDA_TP(4) MSDA_TP_DONE(l)
 }
 
 // grad_value row of every token = the cells that alias it in the (at most four) tiles that hold it, every sample chunk, in
