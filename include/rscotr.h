@@ -227,6 +227,26 @@ int rscotr_gemm_f32_batched(const float* A, const float* B, float* C, int M, int
 int rscotr_softmax_mask_fwd(float* S, const unsigned char* mask, int mask_mode, int B, int heads, int Lq, int Lk,
                             float scale, void* stream);
 int rscotr_softmax_bwd(const float* P, float* dP, int64_t rows, int Lk, float scale, void* stream);
+/* The same attention core as ONE pass per direction for head dim 32 (csrc/attn_core.hip): the chain
+ * rscotr_gemm_f32_batched (q k^T) -> rscotr_softmax_mask_fwd -> rscotr_gemm_f32_batched (P v) of torch.nn.MultiheadAttention
+ * (models/multi/bbox_head/transformer.py:103-108, models/multi/seg_head/mask2former_head.py:183-192) without the
+ * (B, heads, Lq, Lk) score tensor: out[b, i, h*32 + d] = sum_j softmax_j(scale * q_i . k_j + mask_ij) v_j[d], online softmax over
+ * 32 x 32 score tiles held in MFMA accumulators (v_mfma_f32_32x32x2_f32).  q (B, Lq, .) / k, v (B, Lk, .) / out (B, Lq, .) are
+ * addressed in place through their row strides ld? (head h = columns h*32 .. h*32+31; strides multiples of 4, pointers
+ * 16-byte aligned: q | k may be the column halves of one projected tensor); lse (B, heads, Lq) receives log sum exp of every
+ * score row (+inf for a fully blocked row, whose output is 0) and is what backward recomputes the probabilities from.
+ * Backward writes dq (B, Lq, .), dk, dv (B, Lk, .) (overwritten) from dout (row stride ldo, like out): a query-side pass
+ * (dQ, and D = rowsum(dout * out) into the workspace) then a key-side pass (dK, dV); every sum in a fixed order (no atomics).
+ * mask / mask_mode as rscotr_softmax_mask_fwd.  workspace: rscotr_attn_core_workspace(B, heads, Lq, Lk) bytes (backward always;
+ * forward only when the key axis is cut into chunks: few query blocks against thousands of keys). */
+int64_t rscotr_attn_core_workspace(int B, int heads, int Lq, int Lk);
+int rscotr_attn_core_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, int mask_mode, float* out,
+                         float* lse, int B, int heads, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+int rscotr_attn_core_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, int mask_mode, const float* out,
+                         const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int heads, int Lq, int Lk,
+                         int hd, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 /* out[n] (+)= sum_m X[m*ld+n]  (bias gradients of the Linears above); two-stage, deterministic;
  * accumulate != 0 adds into out; workspace of rscotr_colsum_f32_workspace(M, N) bytes required. */
 int64_t rscotr_colsum_f32_workspace(int M, int N);

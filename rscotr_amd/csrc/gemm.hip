@@ -903,7 +903,10 @@ struct SplitOperand {
 // operand row is one whole 128-byte line per step; half as many barriers), PIPE 3 stages 16 (128 x 128 tiles: LDS).
 __device__ const float bf16x6_one = 1.f;
 template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : 16; }
-template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? 2 : PIPE == 3 ? 3 : 1; }
+#ifndef RSCOTR_X6_D2
+#define RSCOTR_X6_D2 2
+#endif
+template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? RSCOTR_X6_D2 : PIPE == 3 ? 3 : 1; }
 
 template <int BM, int BN, bool AKM, bool BKM, int PIPE>
 constexpr int bf16x6_lds_words() {

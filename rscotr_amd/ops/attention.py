@@ -123,17 +123,28 @@ class _MHA(Function):
             q = gemm(q2, in_w[:C], B * Lq, C, C, C, C, 0, 0, bias=in_b[:C])
             k = gemm(k2, in_w[C:2 * C], B * Lk, C, C, C, C, 0, 0, bias=in_b[C:2 * C])
         v = gemm(v2, in_w[2 * C:], B * Lk, C, C, C, C, 0, 0, bias=in_b[2 * C:])
-        P = torch.empty((B, heads, Lq, Lk), dtype=torch.float32, device=dev)
-        sq, sk, sp = (Lq * C, hd), (Lk * C, hd), (heads * Lq * Lk, Lq * Lk)
-        sqp, skp = (Lq * ldq, hd), (Lk * ldq, hd)  # strides of the projected q / k
-        gemm_batched(q, k, P, Lq, Lk, hd, ldq, ldq, Lk, 0, 0, B, heads, sqp, skp, sp, offB=C if fused else 0)
         if mask is not None:
             mask = mask.contiguous()
             assert mask.dtype == torch.bool and mask.is_cuda
-        lib.call('rscotr_softmax_mask_fwd', P.data_ptr(), _ptr(mask), int(mask_mode) if mask is not None else 0, B, heads,
-                 Lq, Lk, float(hd ** -0.5), _stream())
+        mode = int(mask_mode) if mask is not None else 0
         o = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
-        gemm_batched(P, v, o, Lq, hd, Lk, Lk, C, C, 0, 1, B, heads, sp, sk, sq, ksplit=True)
+        core = STATE.attn_core and hd == 32
+        if core:
+            # one pass over the keys, scores in MFMA accumulators; P below = the log-sum-exp of every score row (what backward
+            # recomputes the probabilities from) instead of the (B, heads, Lq, Lk) probabilities
+            P = torch.empty((B, heads, Lq), dtype=torch.float32, device=dev)
+            nws = lib.rscotr_attn_core_workspace(B, heads, Lq, Lk)
+            lib.call('rscotr_attn_core_fwd', q.data_ptr(), k.data_ptr() + (4 * C if fused else 0), v.data_ptr(), _ptr(mask), mode,
+                     o.data_ptr(), P.data_ptr(), B, heads, Lq, Lk, hd, ldq, ldq, C, C, float(hd ** -0.5),
+                     _WS.get(nws, dev).data_ptr(), nws, _stream())
+        else:
+            P = torch.empty((B, heads, Lq, Lk), dtype=torch.float32, device=dev)
+            sq, sk, sp = (Lq * C, hd), (Lk * C, hd), (heads * Lq * Lk, Lq * Lk)
+            sqp, skp = (Lq * ldq, hd), (Lk * ldq, hd)  # strides of the projected q / k
+            gemm_batched(q, k, P, Lq, Lk, hd, ldq, ldq, Lk, 0, 0, B, heads, sqp, skp, sp, offB=C if fused else 0)
+            lib.call('rscotr_softmax_mask_fwd', P.data_ptr(), _ptr(mask), mode, B, heads, Lq, Lk, float(hd ** -0.5), _stream())
+            gemm_batched(P, v, o, Lq, hd, Lk, Lk, C, C, 0, 1, B, heads, sp, sk, sq, ksplit=True)
+        ctx.core, ctx.mask_t, ctx.mask_mode = core, mask, mode
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(B * Lq, C))
         y = gemm(o, out_w, B * Lq, C, C, C, C, 0, 0, bias=out_b, resid=id2)
         ctx.save_for_backward(q2, k2, v2, q, k, v, P, o, in_w, out_w)
@@ -161,22 +172,28 @@ class _MHA(Function):
         do = gemm(g, out_w, B * Lq, C, C, C, C, 0, 1)
         # attention core
         dv = torch.empty((B * Lk, C), dtype=torch.float32, device=dev)
-        gemm_batched(P, do, dv, Lk, hd, Lq, Lk, C, C, 1, 1, B, heads, sp, sq, sk)                 # dV = P^T dO
-        dP = torch.empty_like(P)
-        gemm_batched(do, v, dP, Lq, Lk, hd, C, C, Lk, 0, 0, B, heads, sq, sk, sp)                  # dP = dO V^T
-        lib.call('rscotr_softmax_bwd', P.data_ptr(), dP.data_ptr(), B * heads * Lq, Lk, float(hd ** -0.5), _stream())
         ldq = 2 * C if fused else C
-        sqp, skp = (Lq * ldq, hd), (Lk * ldq, hd)
         if fused:  # dq | dk as the column halves of one (B*L, 2C) tensor, like q | k
             dq = dk = torch.empty((B * Lq, 2 * C), dtype=torch.float32, device=dev)
         else:
             dq = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
             dk = torch.empty((B * Lk, C), dtype=torch.float32, device=dev)
         koff = C if fused else 0
-        # dQ first: its key-split combine sums whole-tensor slabs (when fused that sweeps the dk half too, with
-        # whatever the workspace held) and the dK product below then writes the dk half
-        gemm_batched(dP, k, dq, Lq, hd, Lk, Lk, ldq, ldq, 0, 1, B, heads, sp, skp, sqp, offB=koff, ksplit=True)  # dQ = dS K
-        gemm_batched(dP, q, dk, Lk, hd, Lq, Lk, ldq, ldq, 1, 1, B, heads, sp, sqp, skp, offC=koff)  # dK = dS^T Q
+        if ctx.core:  # P = lse: probabilities recomputed tile by tile; a query-side pass (dQ) and a key-side pass (dK, dV)
+            nws = lib.rscotr_attn_core_workspace(B, heads, Lq, Lk)
+            lib.call('rscotr_attn_core_bwd', q.data_ptr(), k.data_ptr() + 4 * koff, v.data_ptr(), _ptr(ctx.mask_t), ctx.mask_mode,
+                     o.data_ptr(), do.data_ptr(), P.data_ptr(), dq.data_ptr(), dk.data_ptr() + 4 * koff, dv.data_ptr(), B, heads, Lq,
+                     Lk, hd, ldq, ldq, C, C, ldq, ldq, C, float(hd ** -0.5), _WS.get(nws, dev).data_ptr(), nws, _stream())
+        else:
+            gemm_batched(P, do, dv, Lk, hd, Lq, Lk, C, C, 1, 1, B, heads, sp, sq, sk)                 # dV = P^T dO
+            dP = torch.empty_like(P)
+            gemm_batched(do, v, dP, Lq, Lk, hd, C, C, Lk, 0, 0, B, heads, sq, sk, sp)                  # dP = dO V^T
+            lib.call('rscotr_softmax_bwd', P.data_ptr(), dP.data_ptr(), B * heads * Lq, Lk, float(hd ** -0.5), _stream())
+            sqp, skp = (Lq * ldq, hd), (Lk * ldq, hd)
+            # dQ first: its key-split combine sums whole-tensor slabs (when fused that sweeps the dk half too, with
+            # whatever the workspace held) and the dK product below then writes the dk half
+            gemm_batched(dP, k, dq, Lq, hd, Lk, Lk, ldq, ldq, 0, 1, B, heads, sp, skp, sqp, offB=koff, ksplit=True)  # dQ = dS K
+            gemm_batched(dP, q, dk, Lk, hd, Lq, Lk, ldq, ldq, 1, 1, B, heads, sp, sqp, skp, offC=koff)  # dK = dS^T Q
         # in projections (packed (3C, C) weight / (3C) bias: three row blocks; q and k as one block when fused)
         want_w, want_b = need[5], need[6]
         sink_w = _sink(p_in_w) if want_w else None
