@@ -26,6 +26,19 @@
 #include <math.h>
 #include <algorithm>
 
+// register prefetch of the next tile's operands, per kernel.  OFF: a set costs 36 / 52 / 70 registers, the passes then fit one
+// wavefront per SIMD instead of two, and two resident workgroups hide each other's load latency better than the prefetch does
+// (in the step: 35.19 ms per round without any, 35.35 with all three; profiles/r4_attn_core.txt)
+#ifndef ATTN_PF_FWD
+#define ATTN_PF_FWD 0
+#endif
+#ifndef ATTN_PF_DQ
+#define ATTN_PF_DQ 0
+#endif
+#ifndef ATTN_PF_DKV
+#define ATTN_PF_DKV 0
+#endif
+
 namespace rscotr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,6 +46,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr float kNegBig = -3.0e38f;
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -84,16 +98,68 @@ struct AttnGeom {
   float scale;
 };
 
+struct AttnBwdGeom {
+  int H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, mode, nch, tiles_per_chunk;
+  float scale;
+};
+
+// operands of one key tile as the forward / dQ walks read them: half rows of K (and V) for the score products, columns of V
+// (K) for the product that follows, and the lane's 16 mask bytes (loaded WITH the operands: a load issued later would, on the
+// in-order return path, wait for the whole prefetch in front of it)
+template <bool BWD>
+struct KeyTile {
+  float krow[16], vrow[BWD ? 16 : 1], col[16];
+  uint4 mraw;  // vec: the four uchar4 words of keys key0 + 4 * half + 8 * g + 0..3; ragged: mraw[0] = blocked bits
+  __device__ __forceinline__ void load(const float* __restrict__ kb, const float* __restrict__ vb, int ldk, int ldv, int key0,
+                                       int Lk, int half, int l32, const unsigned char* __restrict__ mrow, bool vec) {
+    if (key0 + 32 <= Lk) {  // (uniform) interior tile: no clamps
+      const float* kr = kb + (long)key0 * ldk;
+      const float* vr = vb + (long)key0 * ldv;
+      load_half_row(kr + l32 * ldk + 16 * half, krow);
+      if constexpr (BWD) load_half_row(vr + l32 * ldv + 16 * half, vrow);
+      const float* cb = BWD ? kr + 4 * half * ldk + l32 : vr + 4 * half * ldv + l32;
+      const int ldc = BWD ? ldk : ldv;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) col[j] = cb[((j & 3) + 8 * (j >> 2)) * ldc];
+    } else {
+      const long r = min(key0 + l32, Lk - 1);
+      load_half_row(kb + r * ldk + 16 * half, krow);
+      if constexpr (BWD) load_half_row(vb + r * ldv + 16 * half, vrow);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long rj = min(key0 + tile_row(j, half), Lk - 1);
+        col[j] = BWD ? kb[rj * ldk + l32] : vb[rj * ldv + l32];
+      }
+    }
+    if (vec && key0 + 32 <= Lk) {
+      const unsigned char* mp = mrow + key0 + 4 * half;
+      mraw = mrow ? make_uint4(*reinterpret_cast<const unsigned*>(mp), *reinterpret_cast<const unsigned*>(mp + 8),
+                               *reinterpret_cast<const unsigned*>(mp + 16), *reinterpret_cast<const unsigned*>(mp + 24))
+                  : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      mraw = make_uint4(blocked_keys(mrow, key0, half, Lk, false), 0u, 0u, 0u);
+    }
+  }
+  // bit r: key tile_row(r) of the tile is blocked for the lane's query
+  __device__ __forceinline__ unsigned blocked(int key0, int Lk, bool vec) const {
+    if (!(vec && key0 + 32 <= Lk)) return mraw.x;
+    auto nib = [](unsigned w) { return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u); };
+    return nib(mraw.x) | (nib(mraw.y) << 4) | (nib(mraw.z) << 8) | (nib(mraw.w) << 12);
+  }
+};
+
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------------------------
-// forward: grid (nqb * nch, B * H), 256 threads.  PART: leave (max, sum, unnormalised rows) of the chunk for attn_merge_kernel
-template <bool PART>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v, const unsigned char* __restrict__ mask,
-                                                       float* __restrict__ out, float* __restrict__ lse, float* __restrict__ part,
-                                                       const AttnGeom G) {
-  __shared__ float sO[4][32][33];
-  __shared__ float sM[4][32], sL[4][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+// forward: grid (nqb * nch, B * H), 64 * NW threads.  PART: leave (max, sum, unnormalised rows) of the chunk for attn_merge_kernel
+template <bool PART, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                           float* __restrict__ out, float* __restrict__ lse,
+                                                           float* __restrict__ part, const AttnGeom G) {
+  __shared__ float sO[NW][32][33];
+  __shared__ float sM[NW][32], sL[NW][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int bh = blockIdx.y, b = bh / G.H, h = bh % G.H;
   const int qb = blockIdx.x / G.nch, c = blockIdx.x % G.nch;
   const int q0 = qb * 32, qi = min(q0 + l32, G.Lq - 1);
@@ -102,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   float qreg[16];
   load_half_row(q + ((long)b * G.Lq + qi) * G.ldq + h * 32 + 16 * half, qreg);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) qreg[j] *= G.scale;
+  for (int j = 0; j < 16; ++j) qreg[j] *= G.scale * kLog2e;
   const unsigned char* mrow = nullptr;
   if (mask != nullptr && G.mode != 0) mrow = mask + (mask_block(G.mode, b, bh) * G.Lq + qi) * (long)G.Lk;
   const bool vec = (G.Lk & 3) == 0 && ((reinterpret_cast<uintptr_t>(mask) & 3u) == 0);
@@ -111,36 +177,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
   float m_run = kNegBig, l_run = 0.f;
   f32x16 oacc = zero16();
-  for (int t = t_beg + wave; t < t_end; t += 4) {
+  int t = t_beg + wave;
+  KeyTile<false> cur;
+  if (t < t_end) cur.load(kb, vb, G.ldk, G.ldv, t * 32, G.Lk, half, l32, mrow, vec);
+  for (; t < t_end; t += NW) {
     const int key0 = t * 32;
-    float kreg[16], vreg[16];
-    load_half_row(kb + (long)min(key0 + l32, G.Lk - 1) * G.ldk + 16 * half, kreg);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) vreg[j] = vb[(long)min(key0 + tile_row(j, half), G.Lk - 1) * G.ldv + l32];
-    const unsigned bl = blocked_keys(mrow, key0, half, G.Lk, vec);
+    KeyTile<false> nxt;  // the next tile of this wavefront is on its way while this one is multiplied (past the end: the last again)
+    if (ATTN_PF_FWD) nxt.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);
+    const unsigned bl = cur.blocked(key0, G.Lk, vec);
+    if (__all(bl == 0xffffu)) {  // nothing of this tile is visible to these 32 queries (DINO's denoising groups, whole
+      if (ATTN_PF_FWD) cur = nxt; else cur.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);                 // regions outside a predicted mask): no products at all
+      continue;
+    }
     f32x16 s = zero16();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[j], qreg[j], s, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.krow[j], qreg[j], s, 0, 0, 0);
+    if (__any(bl != 0u)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((bl >> r) & 1u) s[r] = -INFINITY;
+    }
     float tmax = kNegBig;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (!((bl >> r) & 1u)) tmax = fmaxf(tmax, s[r]);
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = ((bl >> r) & 1u) ? 0.f : __expf(s[r] - m_new);
-      s[r] = p;
-      psum += p;
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);  // (scores in log2 units: log2(e) rides in the scale of q)
+      psum += s[r];
     }
-    l_run = l_run * alpha + psum;
+    if (__any(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    }
+    l_run += psum;
     m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j], s[j], oacc, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.col[j], s[j], oacc, 0, 0, 0);
+    if (ATTN_PF_FWD) cur = nxt; else cur.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);
   }
   l_run += __shfl_xor(l_run, 32, 64);
 #pragma unroll
@@ -150,14 +228,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     sL[wave][l32] = l_run;
   }
   __syncthreads();
+  if (tid >= 256) return;
   const int qq = tid >> 3, d4 = (tid & 7) * 4;
   float M = kNegBig;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) M = fmaxf(M, sM[w][qq]);
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, sM[w][qq]);
   float L = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float f = __expf(sM[w][qq] - M);
+  for (int w = 0; w < NW; ++w) {
+    const float f = __builtin_amdgcn_exp2f(sM[w][qq] - M);
     L += f * sL[w][qq];
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] += f * sO[w][qq][d4 + u];
@@ -174,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const float inv = L > 0.f ? 1.f / L : 0.f;
     *reinterpret_cast<float4*>(out + ((long)b * G.Lq + q0 + qq) * G.ldo + h * 32 + d4) =
         make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-    if (d4 == 0) lse[(long)bh * G.Lq + q0 + qq] = L > 0.f ? M + logf(L) : INFINITY;
+    if (d4 == 0) lse[(long)bh * G.Lq + q0 + qq] = L > 0.f ? (M + log2f(L)) * kLn2 : INFINITY;
   }
 }
 
@@ -192,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
   float L = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < nch; ++c) {
     const float* pc = p0 + c * 1088;
-    const float f = SOFTMAX ? __expf(pc[1024 + qq] - M) : 1.f;
+    const float f = SOFTMAX ? __builtin_amdgcn_exp2f(pc[1024 + qq] - M) : 1.f;
     if (SOFTMAX) L += f * pc[1056 + qq];
     const float4 t = *reinterpret_cast<const float4*>(pc + qq * 32 + d4);
     o[0] += f * t.x; o[1] += f * t.y; o[2] += f * t.z; o[3] += f * t.w;
@@ -202,25 +281,21 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
   const float inv = SOFTMAX ? (L > 0.f ? 1.f / L : 0.f) : 1.f;
   *reinterpret_cast<float4*>(out + ((long)b * Lq + qi) * ldo + h * 32 + d4) =
       make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-  if (SOFTMAX && d4 == 0) lse[(long)bh * Lq + qi] = L > 0.f ? M + logf(L) : INFINITY;
+  if (SOFTMAX && d4 == 0) lse[(long)bh * Lq + qi] = L > 0.f ? (M + log2f(L)) * kLn2 : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, query side: dQ = scale * sum_k dS K with dS = P * (dP - D), D = rowsum(dO * O) (written to `dsum` for the key
 // side by the workgroups of chunk 0).  grid (nqb * nch, B * H)
-struct AttnBwdGeom {
-  int H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, mode, nch, tiles_per_chunk;
-  float scale;
-};
-
-template <bool PART>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ v, const unsigned char* __restrict__ mask,
-                                                          const float* __restrict__ out, const float* __restrict__ dout,
-                                                          const float* __restrict__ lse, float* __restrict__ dsum,
-                                                          float* __restrict__ dq, float* __restrict__ part, const AttnBwdGeom G) {
-  __shared__ float sQ[4][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+template <bool PART, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                              const float* __restrict__ out, const float* __restrict__ dout,
+                                                              const float* __restrict__ lse, float* __restrict__ dsum,
+                                                              float* __restrict__ dq, float* __restrict__ part,
+                                                              const AttnBwdGeom G) {
+  __shared__ float sQ[NW][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int bh = blockIdx.y, b = bh / G.H, h = bh % G.H;
   const int qb = blockIdx.x / G.nch, c = blockIdx.x % G.nch;
   const int q0 = qb * 32, qi = min(q0 + l32, G.Lq - 1);
@@ -240,8 +315,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   }
   if (c == 0 && wave == 0 && half == 0 && q0 + l32 < G.Lq) dsum[(long)bh * G.Lq + q0 + l32] = D;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) qreg[j] *= G.scale;
-  const float lse_q = lse[(long)bh * G.Lq + qi];
+  for (int j = 0; j < 16; ++j) qreg[j] *= G.scale * kLog2e;
+  const float lse_q = lse[(long)bh * G.Lq + qi] * kLog2e;
   const unsigned char* mrow = nullptr;
   if (mask != nullptr && G.mode != 0) mrow = mask + (mask_block(G.mode, b, bh) * G.Lq + qi) * (long)G.Lk;
   const bool vec = (G.Lk & 3) == 0 && ((reinterpret_cast<uintptr_t>(mask) & 3u) == 0);
@@ -249,35 +324,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   const float* vb = v + (long)b * G.Lk * G.ldv + h * 32;
 
   f32x16 acc = zero16();  // dQ^T: rows d, columns = this wavefront's queries
-  for (int t = t_beg + wave; t < t_end; t += 4) {
+  int t = t_beg + wave;
+  KeyTile<true> cur;
+  if (t < t_end) cur.load(kb, vb, G.ldk, G.ldv, t * 32, G.Lk, half, l32, mrow, vec);
+  for (; t < t_end; t += NW) {
     const int key0 = t * 32;
-    float kreg[16], vreg[16], kcol[16];
-    const long krow = min(key0 + l32, G.Lk - 1);
-    load_half_row(kb + krow * G.ldk + 16 * half, kreg);
-    load_half_row(vb + krow * G.ldv + 16 * half, vreg);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) kcol[j] = kb[(long)min(key0 + tile_row(j, half), G.Lk - 1) * G.ldk + l32];
-    const unsigned bl = blocked_keys(mrow, key0, half, G.Lk, vec);
+    KeyTile<true> nxt;
+    if (ATTN_PF_DQ) nxt.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);
+    const unsigned bl = cur.blocked(key0, G.Lk, vec);
+    if (__all(bl == 0xffffu)) {
+      if (ATTN_PF_DQ) cur = nxt; else cur.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);
+      continue;
+    }
     f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[j], qreg[j], s, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.krow[j], qreg[j], s, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j], doreg[j], dp, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.vrow[j], doreg[j], dp, 0, 0, 0);
+    if (__any(bl != 0u)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = ((bl >> r) & 1u) ? 0.f : __expf(s[r] - lse_q);
-      s[r] = p * (dp[r] - D) * G.scale;
+      for (int r = 0; r < 16; ++r)
+        if ((bl >> r) & 1u) s[r] = -INFINITY;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kcol[j], s[j], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - lse_q) * (dp[r] - D) * G.scale;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.col[j], s[j], acc, 0, 0, 0);
+    if (ATTN_PF_DQ) cur = nxt; else cur.load(kb, vb, G.ldk, G.ldv, min(t + NW, t_end - 1) * 32, G.Lk, half, l32, mrow, vec);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) sQ[wave][l32][tile_row(r, half)] = acc[r];
   __syncthreads();
+  if (tid >= 256) return;
   const int qq = tid >> 3, d4 = (tid & 7) * 4;
   float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < NW; ++w)
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] += sQ[w][qq][d4 + u];
   if (PART) {
@@ -288,20 +370,88 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   }
 }
 
-// backward, key side: dV = P^T dO, dK = scale * dS^T Q for 32 keys, walking the queries.  grid (nkb, B * H)
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, const unsigned char* __restrict__ mask,
-                                                           const float* __restrict__ dout, const float* __restrict__ lse,
-                                                           const float* __restrict__ dsum, float* __restrict__ dk,
-                                                           float* __restrict__ dv, const AttnBwdGeom G) {
-  __shared__ float sK[4][32][33];
-  __shared__ float sV[4][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+// operands of one query tile as the key-side walk reads them
+struct QueryTile {
+  float qrow[16], drow[16], qcol[16], dcol[16], nlse, nD;
+  unsigned mb[4];  // mask bytes of (query tile_row(r), this lane's key), four per word
+  __device__ __forceinline__ void load(const float* __restrict__ qbp, const float* __restrict__ dob, const float* __restrict__ lseb,
+                                       const float* __restrict__ dsb, const unsigned char* __restrict__ mcol, int ldq, int ldo,
+                                       int q0, int Lq, int Lk, int half, int l32) {
+    if (q0 + 32 <= Lq) {  // (uniform) interior tile
+      const float* qr = qbp + (long)q0 * ldq;
+      const float* dr = dob + (long)q0 * ldo;
+      load_half_row(qr + l32 * ldq + 16 * half, qrow);
+      load_half_row(dr + l32 * ldo + 16 * half, drow);
+      const float* qc = qr + 4 * half * ldq + l32;
+      const float* dc = dr + 4 * half * ldo + l32;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        qcol[j] = qc[((j & 3) + 8 * (j >> 2)) * ldq];
+        dcol[j] = dc[((j & 3) + 8 * (j >> 2)) * ldo];
+      }
+      nlse = lseb[q0 + l32];
+      nD = dsb[q0 + l32];
+      if (mcol) {
+        const unsigned char* mc = mcol + (long)(q0 + 4 * half) * Lk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned char* mg = mc + (long)(8 * g) * Lk;
+          mb[g] = (unsigned)mg[0] | ((unsigned)mg[Lk] << 8) | ((unsigned)mg[2 * (long)Lk] << 16) | ((unsigned)mg[3 * (long)Lk] << 24);
+        }
+      } else {
+        mb[0] = mb[1] = mb[2] = mb[3] = 0u;
+      }
+    } else {
+      const long qrw = min(q0 + l32, Lq - 1);
+      load_half_row(qbp + qrw * ldq + 16 * half, qrow);
+      load_half_row(dob + qrw * ldo + 16 * half, drow);
+      nlse = lseb[qrw];
+      nD = dsb[qrw];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long qr = min(q0 + tile_row(j, half), Lq - 1);
+        qcol[j] = qbp[qr * ldq + l32];
+        dcol[j] = dob[qr * ldo + l32];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        unsigned w = 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int qi = q0 + 4 * half + 8 * g + u;
+          const bool bl = qi >= Lq || (mcol && mcol[(long)min(qi, Lq - 1) * Lk]);
+          w |= (bl ? 1u : 0u) << (8 * u);
+        }
+        mb[g] = w;
+      }
+    }
+  }
+  __device__ __forceinline__ unsigned blocked() const {
+    auto nib = [](unsigned w) { return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u); };
+    return nib(mb[0]) | (nib(mb[1]) << 4) | (nib(mb[2]) << 8) | (nib(mb[3]) << 12);
+  }
+};
+
+// backward, key side: dV = P^T dO, dK = scale * dS^T Q for 32 keys, walking the queries.  grid (nkb, B * H).  The per-query
+// terms of a tile — the row's log-sum-exp and D — enter the score / dP accumulators through ONE extra MFMA step each (A = -lse
+// or -D of the lane's query in the first half of the reduction pair, 0 in the second; B = 1): the keys sit across the lanes
+// here, so subtracting them element-wise would take a broadcast load per register instead
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                               const float* __restrict__ dsum, float* __restrict__ dk,
+                                                               float* __restrict__ dv, const AttnBwdGeom G) {
+  __shared__ float sK[NW][32][33];
+  __shared__ float sV[NW][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int bh = blockIdx.y, b = bh / G.H, h = bh % G.H;
   const int k0 = blockIdx.x * 32, key = k0 + l32, kcl = min(key, G.Lk - 1);
   float kreg[16], vreg[16];
   load_half_row(k + ((long)b * G.Lk + kcl) * G.ldk + h * 32 + 16 * half, kreg);
   load_half_row(v + ((long)b * G.Lk + kcl) * G.ldv + h * 32 + 16 * half, vreg);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) kreg[j] *= G.scale * kLog2e;
   const unsigned char* mcol = nullptr;  // + qi * Lk per query row
   if (mask != nullptr && G.mode != 0) mcol = mask + mask_block(G.mode, b, bh) * G.Lq * (long)G.Lk + kcl;
   const float* qbp = q + (long)b * G.Lq * G.ldq + h * 32;
@@ -309,39 +459,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   const float* lseb = lse + (long)bh * G.Lq;
   const float* dsb = dsum + (long)bh * G.Lq;
   const int nqt = (G.Lq + 31) >> 5;
+  const unsigned kdead = key >= G.Lk ? 0xffffu : 0u;
   f32x16 dvacc = zero16(), dkacc = zero16();  // rows d, columns = this workgroup's keys
-  for (int t = wave; t < nqt; t += 4) {
-    const int q0 = t * 32;
-    float qa[16], da[16], qcol[16], dcol[16];
-    const long qrow = min(q0 + l32, G.Lq - 1);
-    load_half_row(qbp + qrow * G.ldq + 16 * half, qa);
-    load_half_row(dob + qrow * G.ldo + 16 * half, da);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const long qr = min(q0 + tile_row(j, half), G.Lq - 1);
-      qcol[j] = qbp[qr * G.ldq + l32];
-      dcol[j] = dob[qr * G.ldo + l32];
+  int t = wave;
+  QueryTile cur;
+  if (t < nqt) cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, t * 32, G.Lq, G.Lk, half, l32);
+  for (; t < nqt; t += NW) {
+    QueryTile nxt;
+    if (ATTN_PF_DKV) nxt.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+    const unsigned bl = cur.blocked() | kdead;
+    if (__all(bl == 0xffffu)) {
+      if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+      continue;
     }
     f32x16 s = zero16(), dp = zero16();
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? -cur.nlse * kLog2e : 0.f, 1.f, s, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j], kreg[j], s, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.qrow[j], kreg[j], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? -cur.nD : 0.f, 1.f, dp, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[j], vreg[j], dp, 0, 0, 0);
-    f32x16 ds;
+    for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.drow[j], vreg[j], dp, 0, 0, 0);
+    if (__any(bl != 0u)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = q0 + tile_row(r, half);
-      const int qc = min(qi, G.Lq - 1);
-      bool bl = qi >= G.Lq || key >= G.Lk;
-      if (mcol) bl = bl || mcol[(long)qc * G.Lk];
-      const float p = bl ? 0.f : __expf(s[r] * G.scale - lseb[qc]);
-      s[r] = p;
-      ds[r] = p * (dp[r] - dsb[qc]) * G.scale;
+      for (int r = 0; r < 16; ++r)
+        if ((bl >> r) & 1u) s[r] = -INFINITY;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[j], s[j], dvacc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r]);
+      dp[r] = s[r] * dp[r] * G.scale;
+    }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[j], ds[j], dkacc, 0, 0, 0);
+    for (int j = 0; j < 16; ++j) dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.dcol[j], s[j], dvacc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.qcol[j], dp[j], dkacc, 0, 0, 0);
+    if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -349,11 +501,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     sK[wave][l32][tile_row(r, half)] = dkacc[r];
   }
   __syncthreads();
+  if (tid >= 256) return;
   const int kk = tid >> 3, d4 = (tid & 7) * 4;
   if (k0 + kk >= G.Lk) return;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < NW; ++w)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u] += sV[w][kk][d4 + u];
@@ -362,6 +515,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   *reinterpret_cast<float4*>(dv + ((long)b * G.Lk + k0 + kk) * G.lddv + h * 32 + d4) = make_float4(a[0], a[1], a[2], a[3]);
   *reinterpret_cast<float4*>(dk + ((long)b * G.Lk + k0 + kk) * G.lddk + h * 32 + d4) = make_float4(c[0], c[1], c[2], c[3]);
 }
+
+namespace {
 
 // key chunks of a launch: enough workgroups for the chip when the query blocks alone are few, at least 8 key tiles (two per
 // wavefront) per chunk
@@ -392,6 +547,11 @@ int check_attn(const char* what, const void* const* ptrs, int nptr, int B, int h
 
 using namespace rscotr;
 
+#ifndef ATTN_NW
+#define ATTN_NW 4  // wavefronts per workgroup: they split the walk over the key (query) tiles (8: 35.2 ms per round, 4: 35.0)
+#endif
+static_assert(ATTN_NW >= 4, "the combine stages use 256 threads");
+
 extern "C" int64_t rscotr_attn_core_workspace(int B, int heads, int Lq, int Lk) {
   int nch, per;
   attn_chunks(B * heads, Lq, Lk, &nch, &per);
@@ -418,12 +578,12 @@ extern "C" int rscotr_attn_core_fwd(const float* q, const float* k, const float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(nqb * G.nch, B * heads);
   if (G.nch == 1) {
-    attn_fwd_kernel<false><<<grid, 256, 0, s>>>(q, k, v, mask, out, lse, nullptr, G);
+    attn_fwd_kernel<false, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, lse, nullptr, G);
   } else {
     if (workspace == nullptr || workspace_bytes < rscotr_attn_core_workspace(B, heads, Lq, Lk))
       return fail(RSCOTR_E_ARG, "rscotr_attn_core_fwd: workspace of %lld bytes needed", (long long)rscotr_attn_core_workspace(B, heads, Lq, Lk));
     float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((int64_t)B * heads * Lq * 4 + 255) / 256 * 256);
-    attn_fwd_kernel<true><<<grid, 256, 0, s>>>(q, k, v, mask, out, lse, part, G);
+    attn_fwd_kernel<true, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, lse, part, G);
     attn_merge_kernel<true><<<dim3(nqb, B * heads), 256, 0, s>>>(part, out, lse, heads, Lq, ldo, G.nch);
   }
   return check_launch("rscotr_attn_core_fwd");
@@ -451,11 +611,11 @@ extern "C" int rscotr_attn_core_bwd(const float* q, const float* k, const float*
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((int64_t)B * heads * Lq * 4 + 255) / 256 * 256);
   const dim3 grid(nqb * G.nch, B * heads);
   if (G.nch == 1) {
-    attn_bwd_dq_kernel<false><<<grid, 256, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, nullptr, G);
+    attn_bwd_dq_kernel<false, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, nullptr, G);
   } else {
-    attn_bwd_dq_kernel<true><<<grid, 256, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, part, G);
+    attn_bwd_dq_kernel<true, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, part, G);
     attn_merge_kernel<false><<<dim3(nqb, B * heads), 256, 0, s>>>(part, dq, nullptr, heads, Lq, lddq, G.nch);
   }
-  attn_bwd_dkv_kernel<<<dim3(nkb, B * heads), 256, 0, s>>>(q, k, v, mask, dout, lse, dsum, dk, dv, G);
+  attn_bwd_dkv_kernel<ATTN_NW><<<dim3(nkb, B * heads), 64 * ATTN_NW, 0, s>>>(q, k, v, mask, dout, lse, dsum, dk, dv, G);
   return check_launch("rscotr_attn_core_bwd");
 }
