@@ -436,17 +436,20 @@ struct QueryTile {
 // terms of a tile — the row's log-sum-exp and D — enter the score / dP accumulators through ONE extra MFMA step each (A = -lse
 // or -D of the lane's query in the first half of the reduction pair, 0 in the second; B = 1): the keys sit across the lanes
 // here, so subtracting them element-wise would take a broadcast load per register instead
-template <int NW>
+// OWN (few query tiles against many keys — the seg decoder's cross-attention): every wavefront owns a key block of its own and
+// walks ALL query tiles; nothing to combine, no LDS, a quarter of the workgroups
+template <int NW, bool OWN>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                const float* __restrict__ dsum, float* __restrict__ dk,
                                                                float* __restrict__ dv, const AttnBwdGeom G) {
-  __shared__ float sK[NW][32][33];
-  __shared__ float sV[NW][32][33];
+  __shared__ float sK[OWN ? 1 : NW][32][33];
+  __shared__ float sV[OWN ? 1 : NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int bh = blockIdx.y, b = bh / G.H, h = bh % G.H;
-  const int k0 = blockIdx.x * 32, key = k0 + l32, kcl = min(key, G.Lk - 1);
+  const int k0 = (OWN ? blockIdx.x * NW + wave : blockIdx.x) * 32, key = k0 + l32, kcl = min(key, G.Lk - 1);
+  if (OWN && k0 >= G.Lk) return;
   float kreg[16], vreg[16];
   load_half_row(k + ((long)b * G.Lk + kcl) * G.ldk + h * 32 + 16 * half, kreg);
   load_half_row(v + ((long)b * G.Lk + kcl) * G.ldv + h * 32 + 16 * half, vreg);
@@ -461,15 +464,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const float* __re
   const int nqt = (G.Lq + 31) >> 5;
   const unsigned kdead = key >= G.Lk ? 0xffffu : 0u;
   f32x16 dvacc = zero16(), dkacc = zero16();  // rows d, columns = this workgroup's keys
-  int t = wave;
+  constexpr int TS = OWN ? 1 : NW;  // tile stride of this wavefront's walk
+  int t = OWN ? 0 : wave;
   QueryTile cur;
   if (t < nqt) cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, t * 32, G.Lq, G.Lk, half, l32);
-  for (; t < nqt; t += NW) {
+  for (; t < nqt; t += TS) {
     QueryTile nxt;
-    if (ATTN_PF_DKV) nxt.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+    if (ATTN_PF_DKV) nxt.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + TS, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
     const unsigned bl = cur.blocked() | kdead;
     if (__all(bl == 0xffffu)) {
-      if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+      if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + TS, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
       continue;
     }
     f32x16 s = zero16(), dp = zero16();
@@ -493,7 +497,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const float* __re
     for (int j = 0; j < 16; ++j) dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.dcol[j], s[j], dvacc, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.qcol[j], dp[j], dkacc, 0, 0, 0);
-    if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + NW, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+    if (ATTN_PF_DKV) cur = nxt; else cur.load(qbp, dob, lseb, dsb, mcol, G.ldq, G.ldo, min(t + TS, nqt - 1) * 32, G.Lq, G.Lk, half, l32);
+  }
+  if (OWN) {  // lane (key, half) holds d = 4 * half + 8 * g + 0..3 of its key's rows
+    if (key < G.Lk) {
+      float* pv = dv + ((long)b * G.Lk + key) * G.lddv + h * 32 + 4 * half;
+      float* pk = dk + ((long)b * G.Lk + key) * G.lddk + h * 32 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(pv + 8 * g) = make_float4(dvacc[4 * g], dvacc[4 * g + 1], dvacc[4 * g + 2], dvacc[4 * g + 3]);
+        *reinterpret_cast<float4*>(pk + 8 * g) = make_float4(dkacc[4 * g], dkacc[4 * g + 1], dkacc[4 * g + 2], dkacc[4 * g + 3]);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -616,6 +632,9 @@ extern "C" int rscotr_attn_core_bwd(const float* q, const float* k, const float*
     attn_bwd_dq_kernel<true, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, part, G);
     attn_merge_kernel<false><<<dim3(nqb, B * heads), 256, 0, s>>>(part, dq, nullptr, heads, Lq, lddq, G.nch);
   }
-  attn_bwd_dkv_kernel<ATTN_NW><<<dim3(nkb, B * heads), 64 * ATTN_NW, 0, s>>>(q, k, v, mask, dout, lse, dsum, dk, dv, G);
+  if (nqb <= 8 && (long)((nkb + ATTN_NW - 1) / ATTN_NW) * B * heads >= 128)  // few queries, many keys: a key block per wavefront
+    attn_bwd_dkv_kernel<ATTN_NW, true><<<dim3((nkb + ATTN_NW - 1) / ATTN_NW, B * heads), 64 * ATTN_NW, 0, s>>>(q, k, v, mask, dout, lse, dsum, dk, dv, G);
+  else
+    attn_bwd_dkv_kernel<ATTN_NW, false><<<dim3(nkb, B * heads), 64 * ATTN_NW, 0, s>>>(q, k, v, mask, dout, lse, dsum, dk, dv, G);
   return check_launch("rscotr_attn_core_bwd");
 }

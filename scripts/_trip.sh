@@ -1,4 +1,3 @@
-bash scripts/gpu_suite.sh r4s2 > /dev/null 2>&1
-tail -3 gpurun_out/r4s2/pytest.log; cat gpurun_out/r4s2/bench.json | cut -c1-200
-bash scripts/gpu_prof_graph.sh r4b
-bash scripts/gpu_prof_bench.sh r4b | cut -c1-200
+python -m pytest tests/test_mha_gpu.py -q -m gpu -p no:cacheprovider --tb=short 2>&1 | grep -E "^E  |passed|failed" | cut -c1-300 | head
+python scripts/bench_attn.py seg
+bash scripts/gpu_ab_bench.sh ab_own "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_prev.so" "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_prev.so" ""
