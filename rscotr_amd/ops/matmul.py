@@ -313,12 +313,15 @@ class _DeferredCombine:
         tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else
                  ((M + 127) // 128) * ((N + 127) // 128) if k in (4, 6) else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
-        # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k)
-        work = sum(t * p[7] * (4 if k in (2, 4, 6) else 1) for t, k, p in zip(tiles, kinds, probs))
-        klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
+        # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k), per
+        # LAUNCH: with one target for the whole pass the few fp32 64 x 64 members of a det backward (the 4- and 20-row
+        # reg / cls branches over K = 10880) inherited the k-slice of the big bf16x6 launch and ran as 160 workgroups of
+        # K = 3632 each: 260 us for 0.1 GFLOP
         dev = self.group_keep[0].device
         launches, ents = [], []
         for variant in (0, 2, 3, 4, 6):
+            work = sum(t * p[7] * (4 if k in (2, 4, 6) else 1) for t, k, p in zip(tiles, kinds, probs) if k == variant)
+            klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
             rows = []
             for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
                 if x6 != variant:
