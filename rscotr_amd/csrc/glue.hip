@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256) void level_embed_fwd_kernel(const float4* __re
 }
 
 // dw[l, c] (+)= sum over b and the tokens t of level l of g[b, t, c], in a FIXED order (bit-reproducible): workgroup
-// (chunk k, level l) sums its rows of the level (rows = b * n_l + position) column by column, leaves a partial, and the
-// LAST workgroup of a level to finish folds the partials k = 0.. in order (counter[l] returns to 0: self-resetting).
+// (chunk k, level l) sums its rows of the level (rows = b * n_l + position) — four row lanes x 64 float4 columns, every lane a
+// strided chain with eight loads in flight, the lanes folded in LDS in lane order — leaves a partial, and the LAST workgroup of
+// a level to finish folds the partials k = 0.. in order (counter[l] returns to 0: self-resetting).  (Round 4: the first
+// version walked 256 rows per workgroup as ONE dependent load-add chain per column: 27 - 60 us per call, 0.4 ms per round.)
 __global__ __launch_bounds__(256) void level_embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ part,
                                                               int* __restrict__ counter, float* __restrict__ dw,
                                                               LevelStarts ls, int B, int N, int C, int accumulate) {
@@ -44,20 +46,28 @@ __global__ __launch_bounds__(256) void level_embed_bwd_kernel(const float* __res
   const int s0 = ls.start[l], nl = ls.start[l + 1] - s0;
   const long rows = (long)B * nl;
   const long r0 = rows * k / chunks, r1 = rows * (k + 1) / chunks;
+  const int C4 = C >> 2, rl = threadIdx.x >> 6, cq = threadIdx.x & 63;
+  __shared__ float4 sh[4][256];
   __shared__ int last;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    long r = r0;
-    for (; r + 4 <= r1; r += 4) {  // four independent chains, folded in a fixed order
-      const long q0 = r, q1 = r + 1, q2 = r + 2, q3 = r + 3;
-      a0 += g[((q0 / nl) * N + s0 + q0 % nl) * C + c];
-      a1 += g[((q1 / nl) * N + s0 + q1 % nl) * C + c];
-      a2 += g[((q2 / nl) * N + s0 + q2 % nl) * C + c];
-      a3 += g[((q3 / nl) * N + s0 + q3 % nl) * C + c];
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* part4 = reinterpret_cast<float4*>(part);
+  for (int c4 = cq; c4 < C4; c4 += 64) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float4 v = g4[((r / nl) * N + s0 + r % nl) * C4 + c4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    for (; r < r1; ++r) a0 += g[((r / nl) * N + s0 + r % nl) * C + c];
-    part[((long)l * chunks + k) * C + c] = (a0 + a1) + (a2 + a3);
+    sh[rl][c4] = a;
   }
+  __syncthreads();
+  if (rl == 0)
+    for (int c4 = cq; c4 < C4; c4 += 64) {
+      float4 a = sh[0][c4];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) { const float4 v = sh[j][c4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      part4[((long)l * chunks + k) * C4 + c4] = a;
+    }
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last = (atomicAdd(&counter[l], 1) == chunks - 1);
@@ -66,6 +76,7 @@ __global__ __launch_bounds__(256) void level_embed_bwd_kernel(const float* __res
   __threadfence();
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int j = 0; j < chunks; ++j) s += __builtin_nontemporal_load(&part[((long)l * chunks + j) * C + c]);
     dw[(long)l * C + c] = accumulate ? dw[(long)l * C + c] + s : s;
   }
@@ -301,6 +312,8 @@ extern "C" int rscotr_level_embed_bwd(const float* g, float* dw, const int* size
   LevelStarts ls;
   if (int e = level_starts("rscotr_level_embed_bwd", sizes, L, N, &ls)) return e;
   if (!g || !dw || !workspace || !counters) return fail(RSCOTR_E_ARG, "rscotr_level_embed_bwd: null pointer");
+  if ((C & 3) || C > 1024 || !aligned16(g) || !aligned16(workspace))
+    return fail(RSCOTR_E_SHAPE, "rscotr_level_embed_bwd: C = %d (a multiple of 4, at most 1024) and 16-byte aligned g / workspace required", C);
   level_embed_bwd_kernel<<<dim3(32, (unsigned)L), 256, 0, (hipStream_t)stream>>>(g, workspace, counters, dw, ls, B, N, C, accumulate);
   return check_launch("rscotr_level_embed_bwd");
 }
