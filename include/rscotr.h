@@ -138,6 +138,13 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * transposed, the plane set then has K rows).  Plane buffers hold npad * reduction * 6 bytes. */
 int rscotr_gemm_split_weights(const int64_t* table, int n, int total_blocks, void* stream);
 int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K);
+/* 1 if rscotr_gemm_f32_wplanes is worth calling for the shape: the 128-row weight-plane kernel's domain (M >= 4096, K >= 1024)
+ * or — only after rscotr_gemm_set_wplanes_tiled(1) / RSCOTR_WPLANES_TILED=1; off by default: built, tested, measured no faster
+ * (profiles/r4_planes_b_tiled.txt) — whatever the tiled split-product kernels take with their B operand read from the plane set
+ * (K >= 192, enough output tiles); 0: multiply with the fp32 weight (rscotr_gemm_f32).  act_is_gelu: the product carries a GELU
+ * epilogue.  rscotr_gemm_set_wplanes_tiled returns the previous setting. */
+int rscotr_gemm_f32_wplanes_ok(int M, int N, int K, int act_is_gelu);
+int rscotr_gemm_set_wplanes_tiled(int on);
 int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int npad, float* C, int M, int N, int K, int lda, int ldc,
                             const float* bias, int act, const float* aux, float* pre, const float* resid, int accumulate,
                             const float* rowscale, int rows_per_scale, float* out2, float* workspace,

@@ -35,6 +35,7 @@
 #include <atomic>
 #include <mutex>
 #include <set>
+#include <type_traits>
 
 #ifndef RSCOTR_GEMM_PREC_DEFAULT
 #define RSCOTR_GEMM_PREC_DEFAULT 3
@@ -895,6 +896,56 @@ struct SplitOperand {
   }
 };
 
+// B operand that ARRIVES as bf16 planes (round 4): a parameter's plane set written once per optimizer step by
+// rscotr_gemm_split_weights (layout [K / 16][npad rows][3 planes][16 k], zero rows behind N: csrc comment of gemm_wplanes_kernel)
+// goes global -> VGPR -> LDS untouched — no conversion, 96 bytes per row and 16-k step instead of 64 bytes of fp32.  In the
+// tiled kernels below a workgroup converted its B tile (a weight: the same values in every one of the M / 64 row tiles and in
+// every launch of the step) again in every k step; with this operand only A, the activation, is split while it is staged.
+// LDS stage = SBK / 16 sub-stages of R rows x 112 bytes (the weight-plane kernel's row: conflict-free 16-byte fragment reads).
+constexpr int PLANE_LDR = 56;  // bf16 per LDS row: 3 planes x 16 k + 8 pad
+template <int R, int SBK>
+struct PlaneOperand {
+  static constexpr int SUB = SBK / 16;
+  static constexpr int WORDS = SUB * R * PLANE_LDR / 2;  // dwords per stage
+  static constexpr int ITEMS = SUB * R * 6;              // 16-byte pieces per stage
+  static constexpr int NV = (ITEMS + 255) / 256;
+  static_assert(NV <= 3, "three pieces per thread at most");
+  uint4 v0, v1, v2;  // (named members, not an array: the compiler moved a uint4 array of the non-EDGE instantiations to LDS / scratch)
+  template <bool EDGE>
+  static __device__ __forceinline__ uint4 piece_load(const unsigned short* __restrict__ pl, int ld, int row0, int k0, int idx, int klim) {
+    const int sub = idx / (R * 6), rem = idx - sub * (R * 6), row = rem / 6, piece = rem - row * 6;
+    int kt = (k0 >> 4) + sub;
+    const bool past = EDGE && kt * 16 >= klim;
+    if (EDGE) kt = min(kt, (klim >> 4) - 1);
+    uint4 v = *reinterpret_cast<const uint4*>(pl + ((long)kt * ld + row0 + row) * 48 + piece * 8);
+    if (past) v = make_uint4(0u, 0u, 0u, 0u);
+    return v;
+  }
+  static __device__ __forceinline__ void piece_store(unsigned* S, int idx, const uint4& v) {
+    const int sub = idx / (R * 6), rem = idx - sub * (R * 6), row = rem / 6, piece = rem - row * 6;
+    *reinterpret_cast<uint4*>(S + sub * (R * PLANE_LDR / 2) + row * (PLANE_LDR / 2) + piece * 4) = v;
+  }
+  // P = the plane set (as const float*: the slot of GemmParams.B), ld = npad; rows past N are the set's zero rows; k steps past
+  // klim (EDGE: the reduction's end, a multiple of 16) are zeros
+  template <bool EDGE = false>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid, int rlast = 0, int klim = 0) {
+    const unsigned short* pl = reinterpret_cast<const unsigned short*>(P);
+    v0 = piece_load<EDGE>(pl, ld, row0, k0, tid, klim);
+    if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) v1 = piece_load<EDGE>(pl, ld, row0, k0, tid + 256, klim);
+    if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) v2 = piece_load<EDGE>(pl, ld, row0, k0, tid + 512, klim);
+  }
+  __device__ __forceinline__ void store(unsigned* S, int tid) const {
+    piece_store(S, tid, v0);
+    if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) piece_store(S, tid + 256, v1);
+    if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) piece_store(S, tid + 512, v2);
+  }
+  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) {
+    const unsigned* q = S + ks * (R * PLANE_LDR / 2) + (row * PLANE_LDR + 8 * g) / 2;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
+  }
+};
+
 // PIPE: 0 = one LDS stage, two barriers per k-tile of 16; 1 = two LDS stages, one barrier, next tile's loads one step ahead;
 // 2 / 3 = the software-pipelined loop (two LDS stages, one barrier): the loads of tile t + D are issued at the top of step t
 // into the register set step t - 1 freed (D = 2 / 3 sets), and the split / pack / LDS writes of tile t + 1 are interleaved
@@ -908,19 +959,21 @@ template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : 16; }
 #endif
 template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? RSCOTR_X6_D2 : PIPE == 3 ? 3 : 1; }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool BPL = false>
 constexpr int bf16x6_lds_words() {
-  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS);
+  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS +
+                           (BPL ? PlaneOperand<BN, bf16x6_bk<PIPE>()>::WORDS : SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS));
 }
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false>
+// BPL: p.B / p.ldb = the pre-split plane set of B and its row count (PlaneOperand above; BKM is then irrelevant)
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool BPL = false>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
   constexpr int NPL = 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
   using OA = SplitOperand<BM, AKM, NPL, SBK>;
-  using OB = SplitOperand<BN, BKM, NPL, SBK>;
+  using OB = std::conditional_t<BPL, PlaneOperand<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK>>;
   constexpr int NBUF = PIPE ? 2 : 1;
   unsigned* sA[2] = {lds, lds + (NBUF - 1) * OA::WORDS};
   unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
@@ -1132,10 +1185,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, bool BPL = false>
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE>()];
-  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE>(p, blockIdx.x, gridDim.x, lds);
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, BPL>()];
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, BPL>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2396,10 +2449,58 @@ static void wplanes_cfg(int M, int N, int K, int* bn_out, int* splits_out) {
   *bn_out = bbn; *splits_out = bsp;
 }
 
+// Which kernel multiplies with a plane set: the 128-row weight-plane kernel above where it wins (long reductions over many rows:
+// the encoder's FFN2 / its dX), else the TILED split-product kernels with their B operand from planes (gemm_bf16x6_kernel<...,
+// BPL = true>: the 64 x 64 pipelined and the 128 x 128 tiles, k-slices, EDGE instantiations — every shape choose_split6 takes).
+static bool wplanes_classic(int M, int K) {
+  static const int min_m = getenv("RSCOTR_WPLANES_MIN_M") ? atoi(getenv("RSCOTR_WPLANES_MIN_M")) : 4096;
+  static const int min_k = getenv("RSCOTR_WPLANES_MIN_K") ? atoi(getenv("RSCOTR_WPLANES_MIN_K")) : 1024;
+  return M >= min_m && K >= min_k;
+}
+
+// OFF by default (RSCOTR_WPLANES_TILED=1 / rscotr_gemm_set_wplanes_tiled(1)): measured in the step, the tiled kernels are no
+// faster with their B operand from planes (10880 x 256 x 256: 22.0 us against 20.4; the encoder's FFN1 97.8 against 93) and the
+// per-iteration split of every weight in both orientations costs ~0.4 ms: 36.4 ms per round against 35.3
+// (profiles/r4_planes_b_tiled.txt) — the conversion instructions are not what bounds these kernels, as the planes x planes lab
+// kernel of round 3 had shown for both operands.
+static std::atomic<int> g_wplanes_tiled{[] {
+  const char* e = getenv("RSCOTR_WPLANES_TILED");
+  return e ? atoi(e) : 0;
+}()};
+
+static Split6Cfg wplanes_tiled_cfg(GemmParams p, int64_t ws_bytes) {
+  Split6Cfg none{0, 1, p.K};
+  if (!g_wplanes_tiled.load(std::memory_order_relaxed) || p.K % 16) return none;
+  p.vecA = 1; p.vecB = 1; p.kscale = nullptr;
+  return choose_split6(p, 0, 0, ws_bytes);
+}
+
+extern "C" int rscotr_gemm_set_wplanes_tiled(int on) { return g_wplanes_tiled.exchange(on ? 1 : 0); }
+
+/* 1: rscotr_gemm_f32_wplanes takes (M, N, K) — either kernel; 0: the caller multiplies with the fp32 weight (rscotr_gemm_f32) */
+extern "C" int rscotr_gemm_f32_wplanes_ok(int M, int N, int K, int act_is_gelu) {
+  if (M <= 0 || N <= 0 || K < 16 || K % 16) return 0;
+  if (wplanes_classic(M, K)) return N >= 64;
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K; p.act = act_is_gelu ? ACT_GELU : ACT_NONE;
+  return wplanes_tiled_cfg(p, INT64_MAX / 4).bm != 0;
+}
+
 extern "C" int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K) {
+  if (!wplanes_classic(M, K)) {
+    GemmParams p{};
+    p.M = M; p.N = N; p.K = K; p.act = ACT_NONE;
+    const Split6Cfg sc = wplanes_tiled_cfg(p, INT64_MAX / 4);
+    if (sc.bm) return sc.splits > 1 ? (int64_t)sc.splits * ((int64_t)M * N + M) * 4 : 0;
+  }
   int bn, splits;
   wplanes_cfg(M, N, K, &bn, &splits);
   return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+}
+
+template <int BM, int PIPE, bool EDGE = false>
+static void launch_split6_planes(const GemmParams& p, unsigned nwg, hipStream_t s) {
+  gemm_bf16x6_kernel<BM, BM, false, false, PIPE, EDGE, true><<<dim3(nwg), 256, 0, s>>>(p);
 }
 
 // C = epilogue(A x Bplanes): A (M, K) fp32 row-major (lda), planes = the pre-split B of rscotr_gemm_split_weights (N rows,
@@ -2427,6 +2528,41 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
   p.nb1 = 0; p.nb2 = 1;
   p.rowscale = rowscale; p.rows_per = rows_per_scale; p.kscale = nullptr; p.krows_per = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (!wplanes_classic(M, K)) {  // tiled split-product kernels, B from the plane set
+    const Split6Cfg sc = wplanes_tiled_cfg(p, workspace ? workspace_bytes : 0);
+    if (sc.bm) {
+    p.B = reinterpret_cast<const float*>(planes); p.ldb = npad;
+    p.tiles = ((M + sc.bm - 1) / sc.bm) * ((N + sc.bm - 1) / sc.bm);
+    if ((long)((N + sc.bm - 1) / sc.bm) * sc.bm > npad) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32_wplanes: npad %d too small for N = %d", npad, N);
+    const bool ragged = M % sc.bm || N % sc.bm;
+    p.splits = sc.splits; p.ksplit_len = sc.klen;
+    p.slabs = sc.splits > 1 ? workspace : nullptr;
+    p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
+    static const bool prof_shapes_t = getenv("RSCOTR_PROF_SHAPES") != nullptr;
+    char tname[112];
+    if (prof_shapes_t) snprintf(tname, sizeof(tname), "M=%d N=%d K=%d 0p bf16x6-%d-planes splits=%d", M, N, K, sc.bm, sc.splits);
+    else snprintf(tname, sizeof(tname), "rscotr::gemm_bf16x6_kernel<%d, %d, false, planes, *>", sc.bm, sc.bm);
+    ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", tname);
+    const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
+    const bool k32 = K % 32 == 0 && sc.klen % 32 == 0;
+    if (ragged) {
+      if (sc.bm == 128) launch_split6_planes<128, 0, true>(p, nwg, s);
+      else if (k32) launch_split6_planes<64, 2, true>(p, nwg, s);
+      else launch_split6_planes<64, 1, true>(p, nwg, s);
+    } else if (sc.bm == 128) {
+      launch_split6_planes<128, 0>(p, nwg, s);
+    } else {
+      if (k32) launch_split6_planes<64, 2>(p, nwg, s);
+      else launch_split6_planes<64, 1>(p, nwg, s);
+    }
+    if (int e = check_launch("rscotr_gemm_f32_wplanes (tiled)")) return e;
+    if (sc.splits > 1) {
+      launch_splitk_reduce(p, workspace, s);
+      return check_launch("rscotr_gemm_f32_wplanes (tiled, split-K reduce)");
+    }
+    return RSCOTR_OK;
+    }  // (shapes the tiled kernels do not take: the 128-row kernel below handles any M, N)
+  }
   int bn, splits;
   wplanes_cfg(M, N, K, &bn, &splits);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4))

@@ -24,6 +24,7 @@ class _WeightPlanes:
         self.min_k = int(os.environ.get('RSCOTR_WPLANES_MIN_K', 1024))
         self.version = 1
         self.entries, self.groups, self.tables = {}, {}, {}
+        self.shape_ok = {}
         self.current = None
 
     def begin(self, group):
@@ -38,14 +39,20 @@ class _WeightPlanes:
     def bump(self):
         self.version += 1
 
-    def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
-        if not self.enabled or a_kmajor or STATE.grad_sink is None or K % 16 or K < self.min_k or M < self.min_m or N < 64:
+    def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, gelu=False):
+        if not self.enabled or a_kmajor or STATE.grad_sink is None or K % 16 or N < 64:
             return False
         if lda % 4 or A.data_ptr() % 16 or (b_kmajor and ldb % 4):
             return False
         if lib.rscotr_gemm_get_precision() != 3:
             return False
-        return STATE.grad_sink.is_param_ptr(B.data_ptr())
+        # the shape: the 128-row weight-plane kernel's domain or, round 4, whatever the tiled split-product kernels take with
+        # their B operand read from the plane set (the library decides: rscotr_gemm_f32_wplanes_ok)
+        key = (M, N, K, bool(gelu))  # (the tiled route is a process-start switch, RSCOTR_WPLANES_TILED: the answer is cached)
+        ok = self.shape_ok.get(key)
+        if ok is None:
+            ok = self.shape_ok[key] = bool(lib.rscotr_gemm_f32_wplanes_ok(M, N, K, int(bool(gelu))))
+        return ok and STATE.grad_sink.is_param_ptr(B.data_ptr())
 
     def get(self, B, N, K, ldb, b_kmajor):
         """-> (planes pointer, npad) of the weight behind operand B (N output rows, reduction K), fresh."""
@@ -641,7 +648,8 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     if (rowsum is None and kscale is None and STATE.profile is None
-            and WPLANES.eligible(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor)):
+            and WPLANES.eligible(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor,
+                                 gelu=act in (ACT_GELU, ACT_GELU_GRAD) or pre is not None)):
         # B is a parameter: multiply with its pre-split bf16 planes (written once per optimizer step)
         planes, npad = WPLANES.get(B, N, K, ldb, b_kmajor)
         nws = lib.rscotr_gemm_f32_wplanes_workspace(M, N, K)

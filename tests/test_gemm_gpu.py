@@ -91,9 +91,21 @@ def _split_planes(lib, W, rows, red, ldw, tr, cuda):
 
 
 @pytest.mark.parametrize('M,N,K', [(10880, 2048, 256), (10880, 256, 2048), (2048, 384, 1536), (32768, 384, 96), (8192, 288, 192),
-                                   (2048, 1152, 384), (1600, 256, 256), (1000, 200, 112), (300, 45, 64)])
+                                   (2048, 1152, 384), (1600, 256, 256), (1000, 200, 112), (300, 45, 64), (10880, 256, 256),
+                                   (10880, 384, 256), (8192, 768, 192), (13294, 256, 272), (2048, 1536, 384), (2500, 3072, 768),
+                                   (32768, 96, 384)])
 @pytest.mark.parametrize('tr', [0, 1])
-def test_gemm_with_presplit_weight_planes(cuda, M, N, K, tr):
+@pytest.mark.parametrize('tiled', [0, 1])  # 1: the tiled split-product kernels read B from the plane set (opt-in route, round 4)
+def test_gemm_with_presplit_weight_planes(cuda, M, N, K, tr, tiled):
+    from rscotr_amd._lib import lib
+    prev = lib.rscotr_gemm_set_wplanes_tiled(tiled)
+    try:
+        _presplit_weight_planes(cuda, M, N, K, tr)
+    finally:
+        lib.rscotr_gemm_set_wplanes_tiled(prev)
+
+
+def _presplit_weight_planes(cuda, M, N, K, tr):
     """rscotr_gemm_split_weights + rscotr_gemm_f32_wplanes against fp64: both plane orientations (y = x W^T with W (N, K);
     dx = dy W with W (K, N)), ragged M / N, k-slices, bias + activation / residual / second output epilogues; error of the
     class of an fp32 FMA chain (same bound as the in-kernel split)."""
