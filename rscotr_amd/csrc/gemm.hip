@@ -901,12 +901,14 @@ struct SplitOperand {
 // goes global -> VGPR -> LDS untouched — no conversion, 96 bytes per row and 16-k step instead of 64 bytes of fp32.  In the
 // tiled kernels below a workgroup converted its B tile (a weight: the same values in every one of the M / 64 row tiles and in
 // every launch of the step) again in every k step; with this operand only A, the activation, is split while it is staged.
-// LDS stage = SBK / 16 sub-stages of R rows x 112 bytes (the weight-plane kernel's row: conflict-free 16-byte fragment reads).
-constexpr int PLANE_LDR = 56;  // bf16 per LDS row: 3 planes x 16 k + 8 pad
+// LDS stage = R rows of SBK / 16 x 96 bytes + 16 bytes of padding (112 / 208 bytes: the row strides of the weight-plane kernel
+// and of the split operand at 32 k, conflict-free for 16-byte fragment reads; the 64 x 64 pipelined kernel keeps its 53 248
+// bytes = three workgroups per CU).
 template <int R, int SBK>
 struct PlaneOperand {
   static constexpr int SUB = SBK / 16;
-  static constexpr int WORDS = SUB * R * PLANE_LDR / 2;  // dwords per stage
+  static constexpr int LDRW = SUB * 24 + 4;              // dwords per LDS row
+  static constexpr int WORDS = R * LDRW;                 // dwords per stage
   static constexpr int ITEMS = SUB * R * 6;              // 16-byte pieces per stage
   static constexpr int NV = (ITEMS + 255) / 256;
   static_assert(NV <= 3, "three pieces per thread at most");
@@ -923,7 +925,7 @@ struct PlaneOperand {
   }
   static __device__ __forceinline__ void piece_store(unsigned* S, int idx, const uint4& v) {
     const int sub = idx / (R * 6), rem = idx - sub * (R * 6), row = rem / 6, piece = rem - row * 6;
-    *reinterpret_cast<uint4*>(S + sub * (R * PLANE_LDR / 2) + row * (PLANE_LDR / 2) + piece * 4) = v;
+    *reinterpret_cast<uint4*>(S + row * LDRW + sub * 24 + piece * 4) = v;
   }
   // P = the plane set (as const float*: the slot of GemmParams.B), ld = npad; rows past N are the set's zero rows; k steps past
   // klim (EDGE: the reduction's end, a multiple of 16) are zeros
@@ -940,7 +942,7 @@ struct PlaneOperand {
     if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) piece_store(S, tid + 512, v2);
   }
   static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) {
-    const unsigned* q = S + ks * (R * PLANE_LDR / 2) + (row * PLANE_LDR + 8 * g) / 2;
+    const unsigned* q = S + row * LDRW + ks * 24 + 4 * g;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
   }
@@ -2458,11 +2460,10 @@ static bool wplanes_classic(int M, int K) {
   return M >= min_m && K >= min_k;
 }
 
-// OFF by default (RSCOTR_WPLANES_TILED=1 / rscotr_gemm_set_wplanes_tiled(1)): measured in the step, the tiled kernels are no
-// faster with their B operand from planes (10880 x 256 x 256: 22.0 us against 20.4; the encoder's FFN1 97.8 against 93) and the
-// per-iteration split of every weight in both orientations costs ~0.4 ms: 36.4 ms per round against 35.3
-// (profiles/r4_planes_b_tiled.txt) — the conversion instructions are not what bounds these kernels, as the planes x planes lab
-// kernel of round 3 had shown for both operands.
+// OFF by default (RSCOTR_WPLANES_TILED=1 / 2, rscotr_gemm_set_wplanes_tiled): per dispatch the 64 x 64 kernels gain 15-28 % with
+// their B operand from planes (10880 x 256 x 256: 17.3 us against 20.4), the 128 x 128 one-stage kernel loses 4 %, and the
+// per-iteration split of ~23 M weights in both orientations costs ~0.3 ms per round: the round measures 35.7 ms against 35.4
+// (profiles/r4_planes_b_tiled.txt).
 static std::atomic<int> g_wplanes_tiled{[] {
   const char* e = getenv("RSCOTR_WPLANES_TILED");
   return e ? atoi(e) : 0;
@@ -2472,10 +2473,15 @@ static Split6Cfg wplanes_tiled_cfg(GemmParams p, int64_t ws_bytes) {
   Split6Cfg none{0, 1, p.K};
   if (!g_wplanes_tiled.load(std::memory_order_relaxed) || p.K % 16) return none;
   p.vecA = 1; p.vecB = 1; p.kscale = nullptr;
-  return choose_split6(p, 0, 0, ws_bytes);
+  const Split6Cfg sc = choose_split6(p, 0, 0, ws_bytes);
+  // mode 1: the 64 x 64 tiles only (17.3 / 22.3 / 26.7 us against 20.4 / 31 / 33 on the 680 / 576 / 768-workgroup shapes of the
+  // step; the 128 x 128 one-stage kernel measures 4 % SLOWER with its B from planes: 96.9 against 93 us on the encoder's FFN1);
+  // mode 2: both
+  if (sc.bm == 128 && g_wplanes_tiled.load(std::memory_order_relaxed) < 2) return none;
+  return sc;
 }
 
-extern "C" int rscotr_gemm_set_wplanes_tiled(int on) { return g_wplanes_tiled.exchange(on ? 1 : 0); }
+extern "C" int rscotr_gemm_set_wplanes_tiled(int on) { return g_wplanes_tiled.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 
 /* 1: rscotr_gemm_f32_wplanes takes (M, N, K) — either kernel; 0: the caller multiplies with the fp32 weight (rscotr_gemm_f32) */
 extern "C" int rscotr_gemm_f32_wplanes_ok(int M, int N, int K, int act_is_gelu) {
