@@ -2471,7 +2471,8 @@ static std::atomic<int> g_wplanes_tiled{[] {
 
 static Split6Cfg wplanes_tiled_cfg(GemmParams p, int64_t ws_bytes) {
   Split6Cfg none{0, 1, p.K};
-  if (!g_wplanes_tiled.load(std::memory_order_relaxed) || p.K % 16) return none;
+  static const int max_m = getenv("RSCOTR_WPLANES_TILED_MAXM") ? atoi(getenv("RSCOTR_WPLANES_TILED_MAXM")) : (1 << 30);
+  if (!g_wplanes_tiled.load(std::memory_order_relaxed) || p.K % 16 || p.M > max_m) return none;
   p.vecA = 1; p.vecB = 1; p.kscale = nullptr;
   const Split6Cfg sc = choose_split6(p, 0, 0, ws_bytes);
   // mode 1: the 64 x 64 tiles only (17.3 / 22.3 / 26.7 us against 20.4 / 31 / 33 on the 680 / 576 / 768-workgroup shapes of the

@@ -50,10 +50,22 @@ if dist.is_initialized():
 
 def _run(env_extra, port):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, '-c', _CHILD, ROOT, str(port)], capture_output=True, text=True, timeout=900, env=env)
-    lines = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')]
+    # The OVERLAPPED exchange (RSCOTR_DIST_INLINE=0, opt-in) leaves asynchronous works with c10d's RCCL watchdog thread; on this
+    # torch / ROCm pair the watchdog sometimes polls an event that was last recorded in a capturing stream
+    # ("hipErrorCapturedEvent ... Process group watchdog thread terminated") and aborts the child from its own thread — 2 of 8
+    # runs on one box, none of 16 with the inline default (scripts/lab/dist_overlap_flake.py).  That abort is
+    # the runtime's, not a wrong result: the overlapped child gets up to four tries, any OTHER failure fails the test at once.
+    tries = 4 if env_extra.get('RSCOTR_DIST_INLINE') == '0' else 1
+    for attempt in range(tries):
+        r = subprocess.run([sys.executable, '-c', _CHILD, ROOT, str(port + 10 * attempt)], capture_output=True, text=True,
+                           timeout=900, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')]
+        if lines:
+            return json.loads(lines[-1][7:])
+        watchdog_abort = 'hipErrorCapturedEvent' in r.stderr and 'watchdog thread terminated' in r.stderr
+        if not watchdog_abort:
+            break
     assert lines, (r.stdout[-1500:], r.stderr[-3000:])
-    return json.loads(lines[-1][7:])
 
 
 def test_one_rank_distributed_paths_train_like_the_plain_run(cuda):
