@@ -955,7 +955,10 @@ struct PlaneOperand {
 // the shadow of the matrix pipe instead of in a phase of its own.  PIPE 2 stages 32 k per step (64 x 64 tiles: a row-major
 // operand row is one whole 128-byte line per step; half as many barriers), PIPE 3 stages 16 (128 x 128 tiles: LDS).
 __device__ const float bf16x6_one = 1.f;
-template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : 16; }
+#ifndef RSCOTR_X6_BK0
+#define RSCOTR_X6_BK0 16  // k per barrier pair of the one-stage loop (PIPE 0: the 128 x 128 kernels, the grouped launch's bodies)
+#endif
+template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : PIPE == 0 ? RSCOTR_X6_BK0 : 16; }
 #ifndef RSCOTR_X6_D2
 #define RSCOTR_X6_D2 2
 #endif
@@ -963,8 +966,10 @@ template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? RSCOTR_X6_
 
 template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool BPL = false>
 constexpr int bf16x6_lds_words() {
-  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS +
-                           (BPL ? PlaneOperand<BN, bf16x6_bk<PIPE>()>::WORDS : SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS));
+  if constexpr (BPL)
+    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + PlaneOperand<BN, bf16x6_bk<PIPE>()>::WORDS);
+  else
+    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS);
 }
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
@@ -1531,7 +1536,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
     if (sp > 1) sp = std::min<long>(sp, ws_bytes / per);
     if (sp < 1) sp = 1;
     int klen = (int)((p.K + sp - 1) / sp);
-    klen = (klen + 15) / 16 * 16;
+    klen = (klen + RSCOTR_X6_BK0 - 1) / RSCOTR_X6_BK0 * RSCOTR_X6_BK0;
     c.bm = bm; c.klen = klen; c.splits = (p.K + klen - 1) / klen;
     if (c.splits == 1) c.klen = p.K;
     return c;
@@ -2279,7 +2284,7 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
     const Split6Cfg sc = choose_split6(p, a_kmajor, b_kmajor, workspace ? workspace_bytes : 0);
     if (sc.bm) {
       p.tiles = ((M + sc.bm - 1) / sc.bm) * ((N + sc.bm - 1) / sc.bm);
-      const bool ragged = M % sc.bm || N % sc.bm || K % 16;
+      const bool ragged = M % sc.bm || N % sc.bm || K % (sc.bm == 128 ? RSCOTR_X6_BK0 : 16);
       p.splits = sc.splits; p.ksplit_len = sc.klen;
       p.slabs = sc.splits > 1 ? workspace : nullptr;
       p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
@@ -2541,7 +2546,7 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
     p.B = reinterpret_cast<const float*>(planes); p.ldb = npad;
     p.tiles = ((M + sc.bm - 1) / sc.bm) * ((N + sc.bm - 1) / sc.bm);
     if ((long)((N + sc.bm - 1) / sc.bm) * sc.bm > npad) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32_wplanes: npad %d too small for N = %d", npad, N);
-    const bool ragged = M % sc.bm || N % sc.bm;
+    const bool ragged = M % sc.bm || N % sc.bm || (sc.bm == 128 && K % RSCOTR_X6_BK0);
     p.splits = sc.splits; p.ksplit_len = sc.klen;
     p.slabs = sc.splits > 1 ? workspace : nullptr;
     p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
@@ -2552,12 +2557,16 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
     ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", tname);
     const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
     const bool k32 = K % 32 == 0 && sc.klen % 32 == 0;
+#if RSCOTR_X6_BK0 == 16  // (lab builds with 32 k per barrier pair: the plane operand is written for three pieces per thread)
+    if (ragged && sc.bm == 128) launch_split6_planes<128, 0, true>(p, nwg, s);
+    else if (sc.bm == 128) launch_split6_planes<128, 0>(p, nwg, s);
+    else
+#else
+    if (sc.bm == 128) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: no 128 x 128 plane kernel in this build");
+#endif
     if (ragged) {
-      if (sc.bm == 128) launch_split6_planes<128, 0, true>(p, nwg, s);
-      else if (k32) launch_split6_planes<64, 2, true>(p, nwg, s);
+      if (k32) launch_split6_planes<64, 2, true>(p, nwg, s);
       else launch_split6_planes<64, 1, true>(p, nwg, s);
-    } else if (sc.bm == 128) {
-      launch_split6_planes<128, 0>(p, nwg, s);
     } else {
       if (k32) launch_split6_planes<64, 2>(p, nwg, s);
       else launch_split6_planes<64, 1>(p, nwg, s);

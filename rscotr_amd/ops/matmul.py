@@ -334,7 +334,7 @@ class _DeferredCombine:
                 if x6 != variant:
                     continue
                 sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4, 6) else 1))))
-                kq = 32 if x6 == 3 else 16
+                kq = 32 if x6 == 3 else int(os.environ.get('RSCOTR_X6_BK0', 16))  # (lab: the one-stage loop at 32 k per barrier pair)
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
                 if sp == 1:
