@@ -1503,7 +1503,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   Split6Cfg c{0, 1, p.K};
   static const int on = getenv("RSCOTR_BF16X6") ? atoi(getenv("RSCOTR_BF16X6")) : 1;
   static const long t128_min = getenv("RSCOTR_BF16X6_T128") ? atol(getenv("RSCOTR_BF16X6_T128")) : 512;
-  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 512;  // (round 4: 256 measures -0.3 ms per round on mtl512 (192 and 128 lose 0.7) but re-routes the 2500-row stage-4 products of the 800 x 800 det step, whose parity run then lands on another side of its near-tie decisions: kept at 512)
+  static const long t64_min = getenv("RSCOTR_BF16X6_T64") ? atol(getenv("RSCOTR_BF16X6_T64")) : 256;  // (round 4: 256 measures -0.3 ms per round on mtl512 against 512 — Swin stage-2 / -4 products move to the split product, flop share 0.85 -> 0.90; 384: -0.2; 192 and 128 lose 0.7.  It also re-routes the 2500-row stage-4 products of the 800 x 800 det step: that parity run passes with its tensors outside the 1e-3 tier explained by the fp64 anchor)
   static const long dw_t128_min = getenv("RSCOTR_BF16X6_DW_T128") ? atol(getenv("RSCOTR_BF16X6_DW_T128")) : 24;
   static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
   static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;

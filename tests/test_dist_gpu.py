@@ -97,7 +97,10 @@ def test_capture_fallback_keeps_the_step_counts(cuda):
     for k, v in want['losses'].items():
         if not k.startswith('seg.'):
             continue  # (the second capture attempt consumes more draws of the Mixup / CutMix and denoising-noise streams)
-        assert abs(got['losses'][k] - v) <= 2e-3 * max(abs(v), 1e-3), (k, got['losses'][k], v)
+        # (the seg loss after three rounds feels the other two tasks' different draws through the shared weights: 1.3e-3 with the
+        # round-3 GEMM routing, 2.9e-3 with round 4's (64 x 64 split tiles from 256 tiles on); a step count off by one moves it by
+        # percent)
+        assert abs(got['losses'][k] - v) <= 6e-3 * max(abs(v), 1e-3), (k, got['losses'][k], v)
 
 
 _CHILD2 = r'''

@@ -412,7 +412,7 @@ def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
                               resid=resid.to(cuda))
         err[mode] = _rel(outs[mode], ref)
     # the shapes the dispatch rules of csrc/gemm.hip (choose_split6) send to the split product must really take it
-    routed = (M, N, K, ak, bk) in {(10880, 2048, 256, 0, 0), (10880, 256, 2048, 0, 1), (2048, 1536, 384, 0, 0),
+    routed = (M, N, K, ak, bk) in {(10880, 2048, 256, 0, 0), (10880, 256, 2048, 0, 1), (2048, 1536, 384, 0, 0), (8192, 192, 768, 0, 1),
                                    (256, 2048, 10880, 1, 1), (384, 1536, 2048, 1, 1), (4096, 4096, 4096, 0, 0),
                                    (1000, 768, 3072, 0, 0), (53176, 256, 256, 0, 0), (53176, 256, 256, 0, 1),
                                    (256, 2048, 53176, 1, 1), (32768, 96, 384, 0, 0), (2000, 1024, 512, 1, 0),
