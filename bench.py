@@ -418,6 +418,17 @@ def main():
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
                             '2500/3 (bf16x3)')
+        # the fused attention core (csrc/attn_core.hip) reports through the GEMM kind: its own two lines, fp32 matrix pipe
+        def attn(name):
+            d = gg.get(name)
+            if not d:
+                return None
+            ach = d[0] / d[1] / 1e12
+            return dict(bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TF, traffic=None,
+                        kernel=name, launches_sampled=d[2], avg_us=d[1] / d[2] * 1e6, flops_per_launch=d[0] / d[2],
+                        note='algorithmic flops (4 Lq Lk 32 per image and head forward, 10 backward; the backward recomputes the '
+                             'scores in both of its passes: 14 issued), v_mfma_f32_32x32x2_f32, all decoder shapes of the round mixed')
+        r_af, r_ab = attn('rscotr::attn_fwd_kernel'), attn('rscotr::attn_bwd (dq + dkv kernels)')
         r_f = hbm('msda_fwd', 'rscotr::msda_fwd_kernel<32, 4>')
         r_b = hbm('msda_bwd', 'rscotr_msda_bwd (sample + tile + combine kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
@@ -450,6 +461,7 @@ def main():
                                          if dist.is_initialized() else None),
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
+                   roofline_attn_fwd=r_af, roofline_attn_bwd=r_ab,
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)

@@ -593,6 +593,8 @@ extern "C" int rscotr_attn_core_fwd(const float* q, const float* k, const float*
   const int nqb = (Lq + 31) / 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(nqb * G.nch, B * heads);
+  // (launch-site profiler, bench.py: a matrix-pipe kernel like the GEMMs — 2 products of 2 Lq Lk 32 flop per (image, head))
+  ProfScope prof(PROF_GEMM, 4.0 * B * heads * (double)Lq * Lk * 32, s, "rscotr::attn_fwd_kernel");
   if (G.nch == 1) {
     attn_fwd_kernel<false, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, lse, nullptr, G);
   } else {
@@ -626,6 +628,8 @@ extern "C" int rscotr_attn_core_bwd(const float* q, const float* k, const float*
   float* dsum = static_cast<float*>(workspace);
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((int64_t)B * heads * Lq * 4 + 255) / 256 * 256);
   const dim3 grid(nqb * G.nch, B * heads);
+  // (five gradient products + the two recomputed in each pass: 14 Lq Lk 32 flop issued per (image, head), 10 of them algorithmic)
+  ProfScope prof(PROF_GEMM, 10.0 * B * heads * (double)Lq * Lk * 32, s, "rscotr::attn_bwd (dq + dkv kernels)");
   if (G.nch == 1) {
     attn_bwd_dq_kernel<false, ATTN_NW><<<grid, 64 * ATTN_NW, 0, s>>>(q, k, v, mask, out, dout, lse, dsum, dq, nullptr, G);
   } else {

@@ -1,2 +1,5 @@
-python -m pytest tests/test_gemm_gpu.py tests/test_dist_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | cut -c1-300
-bash scripts/gpu_ab_bench.sh ab_knobs3 "" "RSCOTR_BF16X6_T128=384" "RSCOTR_BF16X6_T128=256" "RSCOTR_BF16X6_KMIN=128" "RSCOTR_BF16X6_KMIN=96" "RSCOTR_DW_GROUP_WGS=3072" "RSCOTR_DW_GROUP_WGS=6144" ""
+bash scripts/gpu_suite.sh r4s6 > /dev/null 2>&1
+tail -2 gpurun_out/r4s6/pytest.log | cut -c1-200; cat gpurun_out/r4s6/bench.json | cut -c1-200
+bash scripts/gpu_prof_graph.sh r4d
+bash scripts/gpu_prof_bench.sh r4d | cut -c1-200
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
