@@ -1508,6 +1508,8 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   static const int k_min = getenv("RSCOTR_BF16X6_KMIN") ? atoi(getenv("RSCOTR_BF16X6_KMIN")) : 192;
   static const int mid_split = getenv("RSCOTR_BF16X6_MIDSPLIT") ? atoi(getenv("RSCOTR_BF16X6_MIDSPLIT")) : 1;
   static const int gelu_ok = getenv("RSCOTR_BF16X6_GELU") ? atoi(getenv("RSCOTR_BF16X6_GELU")) : 1;
+  static const long mid_t64 = getenv("RSCOTR_BF16X6_MID_T64") ? atol(getenv("RSCOTR_BF16X6_MID_T64")) : 96;  // (round 4: 96 takes the 512-row Swin stage-4 products with K >= 2304 (96 tiles, 6 k-slices): -0.25 ms per round against 128)
+  static const int mid_k = getenv("RSCOTR_BF16X6_MID_K") ? atoi(getenv("RSCOTR_BF16X6_MID_K")) : 1024;
   static const int dw_ok = getenv("RSCOTR_BF16X6_DW") ? atoi(getenv("RSCOTR_BF16X6_DW")) : 1;
   // Measured on the step (profiles/r2_gemm_census.txt against profiles/history/r1_s7_gemm_census_fp32.txt): the split
   // product wins where the MFMA work dominates — the encoder FFN products (117 -> 85 us, 125 -> 100 us), their weight
@@ -1544,7 +1546,7 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   if (p.kscale) return c;
   if (fit128 && t128 >= t128_min) c.bm = 128;
   else if (t64 >= t64_min && p.K <= 4096) c.bm = 64;
-  else if (mid_split && t64 >= 128 && p.K >= 1024) {
+  else if (mid_split && t64 >= mid_t64 && p.K >= mid_k) {
     // mid-size outputs with a long reduction (Swin stage 3: 2048 x 384 x 1536): too few 64 x 64 tiles for the chip, so the
     // reduction is cut into k-slices whose slabs the combine launch sums and runs the epilogue on
     long sp = std::min<long>((512 + t64 - 1) / t64, p.K / 256);

@@ -1,5 +1,2 @@
-bash scripts/gpu_suite.sh r4s6 > /dev/null 2>&1
-tail -2 gpurun_out/r4s6/pytest.log | cut -c1-200; cat gpurun_out/r4s6/bench.json | cut -c1-200
-bash scripts/gpu_prof_graph.sh r4d
-bash scripts/gpu_prof_bench.sh r4d | cut -c1-200
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+python -m pytest tests/test_dist_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | cut -c1-300
+bash scripts/gpu_ab_bench.sh ab_knobs4 "" "RSCOTR_GEMM_SMALL_TILES=1024" "RSCOTR_GEMM_SMALL_K=768" "RSCOTR_GEMM_KG4_MAX=384" "RSCOTR_GEMM_KG2_MAX=1024" "RSCOTR_BF16X6_T128=768" "RSCOTR_GEMM_SPLIT_TARGET=768" "RSCOTR_GEMM_SPLIT_TARGET=384" ""
