@@ -910,7 +910,10 @@ struct MsdaTileGeom {
   static constexpr int TB = D >= 32 ? 2 : 1;
   static constexpr int CH = D / TB;
   static constexpr int V = CH / 4;                 // float4 per thread and row
-  static constexpr int U = CH <= 16 ? 4 : 2;       // samples in flight per thread in the walk
+#ifndef MSDA_T_U16
+#define MSDA_T_U16 3  // (4 spilled 17 registers under the 168-register cap of three wavefronts per SIMD once the walk took balanced work items: +21 MiB of scratch writes per launch, encoder call 85 -> 78 us in the lab with 3)
+#endif
+  static constexpr int U = CH <= 16 ? MSDA_T_U16 : 2;  // samples in flight per thread in the walk
   static constexpr int TSY = 256 / TB / MSDA_T_TS;  // bins per tile along y
   static constexpr int NBIN = MSDA_T_TS * TSY;
   static constexpr int NCELL = MSDA_T_CW * (TSY + 1);

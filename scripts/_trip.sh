@@ -1,2 +1,3 @@
-python -m pytest tests/test_dist_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | cut -c1-300
-bash scripts/gpu_ab_bench.sh ab_knobs4 "" "RSCOTR_GEMM_SMALL_TILES=1024" "RSCOTR_GEMM_SMALL_K=768" "RSCOTR_GEMM_KG4_MAX=384" "RSCOTR_GEMM_KG2_MAX=1024" "RSCOTR_BF16X6_T128=768" "RSCOTR_GEMM_SPLIT_TARGET=768" "RSCOTR_GEMM_SPLIT_TARGET=384" ""
+python -m pytest tests/test_msda_gpu.py tests/test_golden_gpu.py tests/test_determinism_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -2 | cut -c1-200
+bash scripts/gpu_ab_bench.sh ab_u3 ""
+bash scripts/gpu_pmc.sh r4f > /dev/null 2>&1; ls gpurun_out/r4f_pmc_*csv
