@@ -20,6 +20,11 @@
 //     has an order fixed by the shapes alone.
 //   * backward recomputes the probabilities from the saved log-sum-exp of every row (B * heads * Lq floats) instead of
 //     reading a stored P.
+//   * scores live in log2 units (log2(e) rides in the scale of q: v_exp_f32 is 2^x); a tile whose 32 x 32 mask block is all
+//     True is skipped without a product (the DINO decoder's denoising groups against the matching queries, regions outside a
+//     predicted mask), a tile without any True bit runs without mask arithmetic; interior tiles address their operands from
+//     wave-uniform bases (no clamps).  With few query tiles against many keys (seg cross-attention) the key-side pass gives
+//     every wavefront a key block of its own and walks all queries: nothing to combine.
 // Mask: bool, True = blocked, indexed by mask_mode as in attn.hip (0 none, 1 (Lq, Lk), 2 (B, Lq, Lk), 3 (B * heads, Lq, Lk)); a
 // fully blocked row gives zeros (never produced on this path), as rscotr_softmax_mask_fwd.
 #include "common.h"
