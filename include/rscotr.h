@@ -189,6 +189,26 @@ int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
                     float* pre, const float* resid, int accumulate, float* rowsum, int rowsum_accumulate,
                     const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
                     float* out2, float* workspace, int64_t workspace_bytes, void* stream);
+/* The same product with the VALUE RANGES of its operands (round 5).  amax_a / amax_b: device words holding the bit pattern of
+ * max |x| over (a superset of) each operand — written by rscotr_amax_f32, by the epilogue of the product that made the tensor
+ * (amax_out of that call), by the optimizer for parameters.  With both given, the products that precision mode 3 routes to
+ * the split kernels run as the FP16 SPLIT PRODUCT "h3" instead: x 2^s = h + l 2^-11 with h = rne_f16(x 2^s),
+ * l = rne_f16((x 2^s - h) 2^11), s from the operand's amax so that the scaled amax lies in [2^12, 2^13); three
+ * v_mfma_f32_32x32x16_f16 per 16 k (h h into one accumulator set, l h + h l into a second that enters with 2^-11), fp32
+ * accumulate.  The two planes carry an element to 2^-24 relative down to 2^-26 of the tensor's amax (2^-48 of amax absolute
+ * below): the error class of an fp32 FMA chain, like the six-term bf16 product, at half the MFMA issues and two thirds of
+ * the conversion / LDS traffic.  Everything else (tiles, k-slices, epilogue, row sums, k scaling, workspace) is
+ * rscotr_gemm_f32; null ranges = exactly rscotr_gemm_f32.  rscotr_gemm_set_h3(0 | 1): A/B switch (RSCOTR_GEMM_H3),
+ * returns the previous setting.  amax_out (optional): max |C| of the stored result is folded into this word (atomicMax on
+ * the bit pattern; the caller zeroes it).  rscotr_amax_f32: slot = max(slot, max |X|) over rows x cols, row stride ld. */
+int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                      int ldc, int a_kmajor, int b_kmajor, const float* bias, int act, const float* aux,
+                      float* pre, const float* resid, int accumulate, float* rowsum, int rowsum_accumulate,
+                      const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
+                      float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
+                      const uint32_t* amax_b, uint32_t* amax_out, void* stream);
+int rscotr_gemm_set_h3(int on);
+int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* slot, void* stream);
 /* Deferred split-K combine for weight gradients.  rscotr_gemm_f32_dw_slabs = rscotr_gemm_f32(a_kmajor = b_kmajor = 1,
  * accumulate = 1, rowsum_accumulate = 1) WITHOUT its combine launch: the slabs stay in `slab_region` (caller-owned until
  * the flush; rscotr_gemm_f32_workspace() bytes), *splits_out (HOST int) = number of slabs written ([splits][M][N] floats,

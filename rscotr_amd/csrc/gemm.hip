@@ -782,8 +782,39 @@ __device__ __forceinline__ void split_rows4(const float4& e, const float4& o, ui
   }
 }
 
-template <int R, bool KM, int NPL, int SBK = 16>
+// ---- fp16 split product ("h3", round 5): x 2^s = h + l 2^-11 with h = rne_f16(x 2^s), l = rne_f16((x 2^s - h) 2^11).  The
+// subtraction is exact in fp32 and |x 2^s - h| <= 2^-12 |x 2^s|, so l keeps 11 of the remaining 13 bits: the two planes
+// carry x to 2^-24 relative (the rounding class of fp32 itself) wherever fp16 is normal, i.e. down to 2^-26 of the tensor's
+// amax with the scale of h3_scale_exp; below that the error is 2^-48 of amax absolute.  The product keeps three terms,
+// h h into one accumulator and l h + h l into a second one that enters with 2^-11 at the end (fp32 accumulate; the dropped
+// l l term is <= 2^-24 |a||b|): THREE v_mfma_f32_32x32x16_f16 per 16 k instead of six bf16 ones, two planes instead of three
+// through the conversion and LDS.  7 VALU instructions per value pair (pk_mul, cvt_pk, 2 cvt, pk_mul, pk_fma, cvt_pk).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct H3Scale {
+  float sc, sc2;  // 2^s, 2^(s + 11)
+};
+__device__ __forceinline__ void split_pair_h(float a, float b, const H3Scale& k, unsigned (&out)[3]) {
+  const f32x2_t x = {a, b};
+  const f32x2_t y = x * k.sc, y2 = x * k.sc2;
+  const f16x2_t h = __builtin_convertvector(y, f16x2_t);
+  out[0] = __builtin_bit_cast(unsigned, h);
+  const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, y2.x), __builtin_fmaf((float)h.y, -2048.f, y2.y)};
+  out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ void split_rows4_h(const float4& e, const float4& o, const H3Scale& k, uint4 (&out)[3]) {
+  unsigned a[3], b[3], c[3], d[3];
+  split_pair_h(e.x, o.x, k, a);
+  split_pair_h(e.y, o.y, k, b);
+  split_pair_h(e.z, o.z, k, c);
+  split_pair_h(e.w, o.w, k, d);
+  out[0] = make_uint4(a[0], b[0], c[0], d[0]);
+  out[1] = make_uint4(a[1], b[1], c[1], d[1]);
+}
+
+template <int R, bool KM, int NPL, int SBK = 16, bool H16 = false>
 struct SplitOperand {
+  static_assert(!H16 || NPL == 2, "the fp16 split has two planes");
   static constexpr int LDR = SBK * NPL + 8;                         // bf16 per LDS row (row-major source): 112 / 208 bytes
   static constexpr int KP = SBK / 2;                                // k pairs per stage
   static constexpr int Q = SBK / 4;                                 // float4 per row per stage (row-major source)
@@ -848,7 +879,7 @@ struct SplitOperand {
         a.z = fmaf(f, v[i].z + w[i].z, a.z); a.w = fmaf(f, v[i].w + w[i].w, a.w);
       }
   }
-  __device__ __forceinline__ void store(unsigned* S, int tid) const {
+  __device__ __forceinline__ void store(unsigned* S, int tid, const H3Scale& hs = H3Scale{1.f, 2048.f}) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
@@ -856,8 +887,13 @@ struct SplitOperand {
         if (!KM) {
           const int row = idx / Q, kq = (idx % Q) * 4;
           unsigned ab[3], cd[3];
-          split_pair<NPL>(v[i].x, v[i].y, ab);
-          split_pair<NPL>(v[i].z, v[i].w, cd);
+          if constexpr (H16) {
+            split_pair_h(v[i].x, v[i].y, hs, ab);
+            split_pair_h(v[i].z, v[i].w, hs, cd);
+          } else {
+            split_pair<NPL>(v[i].x, v[i].y, ab);
+            split_pair<NPL>(v[i].z, v[i].w, cd);
+          }
           unsigned* dst = S + (row * LDR + kq) / 2;
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) {
@@ -871,7 +907,8 @@ struct SplitOperand {
           // (even k, odd k) pairs of the four rows: the conversions take one value of each row vector (v_cvt_pk_bf16_f32 has
           // two independent sources), the exact subtractions run on the rows' own register pairs (v_pk_add_f32)
           uint4 q[3];
-          split_rows4<NPL>(v[i], w[i], q);
+          if constexpr (H16) split_rows4_h(v[i], w[i], hs, q);
+          else split_rows4<NPL>(v[i], w[i], q);
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(S + (pl * KP + kp) * R + r4) = q[pl];
         }
@@ -936,7 +973,7 @@ struct PlaneOperand {
     if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) v1 = piece_load<EDGE>(pl, ld, row0, k0, tid + 256, klim);
     if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) v2 = piece_load<EDGE>(pl, ld, row0, k0, tid + 512, klim);
   }
-  __device__ __forceinline__ void store(unsigned* S, int tid) const {
+  __device__ __forceinline__ void store(unsigned* S, int tid, const H3Scale& = H3Scale{1.f, 2048.f}) const {
     piece_store(S, tid, v0);
     if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) piece_store(S, tid + 256, v1);
     if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) piece_store(S, tid + 512, v2);
@@ -962,25 +999,43 @@ template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : PIPE == 
 #ifndef RSCOTR_X6_D2
 #define RSCOTR_X6_D2 2
 #endif
+#ifndef RSCOTR_H3_VPM
+#define RSCOTR_H3_VPM 8
+#endif
+#ifndef RSCOTR_H3_DPM
+#define RSCOTR_H3_DPM 2
+#endif
 template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? RSCOTR_X6_D2 : PIPE == 3 ? 3 : 1; }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool BPL = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool BPL = false, bool H16 = false>
 constexpr int bf16x6_lds_words() {
+  constexpr int NPL = H16 ? 2 : 3;
   if constexpr (BPL)
     return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + PlaneOperand<BN, bf16x6_bk<PIPE>()>::WORDS);
   else
-    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + SplitOperand<BN, BKM, 3, bf16x6_bk<PIPE>()>::WORDS);
+    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS + SplitOperand<BN, BKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS);
 }
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
 // BPL: p.B / p.ldb = the pre-split plane set of B and its row count (PlaneOperand above; BKM is then irrelevant)
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool BPL = false>
+// H16: the fp16 split product (split_pair_h above): operands scaled by powers of two from p.amax_a / p.amax_b (both
+// required), three MFMAs per 16 k into two accumulator sets.
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool BPL = false, bool H16 = false>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
-  constexpr int NPL = 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
+  static_assert(!(H16 && BPL), "pre-split planes are bf16");
+  constexpr int NPL = H16 ? 2 : 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
-  using OA = SplitOperand<BM, AKM, NPL, SBK>;
-  using OB = std::conditional_t<BPL, PlaneOperand<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK>>;
+  using OA = SplitOperand<BM, AKM, NPL, SBK, H16>;
+  using OB = std::conditional_t<BPL, PlaneOperand<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK, H16>>;
+  H3Scale ha{1.f, 2048.f}, hb{1.f, 2048.f};
+  float inva = 1.f, invb = 1.f;
+  if constexpr (H16) {
+    const int ea = h3_scale_exp(*p.amax_a), eb = h3_scale_exp(*p.amax_b);
+    ha.sc = __uint_as_float((unsigned)ea << 23); ha.sc2 = __uint_as_float((unsigned)(ea + 11) << 23);
+    hb.sc = __uint_as_float((unsigned)eb << 23); hb.sc2 = __uint_as_float((unsigned)(eb + 11) << 23);
+    inva = __uint_as_float((unsigned)(254 - ea) << 23); invb = __uint_as_float((unsigned)(254 - eb) << 23);
+  }
   constexpr int NBUF = PIPE ? 2 : 1;
   unsigned* sA[2] = {lds, lds + (NBUF - 1) * OA::WORDS};
   unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
@@ -1007,12 +1062,16 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   const int klast = EDGE ? p.K - 1 : 0x7ffffffe;
 
   f32x16 acc[MT][NT];
+  f32x16 acc2[H16 ? MT : 1][H16 ? NT : 1];  // (fp16 split: the l h + h l terms, scaled by 2^11)
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (H16) acc2[i][j][r] = 0.f;
+      }
   OA las[D];
   OB lbs[D];
   OA& la = las[0];
@@ -1027,8 +1086,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   };
   auto stage = [&](unsigned* a_s, unsigned* b_s) {
     if (AKM && do_rs) la.accum(rs, tid);
-    la.store(a_s, tid);
-    lb.store(b_s, tid);
+    la.store(a_s, tid, ha);
+    lb.store(b_s, tid, hb);
   };
   auto mma = [&](const unsigned* a_s, const unsigned* b_s) {
 #pragma unroll
@@ -1038,6 +1097,20 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       for (int i = 0; i < MT; ++i) OA::frag(a_s, wm * (BM / 2) + i * 32 + fr, g, ks, af[i]);
 #pragma unroll
       for (int j = 0; j < NT; ++j) OB::frag(b_s, wn * (BN / 2) + j * 32 + fr, g, ks, bf[j]);
+      if constexpr (H16) {
+        // l h, h l into the second accumulator set, h h into the first; term-major as below
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const f16x8 a = __builtin_bit_cast(f16x8, af[i][tm == 0 ? 1 : 0]), b = __builtin_bit_cast(f16x8, bf[j][tm == 1 ? 1 : 0]);
+              if (tm < 2) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+            }
+        continue;
+      }
       // small terms first; term-major over the MT x NT accumulators (same sums, bit for bit): consecutive MFMAs write
       // DIFFERENT accumulators, so none waits for its predecessor's result (six back-to-back MFMAs on one accumulator are a
       // dependent chain: RSCOTR_X6_CHAIN below restores that order for A/B builds)
@@ -1065,7 +1138,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     // Steady state without branches inside a step (the scheduler interleaves within one basic block): loads past the end
     // re-read the last tile, the last step stages it a second time into the idle LDS stage (its row sums times 0).
     constexpr int U = (D % 2 == 0) ? D : 2 * D;  // steps per unrolled round: register set and LDS stage indices static
-    constexpr int NMFMA = MT * NT * 6 * (SBK / 16);
+    constexpr int NMFMA = MT * NT * (H16 ? 3 : 6) * (SBK / 16);
+    constexpr int VPM = H16 ? RSCOTR_H3_VPM : 4, DPM = H16 ? RSCOTR_H3_DPM : 1;  // VALU / DS writes the scheduler places behind each MFMA
     // per-sample k scaling of a k-major A (weight gradients under DropPath / Mixup): always applied, so that a step stays
     // one basic block — without a scale vector every k reads the constant 1
     const float* ksp = (AKM && p.kscale) ? p.kscale : &bf16x6_one;
@@ -1078,8 +1152,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     }
     if (AKM) las[0].scale_k(ksp, ksper, kbeg, tid, klast);
     if (AKM) las[0].accum(rs, tid);
-    las[0].store(sA[0], tid);
-    lbs[0].store(sB[0], tid);
+    las[0].store(sA[0], tid, ha);
+    lbs[0].store(sB[0], tid, hb);
     __syncthreads();
     for (int t0 = 0; t0 < nk; t0 += U) {
 #pragma unroll
@@ -1094,13 +1168,13 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
           mma(sA[s & 1], sB[s & 1]);
           if (AKM) las[(s + 1) % D].scale_k(ksp, ksper, kbeg + min(t + 1, nk - 1) * SBK, tid, klast);
           if (AKM) las[(s + 1) % D].accum(rs, tid, t + 1 < nk ? 1.f : 0.f);
-          las[(s + 1) % D].store(sA[(s + 1) & 1], tid);
-          lbs[(s + 1) % D].store(sB[(s + 1) & 1], tid);
+          las[(s + 1) % D].store(sA[(s + 1) & 1], tid, ha);
+          lbs[(s + 1) % D].store(sB[(s + 1) & 1], tid, hb);
 #pragma unroll
           for (int i = 0; i < NMFMA; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, DPM, 0);  // DS write
           }
           __syncthreads();
         }
@@ -1150,6 +1224,14 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     }
   }
 
+  if constexpr (H16) {  // C = (hh + (lh + hl) 2^-11) 2^-(sa + sb)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc2[i][j][r], 0x1p-11f, acc[i][j][r]) * inva * invb;
+  }
   if (p.splits > 1 || SLAB) {
     float* slab = p.slabs + (long)split * p.M * p.N;
 #pragma unroll
@@ -1196,6 +1278,19 @@ template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, bool 
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, BPL>()];
   gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, BPL>(p, blockIdx.x, gridDim.x, lds);
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
+__global__ __launch_bounds__(256) void gemm_h3_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, false, true>()];
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, false, true>(p, blockIdx.x, gridDim.x, lds);
+}
+// 128 x 128 tiles: two accumulator sets are 128 registers; held to two wavefronts per SIMD (256 registers in all) so that
+// two workgroups per CU cover each other's staging phases in the one-stage loop
+template <bool AKM, bool BKM, bool EDGE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_h3_128_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<128, 128, AKM, BKM, 0, false, true>()];
+  gemm_bf16x6_body<128, 128, AKM, BKM, 0, false, EDGE, false, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1569,6 +1664,21 @@ static void launch_split6(const GemmParams& p, int a_kmajor, int b_kmajor, unsig
   else if (!a_kmajor) gemm_bf16x6_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
   else if (!b_kmajor) gemm_bf16x6_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
   else gemm_bf16x6_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+}
+
+template <int BM, int PIPE, bool EDGE = false>
+static void launch_h3(const GemmParams& p, int a_kmajor, int b_kmajor, unsigned nwg, hipStream_t s) {
+  if constexpr (BM == 128 && PIPE == 0) {
+    if (!a_kmajor && !b_kmajor) gemm_h3_128_kernel<false, false, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (!a_kmajor) gemm_h3_128_kernel<false, true, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (!b_kmajor) gemm_h3_128_kernel<true, false, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else gemm_h3_128_kernel<true, true, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    return;
+  }
+  if (!a_kmajor && !b_kmajor) gemm_h3_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!a_kmajor) gemm_h3_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else if (!b_kmajor) gemm_h3_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+  else gemm_h3_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2220,12 +2330,50 @@ extern "C" int64_t rscotr_gemm_f32_workspace(int M, int N, int K) {
   return sp * ((int64_t)M * N + M) * 4;
 }
 
+static std::atomic<int> g_h3_on{[] {
+  const char* e = getenv("RSCOTR_GEMM_H3");
+  return e ? atoi(e) : 1;
+}()};
+extern "C" int rscotr_gemm_set_h3(int on) { return g_h3_on.exchange(on ? 1 : 0); }
+
+static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda,
+                         int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
+                         const float* aux, float* pre, const float* resid, int accumulate,
+                         float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
+                         const float* kscale, int krows_per_scale, float* out2, float* workspace,
+                         int64_t workspace_bytes, void* stream, const uint32_t* amax_a, const uint32_t* amax_b,
+                         uint32_t* amax_out);
+
 extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda,
                                int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
                                const float* aux, float* pre, const float* resid, int accumulate,
                                float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
                                const float* kscale, int krows_per_scale, float* out2, float* workspace,
                                int64_t workspace_bytes, void* stream) {
+  return gemm_f32_impl(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, act, aux, pre, resid, accumulate, rowsum,
+                       rowsum_accumulate, rowscale, rows_per_scale, kscale, krows_per_scale, out2, workspace, workspace_bytes,
+                       stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, int K, int lda,
+                                 int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
+                                 const float* aux, float* pre, const float* resid, int accumulate,
+                                 float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
+                                 const float* kscale, int krows_per_scale, float* out2, float* workspace,
+                                 int64_t workspace_bytes, const uint32_t* amax_a, const uint32_t* amax_b, uint32_t* amax_out,
+                                 void* stream) {
+  return gemm_f32_impl(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, act, aux, pre, resid, accumulate, rowsum,
+                       rowsum_accumulate, rowscale, rows_per_scale, kscale, krows_per_scale, out2, workspace, workspace_bytes,
+                       stream, amax_a, amax_b, amax_out);
+}
+
+static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda,
+                         int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
+                         const float* aux, float* pre, const float* resid, int accumulate,
+                         float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
+                         const float* kscale, int krows_per_scale, float* out2, float* workspace,
+                         int64_t workspace_bytes, void* stream, const uint32_t* amax_a, const uint32_t* amax_b,
+                         uint32_t* amax_out) {
   if (M < 0 || N < 0 || K < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: negative dimension");
   if ((rowscale && rows_per_scale <= 0) || (kscale && (krows_per_scale <= 0 || !a_kmajor)))
     return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: rowscale needs rows_per_scale > 0; kscale needs a k-major A and krows_per_scale > 0");
@@ -2291,13 +2439,26 @@ extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, 
       p.slabs = sc.splits > 1 ? workspace : nullptr;
       p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
       static const bool prof_shapes_6 = getenv("RSCOTR_PROF_SHAPES") != nullptr;
+      const bool h3 = amax_a && amax_b && g_h3_on.load(std::memory_order_relaxed);
+      p.amax_a = amax_a; p.amax_b = amax_b;
       char xname[112];
-      if (prof_shapes_6) snprintf(xname, sizeof(xname), "M=%d N=%d K=%d %d%d bf16x6-%d splits=%d", M, N, K, a_kmajor, b_kmajor, sc.bm, sc.splits);
-      else snprintf(xname, sizeof(xname), "rscotr::gemm_bf16x6_kernel<%d, %d, %s, %s, *>", sc.bm, sc.bm, a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
+      if (prof_shapes_6) snprintf(xname, sizeof(xname), "M=%d N=%d K=%d %d%d %s-%d splits=%d", M, N, K, a_kmajor, b_kmajor, h3 ? "h3" : "bf16x6", sc.bm, sc.splits);
+      else snprintf(xname, sizeof(xname), "rscotr::gemm_%s_kernel<%d, %d, %s, %s, *>", h3 ? "h3" : "bf16x6", sc.bm, sc.bm, a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
       ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", xname);
       const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
       static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;  // bit 0: 64 x 64 (measured -0.45 ms / round), bit 1: 128 x 128 (measured slower on every layout of the step: +0.65 ms)
-      if (ragged) {  // (EDGE instantiations: the 128 x 128 one-stage loop and the pipelined 64 x 64 loop)
+      if (h3) {  // the fp16 split product: same tiles, same loops
+        if (ragged) {
+          if (sc.bm == 128) launch_h3<128, 0, true>(p, a_kmajor, b_kmajor, nwg, s);
+          else if (sc.klen % 32 == 0) launch_h3<64, 2, true>(p, a_kmajor, b_kmajor, nwg, s);
+          else launch_h3<64, 1, true>(p, a_kmajor, b_kmajor, nwg, s);
+        } else if (sc.bm == 128) {
+          launch_h3<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
+        } else {
+          if ((pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0) launch_h3<64, 2>(p, a_kmajor, b_kmajor, nwg, s);
+          else launch_h3<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+        }
+      } else if (ragged) {  // (EDGE instantiations: the 128 x 128 one-stage loop and the pipelined 64 x 64 loop)
         if (sc.bm == 128) launch_split6<128, 0, true>(p, a_kmajor, b_kmajor, nwg, s);
         else if (sc.klen % 32 == 0) launch_split6<64, 2, true>(p, a_kmajor, b_kmajor, nwg, s);
         else launch_split6<64, 1, true>(p, a_kmajor, b_kmajor, nwg, s);
@@ -2779,4 +2940,53 @@ extern "C" int rscotr_colsum_f32(const float* X, float* out, int M, int N, int l
   colsum_partial_kernel<<<dim3((N + 255) / 256, gyu), 256, 0, s>>>(X, workspace, M, N, ld, rpb, vec);
   colsum_final_kernel<<<(N + 255) / 256, 256, 0, s>>>(workspace, out, gyu, N, accumulate);
   return check_launch("rscotr_colsum_f32");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Value range of a tensor for the fp16 split product: slot = max(slot, bit pattern of max |X[r, c]|) over rows x cols with
+// row stride ld.  The caller zeroes the slot (one memset for all slots of an iteration); the maximum is taken per lane,
+// per wavefront (shuffles), per workgroup (LDS) and then with ONE atomicMax on the bit pattern per workgroup — a maximum
+// does not depend on the order, so the result is deterministic.  NaNs compare above every finite pattern.
+namespace rscotr {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, long rows, int cols, int ld, int vec,
+                                                   unsigned* __restrict__ slot) {
+  __shared__ unsigned sm[4];
+  unsigned m = 0u;
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+  if (vec) {
+    const int c4 = cols >> 2;
+    const long n4 = rows * c4;
+    for (long i = tid; i < n4; i += nth) {
+      const long r = i / c4;
+      const int c = (int)(i - r * c4) << 2;
+      const uint4 v = *reinterpret_cast<const uint4*>(X + r * ld + c);
+      m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+  } else {
+    const long n = rows * cols;
+    for (long i = tid; i < n; i += nth) {
+      const long r = i / cols;
+      m = max(m, __float_as_uint(X[r * ld + (i - r * cols)]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (m) atomicMax(slot, m);
+  }
+}
+}  // namespace rscotr
+
+extern "C" int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* slot, void* stream) {
+  if (rows < 0 || cols < 0 || ld < cols) return rscotr::fail(RSCOTR_E_SHAPE, "rscotr_amax_f32: bad shape");
+  if (rows == 0 || cols == 0) return RSCOTR_OK;
+  if (!X || !slot) return rscotr::fail(RSCOTR_E_ARG, "rscotr_amax_f32: null pointer");
+  const int vec = rscotr::aligned16(X) && cols % 4 == 0 && ld % 4 == 0;
+  const long n = rows * (long)cols;
+  const unsigned grid = (unsigned)std::max<long>(1, std::min<long>(256, (n + 8191) / 8192));
+  rscotr::amax_kernel<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(X, rows, cols, ld, vec, slot);
+  return rscotr::check_launch("rscotr_amax_f32");
 }

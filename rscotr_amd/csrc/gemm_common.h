@@ -45,7 +45,24 @@ struct GemmParams {
   const float* rowscale;
   const float* kscale;
   int rows_per, krows_per;
+  // value ranges (round 5, the fp16 split product below): amax_a / amax_b -> the bit pattern of max |x| over (a superset
+  // of) the operand, written by whoever produced the tensor (rscotr_amax_f32, an epilogue, the optimizer); both non-null
+  // = the product may run on fp16 planes scaled by powers of two taken from them.  amax_out: the epilogue folds max |C|
+  // into this slot (atomicMax on the bit pattern: order-independent, hence deterministic).
+  const unsigned* amax_a = nullptr;
+  const unsigned* amax_b = nullptr;
+  unsigned* amax_out = nullptr;
 };
+
+// Power-of-two scale of an operand of the fp16 split product from the bit pattern of its amax: amax * 2^s lands in
+// [2^12, 2^13) — 8 x below fp16's largest finite value (per-sample k factors of DropPath / Mixup ride on top), 26 binades
+// above the point where the planes start to lose relative precision (then the error is 2^-36 absolute in the scaled
+// domain = 2^-48 of amax).  Returns the exponent field of 2^s, clamped so that 2^(s+11) and 2^-s are finite normals; a zero
+// tensor (amax 0) takes the clamp, which multiplies zeros.
+__device__ __forceinline__ int h3_scale_exp(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xffu);
+  return max(13, min(266 - e, 243));
+}
 
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));

@@ -629,7 +629,7 @@ _WS_PARTS = _PartsWS()
 
 def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=ACT_NONE, aux=None, pre=None,
          resid=None, accumulate=False, rowsum=None, rowsum_accumulate=False, rowscale=None, rows_per=0, kscale=None,
-         krows_per=0, out2=None):
+         krows_per=0, out2=None, amax_a=0, amax_b=0, amax_out=0):
     """C[m,n] = epilogue(sum_k Aop[m,k] Bop[n,k]) on the fp32 matrix cores (include/rscotr.h,
     rscotr_gemm_f32).  A, B, out are contiguous fp32 device tensors; out (M,N) is allocated here
     unless given.  `rowsum` (M,) (+)= sum_k Aop[m,k] (k-major A only: the bias gradient riding the dW
@@ -670,13 +670,13 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     args = (A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, int(a_kmajor), int(b_kmajor),
             _ptr(bias), int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowsum),
             int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), _ptr(out2), ws, nws,
-            _stream())
+            int(amax_a), int(amax_b), int(amax_out), _stream())
     if STATE.profile is None:
-        lib.call('rscotr_gemm_f32', *args)
+        lib.call('rscotr_gemm_f32_r', *args)
     else:
         with _Prof('gemm', 2 * M * N * K, gemm_kernel_name(M, N, K, a_kmajor, b_kmajor),
                    shape=(M, N, K, int(a_kmajor), int(b_kmajor))):
-            lib.call('rscotr_gemm_f32', *args)
+            lib.call('rscotr_gemm_f32_r', *args)
     return out
 
 
