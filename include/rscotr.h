@@ -197,10 +197,15 @@ int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
  * v_mfma_f32_32x32x16_f16 per 16 k (h h into one accumulator set, l h + h l into a second that enters with 2^-11), fp32
  * accumulate.  The two planes carry an element to 2^-24 relative down to 2^-26 of the tensor's amax (2^-48 of amax absolute
  * below): the error class of an fp32 FMA chain, like the six-term bf16 product, at half the MFMA issues and two thirds of
- * the conversion / LDS traffic.  Everything else (tiles, k-slices, epilogue, row sums, k scaling, workspace) is
+ * the conversion / LDS traffic.  A RANGE WORD is RSCOTR_RANGE_PLANES (32) sub-words at a stride of RSCOTR_RANGE_STRIDE (16384)
+ * words — the caller owns one buffer of [32][16384] uint32 and names a word by the address of its sub-word 0; the value is
+ * the maximum over the sub-words (producers spread their atomics over them: thousands of same-address atomics from the
+ * wavefronts of one product would take longer than the product).  Everything else (tiles, k-slices, epilogue, row sums, k scaling, workspace) is
  * rscotr_gemm_f32; null ranges = exactly rscotr_gemm_f32.  rscotr_gemm_set_h3(0 | 1): A/B switch (RSCOTR_GEMM_H3),
  * returns the previous setting.  amax_out (optional): max |C| of the stored result is folded into this word (atomicMax on
  * the bit pattern; the caller zeroes it).  rscotr_amax_f32: slot = max(slot, max |X|) over rows x cols, row stride ld. */
+#define RSCOTR_RANGE_PLANES 32
+#define RSCOTR_RANGE_STRIDE 16384
 int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                       int ldc, int a_kmajor, int b_kmajor, const float* bias, int act, const float* aux,
                       float* pre, const float* resid, int accumulate, float* rowsum, int rowsum_accumulate,
@@ -208,7 +213,14 @@ int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, in
                       float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
                       const uint32_t* amax_b, uint32_t* amax_out, void* stream);
 int rscotr_gemm_set_h3(int on);
+/* 1 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
+ * product once both value ranges are supplied: callers ask before they go looking for ranges. */
+int rscotr_gemm_f32_split_route(int M, int N, int K, int lda, int ldb, int a_kmajor, int b_kmajor, int act, int has_pre,
+                                int has_rowscale, int has_kscale, int64_t workspace_bytes);
 int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* slot, void* stream);
+/* rscotr_amax_f32 for n tensors in one launch: table = device (n, 6) int64 rows {X, rows, cols, ld, range word, first block};
+ * entry e is worked on by blocks [first_e, first_{e+1}) of the total_blocks workgroups (>= 1 each, ascending). */
+int rscotr_amax_group(const int64_t* table, int n, int total_blocks, void* stream);
 /* Deferred split-K combine for weight gradients.  rscotr_gemm_f32_dw_slabs = rscotr_gemm_f32(a_kmajor = b_kmajor = 1,
  * accumulate = 1, rowsum_accumulate = 1) WITHOUT its combine launch: the slabs stay in `slab_region` (caller-owned until
  * the flush; rscotr_gemm_f32_workspace() bytes), *splits_out (HOST int) = number of slabs written ([splits][M][N] floats,
@@ -221,6 +233,11 @@ int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* sl
 int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                              float* rowsum, const float* kscale, int krows_per_scale, float* slab_region,
                              int64_t slab_bytes, int32_t* splits_out, void* stream);
+/* ... with the value ranges of the operands (rscotr_gemm_f32_r): the fp16 split product where mode 3 takes the split kernels */
+int rscotr_gemm_f32_dw_slabs_r(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                               float* rowsum, const float* kscale, int krows_per_scale, float* slab_region,
+                               int64_t slab_bytes, int32_t* splits_out, const uint32_t* amax_a, const uint32_t* amax_b,
+                               void* stream);
 int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream);
 /* Grouped launch of deferred weight gradients: n problems dW_i = A_i^T B_i (both operands k-major) with small outputs run
  * as ONE launch on tiles x k-slices; every problem leaves `splits` slabs (+ row-sum partials when rs_slabs != 0) for
@@ -234,8 +251,11 @@ int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, voi
  * bundle taking the ids = x mod 8 — one problem per XCD, so that its operands enter one L2 once; total_wgs = the sum over
  * the bundles; flops = sum of 2 M N K over the problems (the table is device data: the caller states the launch's algorithmic
  * work for the launch-site profiler, rscotr_prof_*; 0 = not stated).  Replaces ~110 short launches per co-training round (torch autograd's per-Linear weight-gradient GEMMs behind
- * mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules). */
-int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops, void* stream);
+ * mmcv's FFN / MultiheadAttention / MultiScaleDeformableAttention modules).  variant 6: the bf16x6 product on 128 x 128
+ * tiles with edge handling (M, N, K multiples of 4); variant 7 (round 5): the fp16 split product (rscotr_gemm_f32_r) on the same
+ * tiles — table column 14 = (index of A's value-range word + 1) << 32 | index of B's + 1, both into `amax_base` (required). */
+int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops,
+                         const uint32_t* amax_base, void* stream);
 
 /* nb0 * nb1 independent products of one shape, problem (b0, b1) at element offsets b0*s?0 + b1*s?1 of A, B, C
  * (b0 = image, b1 = head: the per-head slices of (B, L, heads*32) tensors are addressed in place).  No bias /
@@ -289,9 +309,11 @@ int rscotr_colsum_f32(const float* X, float* out, int M, int N, int ld, int accu
  * or passes the gradient buffer to add into); dx/dweight/dbias may each be NULL; dx_add (M,C) or NULL is added to
  * dx on the way out (pre-norm blocks: the gradient of the residual branch that forks at the LayerNorm input --
  * mmdet SwinBlock `x = x + attn(norm1(x))`, swin.py of mmdet 2.25.1 -- instead of a separate element-wise add); a workspace of
- * rscotr_layernorm_bwd_workspace(M, C) bytes (16-byte aligned) holds per-workgroup partial sums. */
+ * rscotr_layernorm_bwd_workspace(M, C) bytes (16-byte aligned) holds per-workgroup partial sums.
+ * amax_out (all entries of the family; NULL = not wanted): value-range word (rscotr_gemm_f32_r) that receives max |y| (and
+ * |y2|) of a forward, max |dx| of a backward — the range of the operand the next Linear multiplies with. */
 int rscotr_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
-                         float* rstd, int M, int C, float eps, void* stream);
+                         float* rstd, int M, int C, float eps, uint32_t* amax_out, void* stream);
 /* ---- two-stage proposal selection of the DINO transformer (models/multi/bbox_head/transformer.py:226-241) ---------------
  * topk_idx (B, K) int64 = torch.topk(enc_cls.max(-1)[0], K, dim=1)[1] (descending scores; equal scores: lower index first —
  * torch leaves that order unspecified), topk_score (B, K, C) = gather(enc_cls), topk_unact (B, K, 4) = gather(enc_reg +
@@ -321,11 +343,12 @@ int rscotr_det_targets(const int32_t* q_for_gt, const int64_t* gt_lab, const flo
  * own launch instead of an element-wise add; y2 carries no gradient of its own (the attention's backward produces
  * d(query) and d(query_pos) from its projections). */
 int rscotr_layernorm_fwd_sum(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
-                             const float* add, int add_rows, float* y2, int M, int C, float eps, void* stream);
+                             const float* add, int add_rows, float* y2, int M, int C, float eps, uint32_t* amax_out,
+                             void* stream);
 int64_t rscotr_layernorm_bwd_workspace(int M, int C);
 int rscotr_layernorm_bwd(const float* dy, const float* x, const float* weight, const float* mean,
                          const float* rstd, float* dx, const float* dx_add, float* dweight, float* dbias, int M, int C,
-                         float* workspace, int64_t workspace_bytes, void* stream);
+                         float* workspace, int64_t workspace_bytes, uint32_t* amax_out, void* stream);
 
 /* mmcv PatchMerging's `nn.Unfold(kernel_size=2, stride=2)` (zero "corner" padding for odd H / W) followed by its
  * LayerNorm(4 Cin) (mmdet 2.25.1 SwinTransformer stages' `downsample`, cfg ...potsdam.py:9-25), one launch per direction:
@@ -336,11 +359,11 @@ int rscotr_layernorm_bwd(const float* dy, const float* x, const float* weight, c
  * (4 Cin each); fold = 0 leaves the per-workgroup partial rows in `workspace` for rscotr_layernorm_flush (table row
  * {workspace, dweight, dbias, workspace_bytes / (32 Cin), 4 Cin}). */
 int rscotr_patch_merge_norm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
-                                int B, int H, int W, int Cin, float eps, void* stream);
+                                int B, int H, int W, int Cin, float eps, uint32_t* amax_out, void* stream);
 int64_t rscotr_patch_merge_norm_bwd_workspace(int B, int H, int W, int Cin);
 int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, const float* weight, const float* mean, const float* rstd,
                                 float* dx, float* dweight, float* dbias, int B, int H, int W, int Cin, float* workspace,
-                                int64_t workspace_bytes, int fold, void* stream);
+                                int64_t workspace_bytes, int fold, uint32_t* amax_out, void* stream);
 
 /* Deferred parameter-gradient fold: rscotr_layernorm_bwd_partials = rscotr_layernorm_bwd without its second launch (the
  * per-workgroup partial rows stay in `part`, rscotr_layernorm_bwd_workspace() bytes, caller-owned until the flush);
@@ -349,7 +372,7 @@ int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, const float* we
  * 2C columns}.  Two rows with the same destination must go to different launches (the fold is a plain read-add-write). */
 int rscotr_layernorm_bwd_partials(const float* dy, const float* x, const float* weight, const float* mean,
                                   const float* rstd, float* dx, const float* dx_add, int M, int C, float* part, int64_t part_bytes,
-                                  void* stream);
+                                  uint32_t* amax_out, void* stream);
 int rscotr_layernorm_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream);
 
 
@@ -532,6 +555,32 @@ int rscotr_adamw_clip_step(float* param, const float* grad, float* exp_avg, floa
                            const int32_t* chunk_seg, const int64_t* chunk_off, const int32_t* chunk_len,
                            const float* seg_dyn, int nchunks, const float* sumsq, float max_norm,
                            float beta1, float beta2, float eps, void* stream);
+/* The same step keeping the VALUE RANGES of the parameters (round 5; consumed by rscotr_gemm_f32_r as amax_b of a weight
+ * operand): seg_amax[segment] = bit pattern of max |w| over the segment, refreshed for every live segment by the update
+ * itself (zeroed, then one atomicMax per chunk: order-independent, deterministic); other segments keep their word.
+ * rscotr_param_amax computes all nseg words from the arena (construction, checkpoint load, restore). */
+int rscotr_adamw_clip_step_r(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             const int32_t* chunk_seg, const int64_t* chunk_off, const int32_t* chunk_len,
+                             const float* seg_dyn, int nchunks, const float* sumsq, float max_norm,
+                             float beta1, float beta2, float eps, uint32_t* seg_amax, int nseg, void* stream);
+int rscotr_param_amax(const float* param, const int32_t* chunk_seg, const int64_t* chunk_off,
+                      const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, void* stream);
+
+/* ---- gradient exchange on RCCL, called directly ------------------------------------------------------------------------
+ * Replaces the bucket all-reduces of torch DDP / c10d ProcessGroupNCCL behind the reference's MMDistributedDataParallel
+ * (mtl/apis/train.py:37-46; launched from tools/train.py:173-182 `init_dist`) for the DATA path of the exchange: a bucket of
+ * the flat gradient arena is averaged in place by one ncclAllReduce(ncclFloat32, ncclAvg) on the stream the caller names —
+ * ordered against backward by the caller's own events (fork / join, also inside a hipGraph capture), with no watchdog thread
+ * polling events of a capturing stream (c10d's aborted the overlapped exchange in 2 of 8 runs: DESIGN.md section 6).  The
+ * control traffic (the unique id, plan hashes, agreements) stays with whatever process group the job has.  RCCL is resolved
+ * at run time from the instance already in the process (torch's) or librccl.so on the loader path.
+ * rscotr_comm_unique_id: 128 bytes, made by ONE rank and handed to all; rscotr_comm_init: collective, each rank with its
+ * device current; rscotr_comm_allreduce_avg: buf[0 .. count) = mean over the ranks, in place, on `stream` (capturable). */
+int rscotr_comm_available(void);
+int rscotr_comm_unique_id(void* id128);
+int rscotr_comm_init(const void* id128, int rank, int nranks, void** comm_out);
+int rscotr_comm_allreduce_avg(void* comm, float* buf, int64_t count, void* stream);
+int rscotr_comm_destroy(void* comm);
 
 /* ---- device-side input pipeline --------------------------------------------------------
  * One launch turns a batch of ragged decoded uint8 images into the collated network input: crop window ->

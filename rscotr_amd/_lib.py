@@ -11,6 +11,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSCOTR_LIB") or os.path.join(HERE, "librscotr.so")  # RSCOTR_LIB: A/B builds (scripts/)
 HEADER = os.path.join(HERE, "..", "include", "rscotr.h")
+_TRACE = os.environ.get('RSCOTR_TRACE_CALLS') == '1'
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
@@ -75,6 +76,9 @@ class _Lib:
 
     def call(self, name, *args):
         dll = self.load()
+        if _TRACE:  # RSCOTR_TRACE_CALLS=1 (with AMD_SERIALIZE_KERNEL=3): the last line on stderr names a faulting launch
+            import sys
+            print(f'[rscotr] {name}{args}', file=sys.stderr, flush=True)
         rc = getattr(dll, name)(*args)
         if rc != 0:
             msg = dll.rscotr_last_error()

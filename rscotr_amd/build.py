@@ -84,7 +84,7 @@ def build_library(force=False, verbose=True):
         if p.returncode != 0:
             os.remove(os.path.join(objdir, os.path.basename(src) + ".o.stamp"))
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     if verbose:
         print("[rscotr build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -71,4 +71,46 @@ __device__ __forceinline__ float group_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
+// A value-range WORD is kAmaxPlanes sub-words at stride kAmaxStride (the caller's buffer is [kAmaxPlanes][kAmaxStride] words;
+// include/rscotr.h): its value is the maximum of the sub-words.  Producers spread their atomics over the sub-words (a
+// wavefront takes sub-word (4 * workgroup + wavefront) % kAmaxPlanes; the planes are 64 KB apart: different memory channels),
+// consumers read all of them with one load per lane.
+constexpr int kAmaxPlanes = 32;
+constexpr int kAmaxStride = 16384;
+
+// (lane l holds sub-word l % kAmaxPlanes, loaded by the caller as early as it likes) -> the word's value, wave-uniform
+__device__ __forceinline__ unsigned amax_fold(unsigned v) {
+#pragma unroll
+  for (int o = kAmaxPlanes / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ unsigned amax_read(const unsigned* word) {
+  return amax_fold(word[(long)(threadIdx.x & (kAmaxPlanes - 1)) * kAmaxStride]);
+}
+
+// Same-address atomics execute one after the other at the memory side (~10 ns each: thousands of wavefronts finishing
+// together would cost more than a short product itself), so a wavefront first LOOKS at the word (a plain, possibly stale
+// read: staleness only costs an atomic that changes nothing) and stays silent unless it raises it — operands of one
+// tensor are of one magnitude, the first few finishers settle the word.
+__device__ __forceinline__ void amax_commit(unsigned* slot, float amx) {
+  if (!slot) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned b = __float_as_uint(amx);
+#ifdef RSCOTR_AMAX_BY_BLOCK
+    unsigned* sub = slot + (long)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxPlanes - 1)) * kAmaxStride;
+#else
+    // sub-word by (XCD, wavefront of the workgroup): a line is only ever touched by the atomics of ONE XCD's L2
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+    unsigned* sub = slot + (long)(((xcc & 7) * 4 + ((threadIdx.x >> 6) & 3)) & (kAmaxPlanes - 1)) * kAmaxStride;
+#endif
+    if (b) atomicMax(sub, b);  // (fire and forget: nothing waits for the result; a look at the word first would put a second memory round trip at the end of every wavefront)
+  }
+}
+
+__device__ __forceinline__ float amax4(float a, const float4& v) {
+  return fmaxf(fmaxf(a, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 }  // namespace rscotr

@@ -416,6 +416,7 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
     return;
   }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
+  float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -429,7 +430,11 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dm = (r & 3) + 8 * (r >> 2);
-          if (!EDGE || mb + dm < p.M) crow[(long)dm * p.ldc] = acc[i][j][r] + bv;
+          if (!EDGE || mb + dm < p.M) {
+            const float v = acc[i][j][r] + bv;
+            crow[(long)dm * p.ldc] = v;
+            amx = fmaxf(amx, fabsf(v));
+          }
         }
       } else {
 #pragma unroll
@@ -437,11 +442,12 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
           float v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n);
+          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n, amx);
           __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads from being hoisted across (registers)
         }
       }
     }
+  amax_commit(p.amax_out, amx);
 }
 
 template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC = 0>
@@ -663,7 +669,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_big_kernel(GemmParams p) {
           float v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          epilogue_rows4<false>(p, v, mb + 8 * g4, n);
+          float amx_unused = 0.f;
+          epilogue_rows4<false>(p, v, mb + 8 * g4, n, amx_unused);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1030,12 +1037,22 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   using OB = std::conditional_t<BPL, PlaneOperand<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK, H16>>;
   H3Scale ha{1.f, 2048.f}, hb{1.f, 2048.f};
   float inva = 1.f, invb = 1.f;
+  // The range words are REQUESTED here and reduced (h3_scales) only after the first operand tiles have been requested too:
+  // the words are cold lines for this XCD's L2 — waiting for them first would put a full memory latency in front of every
+  // workgroup's first tile (measured in the step: the split product's gain over the six-term one was gone).
+  unsigned ra = 0u, rb = 0u;
   if constexpr (H16) {
-    const int ea = h3_scale_exp(*p.amax_a), eb = h3_scale_exp(*p.amax_b);
-    ha.sc = __uint_as_float((unsigned)ea << 23); ha.sc2 = __uint_as_float((unsigned)(ea + 11) << 23);
-    hb.sc = __uint_as_float((unsigned)eb << 23); hb.sc2 = __uint_as_float((unsigned)(eb + 11) << 23);
-    inva = __uint_as_float((unsigned)(254 - ea) << 23); invb = __uint_as_float((unsigned)(254 - eb) << 23);
+    ra = p.amax_a[(long)(threadIdx.x & (kAmaxPlanes - 1)) * kAmaxStride];
+    rb = p.amax_b[(long)(threadIdx.x & (kAmaxPlanes - 1)) * kAmaxStride];
   }
+  auto h3_scales = [&]() {
+    if constexpr (H16) {
+      const int ea = h3_scale_exp(amax_fold(ra)), eb = h3_scale_exp(amax_fold(rb));
+      ha.sc = __uint_as_float((unsigned)ea << 23); ha.sc2 = __uint_as_float((unsigned)(ea + 11) << 23);
+      hb.sc = __uint_as_float((unsigned)eb << 23); hb.sc2 = __uint_as_float((unsigned)(eb + 11) << 23);
+      inva = __uint_as_float((unsigned)(254 - ea) << 23); invb = __uint_as_float((unsigned)(254 - eb) << 23);
+    }
+  };
   constexpr int NBUF = PIPE ? 2 : 1;
   unsigned* sA[2] = {lds, lds + (NBUF - 1) * OA::WORDS};
   unsigned* sB[2] = {lds + NBUF * OA::WORDS, lds + NBUF * OA::WORDS + (NBUF - 1) * OB::WORDS};
@@ -1150,6 +1167,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       las[d].template load<EDGE>(p.A, p.lda, m0, kbeg + tt * SBK, tid, alast, p.K);
       lbs[d].template load<EDGE>(p.B, p.ldb, n0, kbeg + tt * SBK, tid, blast, p.K);
     }
+    h3_scales();
     if (AKM) las[0].scale_k(ksp, ksper, kbeg, tid, klast);
     if (AKM) las[0].accum(rs, tid);
     las[0].store(sA[0], tid, ha);
@@ -1182,6 +1200,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     }
   } else if (PIPE) {
     fetch(0);
+    h3_scales();
     stage(sA[0], sB[0]);
     if (nk > 1) fetch(1);
     __syncthreads();
@@ -1196,6 +1215,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     }
   } else {
     fetch(0);
+    h3_scales();
     for (int t = 0; t < nk; ++t) {
       __syncthreads();  // the previous tile has been consumed
       stage(sA[0], sB[0]);
@@ -1248,6 +1268,7 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     return;
   }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
+  float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1260,18 +1281,23 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       if (plain) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (!EDGE || mb + (r & 3) + 8 * (r >> 2) < p.M) crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
+          if (!EDGE || mb + (r & 3) + 8 * (r >> 2) < p.M) {
+            const float v = acc[i][j][r] + bv;
+            crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
+            amx = fmaxf(amx, fabsf(v));
+          }
       } else {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           float v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n);
+          epilogue_rows4<EDGE>(p, v, mb + 8 * g4, n, amx);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+  amax_commit(p.amax_out, amx);
 }
 
 template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, bool BPL = false>
@@ -1444,6 +1470,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     return;
   }
+  float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1457,7 +1484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-        epilogue_rows4<true>(p, v, mb + 8 * g4, n);
+        epilogue_rows4<true>(p, v, mb + 8 * g4, n, amx);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1528,8 +1555,10 @@ constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<128, 128, true, 
 // halve the residency of the fp32 body's workgroups (measured: 950 -> 1500 us for the launch).
 // VAR: 0 = fp32 64 x 64 (any problem), 2 = bf16x6 128 x 128, 3 = bf16x6 64 x 64 software-pipelined (32 k per step: M, N
 // multiples of 64, k-slices multiples of 32, 16-byte aligned operands)
+// VAR 7 (round 5): the fp16 split product on the 128 x 128 edge body; table column 14 = (slot of A + 1) << 32 | slot of B + 1,
+// indices into `amax_base` (the value-range words of the two operands).
 template <int VAR>
-__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
+__device__ __forceinline__ void gemm_group_dispatch(const int64_t* __restrict__ table, int n, const unsigned* __restrict__ amax_base) {
   extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
   // the problem of this workgroup.  The table comes in BUNDLES of 8 rows that share the first-workgroup column: workgroup
   // first + 8 j + x is the j-th workgroup of the bundle's row x, so that (round-robin dispatch: XCD = id % 8) ALL tiles and
@@ -1561,8 +1590,12 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   p.vecB = ((t[1] & 15) == 0) && (p.ldb % 4 == 0);
   p.vecC = 0;
   p.nb1 = 0; p.nb2 = 1;
+  if constexpr (VAR == 7) {
+    p.amax_a = amax_base + (unsigned)((uint64_t)t[14] >> 32) - 1;
+    p.amax_b = amax_base + (unsigned)((uint64_t)t[14] & 0xffffffffu) - 1;
+  }
   p.tiles = VAR == 2 ? (p.M / 128) * (p.N / 128) : VAR == 3 ? (p.M / 64) * (p.N / 64)
-            : (VAR == 4 || VAR == 6) ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+            : (VAR == 4 || VAR == 6 || VAR == 7) ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // the bodies decode (tile, k-slice) from a workgroup id laid out for XCD runs (x = id & 7 owns a run of tiles, id >> 3 =
   // slice * run + position in the run): build the id whose decoding is (tile = jwg % tiles, slice = jwg / tiles)
   const int tl_ = jwg % p.tiles, sl_ = jwg / p.tiles;
@@ -1580,6 +1613,8 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
     // bf16x6 on 128 x 128 tiles with edge handling: the ragged members (Swin stage 1 / 2: 96, 192, 288, 576 rows or columns) —
     // on the fp32 pipe of variant 0 they ran at 41 TFLOP/s
     gemm_bf16x6_body<128, 128, true, true, 0, true, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
+  } else if constexpr (VAR == 7) {
+    gemm_bf16x6_body<128, 128, true, true, 0, true, true, false, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else if constexpr (VAR == 4) {
     // fp32 pipe on 128 x 128 tiles: a 256 x 256 output is 4 tiles instead of 16 — each k-major operand panel is read twice
     // instead of four times (the 64 x 64 launch moved 2.1 GB of HBM traffic for 0.7 GB of operands)
@@ -1587,6 +1622,15 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __re
   } else {
     gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, bx, gx, 0);
   }
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const int64_t* __restrict__ table, int n) {
+  gemm_group_dispatch<VAR>(table, n, nullptr);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_h3_group_kernel(
+    const int64_t* __restrict__ table, int n, const unsigned* __restrict__ amax_base) {
+  gemm_group_dispatch<7>(table, n, amax_base);
 }
 
 // Tile / slice choice of the bf16x6 kernel for one problem; bm == 0: not its domain (the fp32 pipe takes it).
@@ -1770,21 +1814,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmParams p) {
   }
   if (w >= 4) return;
   const int n = n0 + fr;
-  if (n >= p.N) return;
-  float v[4];
+  float amx = 0.f;
+  if (n < p.N) {
+    float v[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    float t = 0.f;
+    for (int u = 0; u < 4; ++u) {
+      float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < NW; ++g) t += gemm_smem[(g * 16 + 4 * w + u) * 64 + lane];
-    v[u] = t;
+      for (int g = 0; g < NW; ++g) t += gemm_smem[(g * 16 + 4 * w + u) * 64 + lane];
+      v[u] = t;
+    }
+    if (p.bias) {
+      const float bv = p.bias[n];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] += bv;
+    }
+    epilogue_rows4<true>(p, v, m0 + 8 * w + 4 * h, n, amx);
   }
-  if (p.bias) {
-    const float bv = p.bias[n];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] += bv;
-  }
-  epilogue_rows4<true>(p, v, m0 + 8 * w + 4 * h, n);
+  amax_commit(p.amax_out, amx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1926,6 +1973,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
   const long total = (long)p.M * p.N;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  float amx = 0.f;
   if (VEC) {
     const long total4 = total >> 2;
     const float4* sl = reinterpret_cast<const float4*>(p.slabs);
@@ -1939,13 +1987,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
       const long e = i << 2;
       const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
       if (p.vecC) {
-        epilogue_store4(p, v, m, n);
+        epilogue_store4(p, v, m, n, amx);
       } else {
         float* c = p.C + (long)m * p.ldc + n;
-        c[0] = epilogue_one(p, v.x, m, n);
-        c[1] = epilogue_one(p, v.y, m, n + 1);
-        c[2] = epilogue_one(p, v.z, m, n + 2);
-        c[3] = epilogue_one(p, v.w, m, n + 3);
+        c[0] = epilogue_one(p, v.x, m, n, amx);
+        c[1] = epilogue_one(p, v.y, m, n + 1, amx);
+        c[2] = epilogue_one(p, v.z, m, n + 2, amx);
+        c[3] = epilogue_one(p, v.w, m, n + 3, amx);
       }
     }
   } else {
@@ -1954,7 +2002,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 #pragma unroll 8
       for (int s = 0; s < p.splits; ++s) v += p.slabs[(long)s * total + i];
       const int m = (int)(i / p.N), n = (int)(i - (long)m * p.N);
-      p.C[(long)m * p.ldc + n] = epilogue_one(p, v, m, n);
+      p.C[(long)m * p.ldc + n] = epilogue_one(p, v, m, n, amx);
     }
   }
   if (p.rowsum && gid < p.M) {
@@ -1962,6 +2010,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     for (int s = 0; s < p.splits; ++s) v += p.rs_slabs[(long)s * p.M + gid];
     p.rowsum[gid] = p.rowsum_acc ? p.rowsum[gid] + v : v;
   }
+  amax_commit(p.amax_out, amx);
 }
 
 // Same combine for SMALL outputs cut into many slabs (the 256x256 weight gradients of the encoder / decoder
@@ -1976,6 +2025,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_sg_kernel(GemmParams p
   const long i = (long)blockIdx.x * 64 + lane;
   const float4* sl = reinterpret_cast<const float4*>(p.slabs);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amx = 0.f;
   if (i < total4) {
 #pragma unroll 8
     for (int s = g; s < p.splits; s += 4) {
@@ -1994,13 +2044,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_sg_kernel(GemmParams p
     const long e = i << 2;
     const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
     if (p.vecC) {
-      epilogue_store4(p, v, m, n);
+      epilogue_store4(p, v, m, n, amx);
     } else {
       float* c = p.C + (long)m * p.ldc + n;
-      c[0] = epilogue_one(p, v.x, m, n);
-      c[1] = epilogue_one(p, v.y, m, n + 1);
-      c[2] = epilogue_one(p, v.z, m, n + 2);
-      c[3] = epilogue_one(p, v.w, m, n + 3);
+      c[0] = epilogue_one(p, v.x, m, n, amx);
+      c[1] = epilogue_one(p, v.y, m, n + 1, amx);
+      c[2] = epilogue_one(p, v.z, m, n + 2, amx);
+      c[3] = epilogue_one(p, v.w, m, n + 3, amx);
     }
   }
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2009,6 +2059,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_sg_kernel(GemmParams p
     for (int s = 0; s < p.splits; ++s) r += p.rs_slabs[(long)s * p.M + gid];
     p.rowsum[gid] = p.rowsum_acc ? p.rowsum[gid] + r : r;
   }
+  amax_commit(p.amax_out, amx);
 }
 
 // Column sums of a row-major (M, N) matrix: out[n] = sum_m X[m, n]  (bias gradients).
@@ -2395,6 +2446,7 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
   p.rowsum = rowsum; p.rowsum_acc = rowsum_accumulate;
   p.nb1 = 0; p.nb2 = 1;
   p.rowscale = rowscale; p.rows_per = rows_per_scale; p.kscale = kscale; p.krows_per = krows_per_scale;
+  p.amax_out = amax_out;
   hipStream_t s = (hipStream_t)stream;
 
   if (small_gemm_ok(p, a_kmajor, b_kmajor, 1)) {
@@ -2563,17 +2615,48 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
 // rscotr_gemm_f32(a_kmajor = b_kmajor = 1, accumulate = 1, rowsum_accumulate = 1) without its combine.  *splits_out = the
 // number of slabs written ([splits][M][N] floats at slab_region, then [splits][M] row-sum partials); 1 = the problem
 // was not split and C / rowsum already hold the final result.
-extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
-                                        int ldc, float* rowsum, const float* kscale, int krows_per_scale,
-                                        float* slab_region, int64_t slab_bytes, int32_t* splits_out, void* stream) {
+extern "C" int rscotr_gemm_f32_dw_slabs_r(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                          int ldc, float* rowsum, const float* kscale, int krows_per_scale,
+                                          float* slab_region, int64_t slab_bytes, int32_t* splits_out,
+                                          const uint32_t* amax_a, const uint32_t* amax_b, void* stream) {
   if (!splits_out) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_dw_slabs: splits_out required");
   tl_defer = 1;
   tl_last_splits = 1;
-  const int e = rscotr_gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, 1, 1, nullptr, ACT_NONE, nullptr, nullptr, nullptr, 1, rowsum,
-                                1, nullptr, 0, kscale, krows_per_scale, nullptr, slab_region, slab_bytes, stream);
+  const int e = gemm_f32_impl(A, B, C, M, N, K, lda, ldb, ldc, 1, 1, nullptr, ACT_NONE, nullptr, nullptr, nullptr, 1, rowsum,
+                              1, nullptr, 0, kscale, krows_per_scale, nullptr, slab_region, slab_bytes, stream, amax_a, amax_b,
+                              nullptr);
   tl_defer = 0;
   *splits_out = tl_last_splits;
   return e;
+}
+
+extern "C" int rscotr_gemm_f32_dw_slabs(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                        int ldc, float* rowsum, const float* kscale, int krows_per_scale,
+                                        float* slab_region, int64_t slab_bytes, int32_t* splits_out, void* stream) {
+  return rscotr_gemm_f32_dw_slabs_r(A, B, C, M, N, K, lda, ldb, ldc, rowsum, kscale, krows_per_scale, slab_region, slab_bytes,
+                                    splits_out, nullptr, nullptr, stream);
+}
+
+// 1 if rscotr_gemm_f32 with these arguments (16-byte aligned operands assumed) runs on the split-product kernels, i.e. as the
+// fp16 split product when the value ranges of both operands are supplied (rscotr_gemm_f32_r): callers ask before they
+// go looking for ranges.
+extern "C" int rscotr_gemm_f32_split_route(int M, int N, int K, int lda, int ldb, int a_kmajor, int b_kmajor, int act,
+                                           int has_pre, int has_rowscale, int has_kscale, int64_t workspace_bytes) {
+  if (M <= 0 || N <= 0 || K <= 0 || g_gemm_prec.load(std::memory_order_relaxed) != 3 || !g_h3_on.load(std::memory_order_relaxed)) return 0;
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N;
+  p.act = act;
+  p.vecA = lda % 4 == 0; p.vecB = ldb % 4 == 0;
+  static float dummy;
+  p.pre = has_pre ? &dummy : nullptr;
+  p.rowscale = has_rowscale ? &dummy : nullptr;
+  p.kscale = has_kscale ? &dummy : nullptr;
+  if (small_gemm_ok(p, a_kmajor, b_kmajor, 1)) return 0;
+  if (a_kmajor && b_kmajor && workspace_bytes > 0 && !has_rowscale) {
+    const DwCfg d = choose_dw_direct(M, N, K);
+    if (d.splits >= 2 && workspace_bytes >= d.splits * ((int64_t)M * N + M) * 4) return 0;
+  }
+  return choose_split6(p, a_kmajor, b_kmajor, workspace_bytes).bm ? 1 : 0;
 }
 
 // Planes of weights for rscotr_gemm_f32_wplanes (layout: gemm_wplanes_kernel).  table: device (n, 8) int64 rows {W, planes, N,
@@ -2779,12 +2862,16 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
 // Grouped launch of deferred weight gradients: see gemm_f32_group_kernel.  table: device (n, 16) int64 (layout there),
 // total_wgs = sum of the problems' workgroup counts; flops = sum of 2 M N K over the problems (the table lives on the device:
 // the caller, who built it, states the algorithmic work of the launch for the launch-site profiler; 0 = not stated).
-extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops, void* stream) {
+extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, int variant, double flops,
+                                    const uint32_t* amax_base, void* stream) {
   if (n < 0 || total_wgs < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_dw_group: negative count");
   if (n == 0 || total_wgs == 0) return RSCOTR_OK;
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: null table");
-  ProfScope prof(PROF_GEMM, flops, (hipStream_t)stream, "rscotr::gemm_f32_group_kernel<%d>", variant);  // (2 / 3 / 6: bf16x6 bodies)
-  if (variant == 0) {
+  ProfScope prof(PROF_GEMM, flops, (hipStream_t)stream, variant == 7 ? "rscotr::gemm_h3_group_kernel" : "rscotr::gemm_f32_group_kernel<%d>", variant);  // (2 / 3 / 6: bf16x6 bodies)
+  if (variant == 7) {
+    if (!amax_base) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant 7 needs the value-range words (amax_base)");
+    gemm_h3_group_kernel<<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n, amax_base);
+  } else if (variant == 0) {
     gemm_f32_group_kernel<0><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else if (variant == 2) {
     gemm_f32_group_kernel<2><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
@@ -2795,7 +2882,7 @@ extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, 
   } else if (variant == 4) {
     gemm_f32_group_kernel<4><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<128, 128, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else {
-    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128), 3 (bf16x6 64 x 64), 4 (fp32 128 x 128) or 6 (bf16x6 128 x 128 with edges)");
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128), 3 (bf16x6 64 x 64), 4 (fp32 128 x 128), 6 (bf16x6 128 x 128 with edges) or 7 (fp16 split product, 128 x 128 with edges)");
   }
   return check_launch("rscotr_gemm_dw_group");
 }
@@ -2944,7 +3031,7 @@ extern "C" int rscotr_colsum_f32(const float* X, float* out, int M, int N, int l
 
 // ---------------------------------------------------------------------------------------------------------------
 // Value range of a tensor for the fp16 split product: slot = max(slot, bit pattern of max |X[r, c]|) over rows x cols with
-// row stride ld.  The caller zeroes the slot (one memset for all slots of an iteration); the maximum is taken per lane,
+// row stride ld (slot = a range word of kAmaxPlanes sub-words, gemm_common.h).  The caller zeroes the slot (one memset for all slots of an iteration); the maximum is taken per lane,
 // per wavefront (shuffles), per workgroup (LDS) and then with ONE atomicMax on the bit pattern per workgroup — a maximum
 // does not depend on the order, so the result is deterministic.  NaNs compare above every finite pattern.
 namespace rscotr {
@@ -2975,10 +3062,63 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-    if (m) atomicMax(slot, m);
+    if (m) atomicMax(slot + (long)(blockIdx.x & (kAmaxPlanes - 1)) * kAmaxStride, m);
   }
 }
 }  // namespace rscotr
+
+namespace rscotr {
+// The same for MANY tensors in one launch (the operands of the grouped weight-gradient launch that arrived without a range):
+// table rows {X, rows, cols, ld, slot, first block}; entry e owns blocks [first_e, first_{e+1}) (the last one up to gridDim.x).
+__global__ __launch_bounds__(256) void amax_group_kernel(const int64_t* __restrict__ table, int n) {
+  __shared__ unsigned sm[4];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)table[(long)mid * 6 + 5] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* t = table + (long)lo * 6;
+  const float* X = reinterpret_cast<const float*>(t[0]);
+  const long rows = t[1];
+  const int cols = (int)t[2], ld = (int)t[3];
+  unsigned* slot = reinterpret_cast<unsigned*>(t[4]);
+  const int first = (int)t[5], nb = (lo + 1 < n ? (int)table[(long)(lo + 1) * 6 + 5] : (int)gridDim.x) - first;
+  const long tid = (long)(blockIdx.x - first) * 256 + threadIdx.x, nth = (long)nb * 256;
+  unsigned m = 0u;
+  if (((t[0] & 15) == 0) && cols % 4 == 0 && ld % 4 == 0) {
+    const int c4 = cols >> 2;
+    const long n4 = rows * c4;
+    for (long i = tid; i < n4; i += nth) {
+      const long r = i / c4;
+      const int c = (int)(i - r * c4) << 2;
+      const uint4 v = *reinterpret_cast<const uint4*>(X + r * ld + c);
+      m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+  } else {
+    const long nn = rows * cols;
+    for (long i = tid; i < nn; i += nth) {
+      const long r = i / cols;
+      m = max(m, __float_as_uint(X[r * ld + (i - r * cols)]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (m) atomicMax(slot + (long)(blockIdx.x & (kAmaxPlanes - 1)) * kAmaxStride, m);
+  }
+}
+}  // namespace rscotr
+
+extern "C" int rscotr_amax_group(const int64_t* table, int n, int total_blocks, void* stream) {
+  if (n < 0 || total_blocks < 0) return rscotr::fail(RSCOTR_E_SHAPE, "rscotr_amax_group: negative count");
+  if (n == 0 || total_blocks == 0) return RSCOTR_OK;
+  if (!table) return rscotr::fail(RSCOTR_E_ARG, "rscotr_amax_group: null table");
+  rscotr::amax_group_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(table, n);
+  return rscotr::check_launch("rscotr_amax_group");
+}
 
 extern "C" int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* slot, void* stream) {
   if (rows < 0 || cols < 0 || ld < cols) return rscotr::fail(RSCOTR_E_SHAPE, "rscotr_amax_f32: bad shape");

@@ -73,7 +73,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
-__device__ __forceinline__ float epilogue_one(const GemmParams& p, float v, int m, int n) {
+// amx (all epilogue forms): running max |stored value| of this thread (C and, when present, C2) — folded into
+// p.amax_out by amax_commit at the end of the kernel.
+__device__ __forceinline__ float epilogue_one(const GemmParams& p, float v, int m, int n, float& amx) {
   if (p.bias) v += p.bias[n];
   const long o = (long)m * p.ldc + n;
   if (p.pre) p.pre[o] = v;
@@ -87,17 +89,25 @@ __device__ __forceinline__ float epilogue_one(const GemmParams& p, float v, int 
   if (p.rowscale) v *= p.rowscale[m / p.rows_per];
   if (p.C2) {
     if (p.accumulate) v += p.C[o];
-    p.C2[o] = p.resid ? v + p.resid[o] : v;
+    const float v2 = p.resid ? v + p.resid[o] : v;
+    p.C2[o] = v2;
+    amx = fmaxf(amx, fmaxf(fabsf(v), fabsf(v2)));
     return v;
   }
   if (p.resid) v += p.resid[o];
   if (p.accumulate) v += p.C[o];
+  amx = fmaxf(amx, fabsf(v));
   return v;
 }
 
+
+// End of a kernel: the wavefront's max goes to p.amax_out with one atomicMax on the bit pattern (non-negative floats order
+// like unsigned integers; a maximum does not depend on the order of its operands: deterministic).  Every lane of the
+// wavefront must reach this call.
+
 // Four consecutive columns of one row (n % 4 == 0, p.vecC): every load is issued before the first store — the
 // element-wise form chains load -> store four times, and each wait also drains the store queued before it.
-__device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, int m, int n) {
+__device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, int m, int n, float& amx) {
   const long o = (long)m * p.ldc + n;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = a, c = a;
   const bool need_aux = p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD;
@@ -127,12 +137,15 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, i
   if (p.C2) {
     if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
     *reinterpret_cast<float4*>(p.C + o) = v;
-    *reinterpret_cast<float4*>(p.C2 + o) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+    const float4 v2 = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+    *reinterpret_cast<float4*>(p.C2 + o) = v2;
+    amx = amax4(amax4(amx, v), v2);
     return;
   }
   if (p.resid) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
   if (p.accumulate) { v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
   *reinterpret_cast<float4*>(p.C + o) = v;
+  amx = amax4(amx, v);
 }
 
 // Staged epilogue of four consecutive rows m..m+3 of one column n (v already holds accumulator + bias): the loads of
@@ -141,7 +154,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, float4 v, i
 // of a K = 256 tile); four rows at a time keep the 64x64 kernels at 55-76 VGPRs (8 rows: 75-96, 16 rows: 110-170;
 // measured on the step: 41.3 / 42.0 / 43.0 ms of GEMM per round against 44.3 element-wise).
 template <bool EDGE>
-__device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4], int m, int n) {
+__device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4], int m, int n, float& amx) {
   float x[4];
   int o[4];  // element offsets from row m
   bool ok[4];
@@ -204,7 +217,10 @@ __device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4
     float* c2 = p.C2 + base;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (ok[u]) { crow[o[u]] = v[u]; c2[o[u]] = v[u] + r[u]; }
+      if (ok[u]) {
+        crow[o[u]] = v[u]; c2[o[u]] = v[u] + r[u];
+        amx = fmaxf(amx, fmaxf(fabsf(v[u]), fabsf(v[u] + r[u])));
+      }
     return;
   }
   if (p.resid) {
@@ -222,7 +238,7 @@ __device__ __forceinline__ void epilogue_rows4(const GemmParams& p, float (&v)[4
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u)
-    if (ok[u]) crow[o[u]] = v[u];
+    if (ok[u]) { crow[o[u]] = v[u]; amx = fmaxf(amx, fabsf(v[u])); }
 }
 
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, used for speed

@@ -53,8 +53,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             int M, int C, float eps,
                                                             const float* __restrict__ add = nullptr, int add_rows = 1,
-                                                            float* __restrict__ y2 = nullptr, MergeGeom mg = MergeGeom{}) {
+                                                            float* __restrict__ y2 = nullptr, MergeGeom mg = MergeGeom{},
+                                                            unsigned* __restrict__ amax_out = nullptr) {
+  // amax_out: value-range word of the output(s) (common.h: amax_commit) — max |y| (and |y2|) for the fp16 split product
+  // of the GEMM that multiplies with them
   constexpr int RW = kWave / G;  // rows per wavefront
+  float amx = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rw = lane / G;
   const int C4 = C >> 2;
@@ -102,9 +106,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
           o.z = (v[i].z - mu) * rs * wv[i].z + bv[i].z;
           o.w = (v[i].w - mu) * rs * wv[i].w + bv[i].w;
           reinterpret_cast<float4*>(y + row * C)[c] = o;
+          amx = amax4(amx, o);
           if (y2) {  // second output: y + add[row % add_rows] (the positional embedding the next attention adds to its query)
             const float4 a = reinterpret_cast<const float4*>(add + (row % add_rows) * C)[c];
-            reinterpret_cast<float4*>(y2 + row * C)[c] = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+            const float4 o2 = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+            reinterpret_cast<float4*>(y2 + row * C)[c] = o2;
+            amx = amax4(amx, o2);
           }
         }
       }
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       }
     }
   }
+  amax_commit(amax_out, amx);
 }
 
 template <int G, int NV, bool MG = false>
@@ -124,8 +132,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             const float* __restrict__ dres,
                                                             float* __restrict__ part, int M, int C,
-                                                            MergeGeom mg = MergeGeom{}) {
+                                                            MergeGeom mg = MergeGeom{},
+                                                            unsigned* __restrict__ amax_out = nullptr) {
+  // no implicit fused multiply-adds in this body: the plain and the patch-merging instantiation must round alike
+  // (tests/test_norm_gpu.py holds them bit-equal), whatever the optimiser would contract in each of them
+#pragma clang fp contract(off)
   constexpr int RW = kWave / G;
+  float amx = 0.f;  // max |dx| -> amax_out (as the forward kernel)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rw = lane / G;
   const int C4 = C >> 2;
@@ -167,26 +180,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = sub + i * G;
         if (c < C4) {
           float4 o;
-          o.x = rs * (g[i].x - m1 - xh[i].x * m2);
-          o.y = rs * (g[i].y - m1 - xh[i].y * m2);
-          o.z = rs * (g[i].z - m1 - xh[i].z * m2);
-          o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+          o.x = rs * fmaf(-xh[i].x, m2, g[i].x - m1);
+          o.y = rs * fmaf(-xh[i].y, m2, g[i].y - m1);
+          o.z = rs * fmaf(-xh[i].z, m2, g[i].z - m1);
+          o.w = rs * fmaf(-xh[i].w, m2, g[i].w - m1);
           if (!MG) {
             if (dres) {  // gradient of the residual branch that forks at this LayerNorm's input
               const float4 r = reinterpret_cast<const float4*>(dres + row * C)[c];
               o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             reinterpret_cast<float4*>(dx + row * C)[c] = o;
+            amx = amax4(amx, o);
           } else {  // channel c back to its four window positions
             if (off[0] >= 0) dx[off[0] + c] = o.x;
             if (off[1] >= 0) dx[off[1] + c] = o.y;
             if (off[2] >= 0) dx[off[2] + c] = o.z;
             if (off[3] >= 0) dx[off[3] + c] = o.w;
+            amx = amax4(amx, o);  // (positions past the map are not stored: still a bound)
           }
         }
       }
     }
   }
+  amax_commit(amax_out, amx);
   if (!part) return;
   // fold the RW row-slots of the wavefront, then the 4 wavefronts through LDS, then store this
   // workgroup's partial row: part[blockIdx.x][{dgamma, dbeta}][C].  (Hundreds of workgroups adding
@@ -322,7 +338,7 @@ using namespace rscotr;
   } while (0)
 
 extern "C" int rscotr_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
-                                    float* mean, float* rstd, int M, int C, float eps, void* stream) {
+                                    float* mean, float* rstd, int M, int C, float eps, uint32_t* amax_out, void* stream) {
   if (M < 0 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd: bad shape M=%d C=%d", M, C);
   if (C % 4 != 0 || C > 2048) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd: C=%d must be a multiple of 4, <= 2048", C);
   if (M == 0) return RSCOTR_OK;
@@ -331,7 +347,8 @@ extern "C" int rscotr_layernorm_fwd(const float* x, const float* weight, const f
     return fail(RSCOTR_E_ALIGN, "rscotr_layernorm_fwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
 #define CALL(G, NV)                                                                                       \
-  layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps)
+  layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps, nullptr, 1, \
+                                                                         nullptr, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("rscotr_layernorm_fwd");
@@ -339,7 +356,7 @@ extern "C" int rscotr_layernorm_fwd(const float* x, const float* weight, const f
 
 extern "C" int rscotr_layernorm_fwd_sum(const float* x, const float* weight, const float* bias, float* y, float* mean,
                                         float* rstd, const float* add, int add_rows, float* y2, int M, int C, float eps,
-                                        void* stream) {
+                                        uint32_t* amax_out, void* stream) {
   if (M < 0 || C <= 0 || add_rows <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd_sum: bad shape M=%d C=%d add_rows=%d", M, C, add_rows);
   if (C % 4 != 0 || C > 2048) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_fwd_sum: C=%d must be a multiple of 4, <= 2048", C);
   if (M == 0) return RSCOTR_OK;
@@ -350,7 +367,7 @@ extern "C" int rscotr_layernorm_fwd_sum(const float* x, const float* weight, con
   hipStream_t s = (hipStream_t)stream;
 #define CALL(G, NV)                                                                                                  \
   layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps, add, \
-                                                                         add_rows, y2)
+                                                                         add_rows, y2, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("rscotr_layernorm_fwd_sum");
@@ -373,7 +390,7 @@ extern "C" int64_t rscotr_layernorm_bwd_workspace(int M, int C) {
 // `dx_add` (M,C) or null: added to dx on the way out (the gradient of a residual branch forking at the input).
 extern "C" int rscotr_layernorm_bwd(const float* dy, const float* x, const float* weight, const float* mean,
                                     const float* rstd, float* dx, const float* dx_add, float* dweight, float* dbias, int M, int C,
-                                    float* workspace, int64_t workspace_bytes, void* stream) {
+                                    float* workspace, int64_t workspace_bytes, uint32_t* amax_out, void* stream) {
   if (M < 0 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_bwd: bad shape M=%d C=%d", M, C);
   if (C % 4 != 0 || C > 2048) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_bwd: C=%d must be a multiple of 4, <= 2048", C);
   if (M == 0) return RSCOTR_OK;
@@ -389,7 +406,7 @@ extern "C" int rscotr_layernorm_bwd(const float* dy, const float* x, const float
   hipStream_t s = (hipStream_t)stream;
   float* part = params ? workspace : nullptr;
 #define CALL(G, NV) \
-  layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C)
+  layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   if (int e = check_launch("rscotr_layernorm_bwd")) return e;
@@ -404,7 +421,7 @@ extern "C" int rscotr_layernorm_bwd(const float* dy, const float* x, const float
 // stay in `part` (caller-owned until rscotr_layernorm_flush), dx is written as usual.
 extern "C" int rscotr_layernorm_bwd_partials(const float* dy, const float* x, const float* weight, const float* mean,
                                              const float* rstd, float* dx, const float* dx_add, int M, int C, float* part, int64_t part_bytes,
-                                             void* stream) {
+                                             uint32_t* amax_out, void* stream) {
   if (M <= 0 || C <= 0) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_bwd_partials: bad shape M=%d C=%d", M, C);
   if (C % 4 != 0 || C > 2048) return fail(RSCOTR_E_SHAPE, "rscotr_layernorm_bwd_partials: C=%d must be a multiple of 4, <= 2048", C);
   if (!dy || !x || !mean || !rstd || !part) return fail(RSCOTR_E_ARG, "rscotr_layernorm_bwd_partials: null pointer");
@@ -415,7 +432,7 @@ extern "C" int rscotr_layernorm_bwd_partials(const float* dy, const float* x, co
     return fail(RSCOTR_E_ARG, "rscotr_layernorm_bwd_partials: region of rscotr_layernorm_bwd_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
 #define CALL(G, NV) \
-  layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C)
+  layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("rscotr_layernorm_bwd_partials");
@@ -433,7 +450,7 @@ static int pm_check(const char* who, int B, int H, int W, int Cin, long* M) {
 }
 
 extern "C" int rscotr_patch_merge_norm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
-                                           float* rstd, int B, int H, int W, int Cin, float eps, void* stream) {
+                                           float* rstd, int B, int H, int W, int Cin, float eps, uint32_t* amax_out, void* stream) {
   long M;
   if (int e = pm_check("rscotr_patch_merge_norm_fwd", B, H, W, Cin, &M)) return e;
   if (M == 0) return RSCOTR_OK;
@@ -445,7 +462,7 @@ extern "C" int rscotr_patch_merge_norm_fwd(const float* x, const float* weight, 
   const int C = 4 * Cin;
 #define CALL(G, NV)                                                                                                     \
   layernorm_fwd_kernel<G, NV, true><<<ln_blocks((int)M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, (int)M, C, \
-                                                                                    eps, nullptr, 1, nullptr, mg)
+                                                                                    eps, nullptr, 1, nullptr, mg, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("rscotr_patch_merge_norm_fwd");
@@ -459,7 +476,7 @@ extern "C" int64_t rscotr_patch_merge_norm_bwd_workspace(int B, int H, int W, in
 
 extern "C" int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, const float* weight, const float* mean,
                                            const float* rstd, float* dx, float* dweight, float* dbias, int B, int H, int W,
-                                           int Cin, float* workspace, int64_t workspace_bytes, int fold, void* stream) {
+                                           int Cin, float* workspace, int64_t workspace_bytes, int fold, uint32_t* amax_out, void* stream) {
   long M;
   if (int e = pm_check("rscotr_patch_merge_norm_bwd", B, H, W, Cin, &M)) return e;
   if (M == 0) return RSCOTR_OK;
@@ -476,7 +493,7 @@ extern "C" int rscotr_patch_merge_norm_bwd(const float* dy, const float* x, cons
   float* part = params ? workspace : nullptr;
   const MergeGeom mg{H, W, Cin};
 #define CALL(G, NV) \
-  layernorm_bwd_kernel<G, NV, true><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, nullptr, part, (int)M, C, mg)
+  layernorm_bwd_kernel<G, NV, true><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, nullptr, part, (int)M, C, mg, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
 #undef CALL
   if (int e = check_launch("rscotr_patch_merge_norm_bwd")) return e;

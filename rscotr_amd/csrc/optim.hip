@@ -56,12 +56,47 @@ __global__ __launch_bounds__(256) void grad_sumsq_final_kernel(float* __restrict
   if (threadIdx.x == 0) sumsq[0] = part[0] + part[1] + part[2] + part[3];
 }
 
+// Value ranges of the parameters (round 5: the fp16 split product of csrc/gemm.hip scales a weight operand by a power of two
+// taken from max |w| of its tensor): seg_amax[segment] = bit pattern of max |w|.  The update kernel below refreshes the word
+// of every segment it touches — amax_reset_kernel zeroes the live segments' words, each chunk's workgroup then folds its
+// maximum in with one atomicMax on the bit pattern (a maximum does not depend on the order: deterministic; the plain read
+// in front only skips atomics that cannot raise the word).  Segments that are not stepped keep their word.
+__global__ __launch_bounds__(256) void amax_reset_kernel(const float* __restrict__ seg_dyn, unsigned* __restrict__ seg_amax, int nseg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nseg && (!seg_dyn || seg_dyn[i * SEG_STRIDE + 4] != 0.f)) seg_amax[i] = 0u;
+}
+
+__device__ __forceinline__ void chunk_amax_commit(unsigned* __restrict__ word, float amx) {
+  __shared__ float part_amax[4];
+  amx = wave_max(amx);
+  if ((threadIdx.x & 63) == 0) part_amax[threadIdx.x >> 6] = amx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned m = __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3])));
+    if (m > *reinterpret_cast<volatile unsigned*>(word)) atomicMax(word, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void param_amax_kernel(const float* __restrict__ param, const int32_t* __restrict__ chunk_seg,
+                                                         const int64_t* __restrict__ chunk_off,
+                                                         const int32_t* __restrict__ chunk_len, unsigned* __restrict__ seg_amax) {
+  const int c = blockIdx.x;
+  const float4* p4 = reinterpret_cast<const float4*>(param + chunk_off[c]);
+  const int n4 = chunk_len[c] >> 2;
+  float amx = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 p = p4[i];
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(p.x), fabsf(p.y))), fmaxf(fabsf(p.z), fabsf(p.w)));
+  }
+  chunk_amax_commit(seg_amax + chunk_seg[c], amx);
+}
+
 __global__ __launch_bounds__(256) void adamw_clip_kernel(
     float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
     float* __restrict__ exp_avg_sq, const int32_t* __restrict__ chunk_seg,
     const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ chunk_len,
     const float* __restrict__ seg_dyn, const float* __restrict__ sumsq, float max_norm, float beta1,
-    float beta2, float eps) {
+    float beta2, float eps, unsigned* __restrict__ seg_amax) {
   const int c = blockIdx.x;
   const float* d = seg_dyn + chunk_seg[c] * SEG_STRIDE;
   if (d[4] == 0.f) return;
@@ -80,6 +115,7 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(
   const float decay = 1.f - lr * wd;
   const float step_size = lr * inv_bc1;
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  float amx = 0.f;
   for (int i = threadIdx.x; i < n4; i += 256) {
     float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
 #define RSCOTR_ADAMW_1(X)                                   \
@@ -96,7 +132,9 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(
     p4[i] = p;
     m4[i] = m;
     v4[i] = v;
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(p.x), fabsf(p.y))), fmaxf(fabsf(p.z), fabsf(p.w)));
   }
+  if (seg_amax) chunk_amax_commit(seg_amax + chunk_seg[c], amx);
 }
 
 }  // namespace rscotr
@@ -118,11 +156,36 @@ extern "C" int rscotr_grad_sumsq(const float* grad, const int32_t* chunk_seg, co
   return check_launch("rscotr_grad_sumsq");
 }
 
+extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                        const int32_t* chunk_seg, const int64_t* chunk_off,
+                                        const int32_t* chunk_len, const float* seg_dyn, int nchunks,
+                                        const float* sumsq, float max_norm, float beta1, float beta2,
+                                        float eps, uint32_t* seg_amax, int nseg, void* stream);
+
 extern "C" int rscotr_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                                       const int32_t* chunk_seg, const int64_t* chunk_off,
                                       const int32_t* chunk_len, const float* seg_dyn, int nchunks,
                                       const float* sumsq, float max_norm, float beta1, float beta2,
                                       float eps, void* stream) {
+  return rscotr_adamw_clip_step_r(param, grad, exp_avg, exp_avg_sq, chunk_seg, chunk_off, chunk_len, seg_dyn, nchunks, sumsq,
+                                  max_norm, beta1, beta2, eps, nullptr, 0, stream);
+}
+
+extern "C" int rscotr_param_amax(const float* param, const int32_t* chunk_seg, const int64_t* chunk_off,
+                                 const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, void* stream) {
+  if (nchunks < 0 || nseg < 0) return fail(RSCOTR_E_SHAPE, "rscotr_param_amax: negative count");
+  if (nchunks == 0 || nseg == 0) return RSCOTR_OK;
+  if (!param || !chunk_seg || !chunk_off || !chunk_len || !seg_amax) return fail(RSCOTR_E_ARG, "rscotr_param_amax: null pointer");
+  amax_reset_kernel<<<dim3((nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(nullptr, seg_amax, nseg);
+  param_amax_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(param, chunk_seg, chunk_off, chunk_len, seg_amax);
+  return check_launch("rscotr_param_amax");
+}
+
+extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                        const int32_t* chunk_seg, const int64_t* chunk_off,
+                                        const int32_t* chunk_len, const float* seg_dyn, int nchunks,
+                                        const float* sumsq, float max_norm, float beta1, float beta2,
+                                        float eps, uint32_t* seg_amax, int nseg, void* stream) {
   if (nchunks < 0) return fail(RSCOTR_E_SHAPE, "rscotr_adamw_clip_step: negative chunk count");
   if (nchunks == 0) return RSCOTR_OK;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !chunk_seg || !chunk_off || !chunk_len || !seg_dyn)
@@ -130,8 +193,10 @@ extern "C" int rscotr_adamw_clip_step(float* param, const float* grad, float* ex
   if (max_norm > 0.f && !sumsq) return fail(RSCOTR_E_ARG, "rscotr_adamw_clip_step: sumsq required when clipping");
   if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
     return fail(RSCOTR_E_ALIGN, "rscotr_adamw_clip_step: arenas must be 16-byte aligned");
+  if (seg_amax && nseg > 0)
+    amax_reset_kernel<<<dim3((nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(seg_dyn, seg_amax, nseg);
   adamw_clip_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, chunk_seg, chunk_off, chunk_len, seg_dyn, sumsq, max_norm, beta1,
-      beta2, eps);
+      beta2, eps, seg_amax);
   return check_launch("rscotr_adamw_clip_step");
 }

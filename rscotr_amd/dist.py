@@ -29,6 +29,87 @@ import torch.distributed as dist
 INLINE = os.environ.get('RSCOTR_DIST_INLINE', '1') == '1'
 
 
+class DirectComm:
+    """An RCCL communicator of this job's ranks driven through the C ABI (rscotr_comm_*, csrc/comm.cpp) with a stream of its
+    own: the OVERLAPPED exchange issues its collectives here, ordered against the compute stream by plain events (fork after
+    a bucket's last gradient, join before clip + AdamW) — also inside a hipGraph capture.  No c10d work objects exist for
+    these collectives, so c10d's watchdog thread has no event of a capturing stream to poll (that poll aborted 2 of 8
+    overlapped runs in round 4).  The unique id travels over the job's existing process group."""
+
+    def __init__(self, device):
+        import ctypes
+        from ._lib import lib
+        self.lib = lib
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank() == 0:
+            lib.call('rscotr_comm_unique_id', idt.data_ptr())
+        d = idt.to(device)
+        dist.broadcast(d, 0)
+        idt = d.cpu()
+        handle = ctypes.c_void_p()
+        lib.call('rscotr_comm_init', idt.data_ptr(), dist.get_rank(), dist.get_world_size(), ctypes.byref(handle))
+        self.handle = handle.value
+        self.stream = torch.cuda.Stream(device)
+        self.forked = False
+
+    def allreduce_avg(self, t):
+        """t (contiguous fp32, complete on the CURRENT stream) = mean over the ranks, in place, on the communicator's stream."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        self.lib.call('rscotr_comm_allreduce_avg', self.handle, t.data_ptr(), t.numel(), self.stream.cuda_stream)
+        self.forked = True
+
+    def join(self):
+        """The current stream waits for everything issued on the communicator's stream."""
+        if self.forked:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self.forked = False
+
+    def close(self):
+        if self.handle:
+            self.lib.call('rscotr_comm_destroy', self.handle)
+            self.handle = 0
+
+
+_ACTIVE_COMM = [None]  # the DirectComm of the overlapped exchange, when there is one (GradSync creates it)
+
+
+def direct_comm():
+    return _ACTIVE_COMM[0]
+
+
+def control_all_reduce(t, op):
+    """All-reduce of a small CONTROL value (capacities, success flags, plan hashes, step counts — start-up agreements, a few
+    per run).  Through the host control group (gloo) when the runner made one: the device tensor is staged through the
+    host, and the RCCL process group never sees these — with the overlapped exchange on its own communicator c10d's RCCL
+    watchdog then has no work at all whose end event could sit on a stream that goes into capture."""
+    from .ops.distutil import host_group
+    hg = host_group()
+    if hg is None or not t.is_cuda:
+        dist.all_reduce(t, op=op)
+        return t
+    c = t.detach().cpu()
+    dist.all_reduce(c, op=op, group=hg)
+    t.copy_(c)
+    return t
+
+
+def mean_over_ranks(t):
+    """t (small contiguous fp32 device vector) = its mean over the ranks, in place: on the exchange's own communicator when
+    there is one (ordered after everything on the current stream, joined before returning), else one c10d all-reduce."""
+    comm = direct_comm()
+    if comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        comm.allreduce_avg(t)
+        comm.join()
+        return t
+    t.div_(dist.get_world_size())
+    dist.all_reduce(t)
+    return t
+
+
 def is_dist():
     """True when gradients have to be exchanged.  RSCOTR_DIST_SINGLE=1 takes the distributed code path with a
     one-rank group (exercises bucket plans, RCCL calls and the split graph/optimizer flow on a 1-GPU box)."""
@@ -57,6 +138,25 @@ class GradSync:
         # every time a bucket has seen all of its writes, which completes that bucket and launches its all-reduce.
         optimizer.written_callbacks.append(self._on_written)
         self.vfires, self.vfired, self._vpending = {}, None, None
+        # the overlapped exchange runs on a communicator of its own (DirectComm); the inline one stays with c10d
+        self.comm = None
+        if (not INLINE and is_dist() and dist.get_backend() == 'nccl' and optimizer.flat_g.is_cuda
+                and os.environ.get('RSCOTR_DIST_DIRECT', '1') != '0'):
+            from ._lib import lib
+            if lib.rscotr_comm_available():
+                self.comm = _ACTIVE_COMM[0] = DirectComm(optimizer.flat_g.device)
+
+    def allreduce_avg_async(self, t):
+        """Overlapped form: mean of a small vector (the packed log variables) over the ranks, in the exchange's own sequence
+        (after the buckets); `wait()` joins."""
+        self.comm.allreduce_avg(t)
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.comm is not None:
+            self.comm.join()
 
     def _on_ready(self, i):
         """A gradient contribution of parameter i is complete (AccumulateGrad ran, or a backward
@@ -84,7 +184,7 @@ class GradSync:
         import zlib
         h = zlib.crc32(repr([(b['lo'], b['hi']) for b in self.plans[task]]).encode()) & 0x7FFFFFFF
         t = torch.tensor([h, -h], dtype=torch.int64, device=self.opt.flat_g.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        control_all_reduce(t, dist.ReduceOp.MAX)
         lo, hi = -int(t[1]), int(t[0])
         if lo != hi:
             raise RuntimeError(f'gradient bucket plans of task {task!r} differ across ranks: the ranks did not run the '
@@ -109,9 +209,7 @@ class GradSync:
         self.handles = []
         for b in reversed(self.plans[task]):  # the one launch order of every path: back to front
             self._launch(b)
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        self.wait()
 
     def _launch(self, b):
         if not is_dist():
@@ -121,6 +219,8 @@ class GradSync:
             # the collective on the COMPUTE stream, in launch order (c10d runs a synchronous collective on the current
             # stream): no fork, so a captured iteration stays ONE chain on one hardware queue
             dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=False)
+        elif self.comm is not None:  # overlapped: ncclAllReduce(ncclAvg) on the communicator's stream, forked by an event
+            self.comm.allreduce_avg(view)
         elif dist.get_backend() == 'nccl':  # RCCL: mean in the collective
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True))
         else:  # gloo (CPU tests) has no AVG
@@ -207,9 +307,7 @@ class GradSync:
             while self._next < len(self._order):
                 self._launch(self._order[self._next])
                 self._next += 1
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        self.wait()
         self._bucket_of = self._vpending = None
 
     def describe(self):

@@ -60,8 +60,8 @@ class LazyLogVars(Mapping):
     def all_reduced(self):
         """Rank-averaged values (multitask_learner.py:299-304): ONE all-reduce of the packed vector, still no host sync."""
         assert self._vals is None
-        packed = self._packed / dist.get_world_size()
-        dist.all_reduce(packed)
+        from .dist import mean_over_ranks
+        packed = mean_over_ranks(self._packed.float().clone().contiguous())
         return LazyLogVars(self._all, packed)
 
     def scaled(self, weight):
@@ -247,11 +247,14 @@ class MTL(nn.Module):
     # -------------------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
         ops.WPLANES.bump()  # parameters change in place: the pre-split weight planes are stale
+        if ops.STATE.grad_sink is not None:
+            ops.STATE.grad_sink.params_changed()  # ... and so are the value ranges the optimizer keeps for them
         return super().load_state_dict(*args, **kwargs)
 
     def forward(self, task, img, img_metas, return_loss=True, dataset_name=None, **kwargs):
         ops.WPLANES.begin(task)  # (the weight-plane sets this task uses are refreshed together)
         ops.PP.clear()           # (activation plane sets live for one forward + backward pass)
+        ops.RANGES.begin(img.device)  # (value-range slots of the GEMM operands: one generation per iteration)
         if return_loss:
             return self.forward_train(task=task, img=img, img_metas=img_metas, **kwargs)
         with torch.no_grad():
@@ -314,10 +317,10 @@ class MTL(nn.Module):
         if dist.is_available() and dist.is_initialized() and not getattr(self, 'defer_log_allreduce', False):
             world = dist.get_world_size()
             # rank-consistency guard of the reference (multitask_learner.py:289-296) rides along
-            packed = torch.cat([packed / world, packed.new_tensor([float(len(names))])])
-            dist.all_reduce(packed)
-            host = packed.tolist()
-            assert host[-1] == len(names) * world, \
+            from .dist import mean_over_ranks
+            packed = torch.cat([packed, packed.new_tensor([float(len(names))])]).float().contiguous()
+            host = mean_over_ranks(packed).tolist()
+            assert host[-1] == len(names), \
                 'loss log variables are different across GPUs!\n' + f'rank {dist.get_rank()} keys: ' + ','.join(names)
             host = host[:-1]
         else:

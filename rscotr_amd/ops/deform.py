@@ -5,6 +5,7 @@ from torch.autograd import Function
 
 from .core import _WS, _Prof, _chk, _f32c, _ptr, _stream, lib
 from .matmul import _linear_param_grad, gemm
+from .ranges import RANGES
 from .state import STATE
 
 # ------------------------------------------------------------------------------------------
@@ -183,12 +184,13 @@ class _MSDAAttn(Function):
         B, Nq, C = x.shape
         H, D = heads, C // heads
         M = B * Nq
-        x2 = _f32c(x).reshape(M, C)
+        x2 = RANGES.carry(x, _f32c(x).reshape(M, C))
         # q_sum: x + q_pos already formed by the producer of x (ops.layer_norm_sum): data only, no gradient of its own
-        q2 = x2 if q_pos is None else _f32c(torch.add(x, q_pos) if q_sum is None else q_sum).reshape(M, C)
+        q2 = x2 if q_pos is None else (_f32c(torch.add(x, q_pos)).reshape(M, C) if q_sum is None else
+                                       RANGES.carry(q_sum, _f32c(q_sum).reshape(M, C)))
         v_is_x = value_in is None or value_in is x
         id_is_x = identity is x
-        val2 = x2 if v_is_x else _f32c(value_in).reshape(-1, C)
+        val2 = x2 if v_is_x else RANGES.carry(value_in, _f32c(value_in).reshape(-1, C))
         Mk = val2.shape[0]
         Nk = Mk // B
         ws = [w if w.is_contiguous() else w.contiguous() for w in (w_off, w_aw, w_v, w_o)]
@@ -217,8 +219,11 @@ class _MSDAAttn(Function):
             loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
         out = _msda_fwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn)
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(M, C))
-        y = gemm(out.view(M, C), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2)
+        # (every output element is a convex combination of value entries — softmax weights x bilinear weights, zeros outside
+        # the maps: max |out| <= max |v|, so the value's range word serves the output projection's operand too)
+        y = gemm(RANGES.carry(v, out.view(M, C)), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2)
         ctx.save_for_backward(q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, *ws)
+        ctx.slots = (RANGES.slot_of(q2), RANGES.slot_of(val2))
         ctx.kpm = kpm
         ctx.w_cat = w_cat  # (a temporary of this node: not an autograd-tracked tensor)
         ctx.params = (w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)  # handles for the gradient sink
@@ -226,7 +231,7 @@ class _MSDAAttn(Function):
         ctx.flags = (v_is_x, id_is_x, q_pos is not None, identity is not None)
         ctx.shapes = (x.shape, None if q_pos is None else q_pos.shape, None if value_in is None else value_in.shape,
                       None if identity is None else identity.shape)
-        return y.view(B, Nq, C)
+        return RANGES.carry(y, y.view(B, Nq, C))
 
     @staticmethod
     def backward(ctx, dy):
@@ -237,7 +242,9 @@ class _MSDAAttn(Function):
         need = ctx.needs_input_grad
         M, Mk = B * Nq, B * Nk
         n_off, n_aw = H * L * P * 2, H * L * P
-        g = _f32c(dy).reshape(M, C)
+        g = RANGES.carry(dy, _f32c(dy).reshape(M, C))
+        RANGES.tag(q2, ctx.slots[0])
+        RANGES.tag(val2, ctx.slots[1])
         sinks = []
         # output projection
         gw_o, gb_o, s1, s2 = _linear_param_grad(g, out.view(M, C), C, C, M, p_o, pb_o, 0, need[18], pb_o is not None and need[19])
@@ -296,7 +303,8 @@ class _MSDAAttn(Function):
         d_id = g.view(ctx.shapes[3]) if (has_id and not merge_id and need[3]) else None
         if id_is_x and not merge_id:
             d_id = None
-        return (None if d_x is None else d_x.view(ctx.shapes[0]), None if d_pos is None else d_pos.view(ctx.shapes[1]),
+        return (None if d_x is None else RANGES.carry(d_x, d_x.view(ctx.shapes[0])),
+                None if d_pos is None else RANGES.carry(d_pos, d_pos.view(ctx.shapes[1])),
                 d_val, d_id, None, None, None, None, None, None, None, None,
                 gw_off, gb_off, gw_aw, gb_aw, gw_v, gb_v, gw_o, gb_o, None)
 

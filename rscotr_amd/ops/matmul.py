@@ -8,7 +8,9 @@ from torch.autograd import Function
 
 from .core import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_RELU_GRAD, _ACT, _WS, _Prof, _chk, _f32c, _gemm_ws_bytes,
                    _off_path, _ptr, _sink, _stream, lib)
+from .ranges import RANGES
 from .state import STATE
+
 
 class _WeightPlanes:
     """bf16 plane sets of the parameters that serve as the B operand of y = x W^T (and dx = dy W): rscotr_gemm_split_weights
@@ -19,7 +21,9 @@ class _WeightPlanes:
     "the parameters have changed" (optimizer step, checkpoint load, snapshot restore)."""
 
     def __init__(self):
-        self.enabled = os.environ.get('RSCOTR_WPLANES', '1') != '0'
+        # (round 5: with the fp16 split product on, the tiled kernels are as fast as the 128-row weight-plane kernel on its own
+        # shapes — 10880 x 256 x 2048: 72 us against 70 — and need no plane sets: the route is only taken with RSCOTR_GEMM_H3=0)
+        self.enabled = os.environ.get('RSCOTR_WPLANES', '1') != '0' and not RANGES.enabled
         self.min_m = int(os.environ.get('RSCOTR_WPLANES_MIN_M', 4096))
         self.min_k = int(os.environ.get('RSCOTR_WPLANES_MIN_K', 1024))
         self.version = 1
@@ -282,6 +286,7 @@ class _DeferredCombine:
         self.group_edge = int(os.environ.get('RSCOTR_DW_GROUP_EDGE', -48))  # members with min(M, N) >= |this| on the bf16x6 edge body: > 0 only the ragged ones (interior ones in a launch of their own), < 0 all of them in one launch, 0 none
         self.group_big_out = int(os.environ.get('RSCOTR_DW_GROUP_BIG_OUT', 32768))  # (variant 4: outputs from this many elements on)
         self.group, self.group_keep, self.group_cache = [], [], {}
+        self.group_amax, self.amax_cache = {}, {}  # operands of grouped problems whose value range is measured at the flush
         self.pinned_pool, self.pinned_live = [], []
         self.wattn_entries, self.wattn_cache = [], {}
 
@@ -299,10 +304,16 @@ class _DeferredCombine:
         combine entries).  Interior problems (M, N multiples of 128, aligned operands) go to the bf16x6 128 x 128 variant of
         the grouped kernel, the rest to the fp32 64 x 64 variant: one launch each."""
         import numpy as np
-        probs = self.group
+        probs = [p if len(p) == 13 else tuple(p) + (0, 0) for p in self.group]  # (+ the range slots of the two operands | 0)
 
         def kind(p):
-            a, b, _, _, _, M, N, K, lda, ldb, _ = p
+            k = kind6(p)
+            if k == 6 and p[11] and p[12] and RANGES.enabled:
+                return 7  # the same body as the fp16 split product: both operands carry their value range
+            return k
+
+        def kind6(p):
+            a, b, _, _, _, M, N, K, lda, ldb, _ = p[:11]
             if self.group_x6 == 4:  # fp32 pipe on 128 x 128 tiles where the output holds at least a few of them
                 return 4 if min(M, N) >= 96 and M * N >= self.group_big_out else 0
             ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
@@ -318,22 +329,22 @@ class _DeferredCombine:
             return 0
         kinds = [kind(p) for p in probs]
         tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else
-                 ((M + 127) // 128) * ((N + 127) // 128) if k in (4, 6) else ((M + 63) // 64) * ((N + 63) // 64)
-                 for k, (_, _, _, _, _, M, N, K, _, _, _) in zip(kinds, probs)]
+                 ((M + 127) // 128) * ((N + 127) // 128) if k in (4, 6, 7) else ((M + 63) // 64) * ((N + 63) // 64)
+                 for k, (_, _, _, _, _, M, N, K, _, _, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k), per
         # LAUNCH: with one target for the whole pass the few fp32 64 x 64 members of a det backward (the 4- and 20-row
         # reg / cls branches over K = 10880) inherited the k-slice of the big bf16x6 launch and ran as 160 workgroups of
         # K = 3632 each: 260 us for 0.1 GFLOP
         dev = self.group_keep[0].device
         launches, ents = [], []
-        for variant in (0, 2, 3, 4, 6):
-            work = sum(t * p[7] * (4 if k in (2, 4, 6) else 1) for t, k, p in zip(tiles, kinds, probs) if k == variant)
+        for variant in (0, 2, 3, 4, 6, 7):
+            work = sum(t * p[7] * (4 if k in (2, 4, 6, 7) else 1) for t, k, p in zip(tiles, kinds, probs) if k == variant)
             klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
             rows = []
-            for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper) in zip(tiles, kinds, probs):
+            for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper, sa, sb) in zip(tiles, kinds, probs):
                 if x6 != variant:
                     continue
-                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4, 6) else 1))))
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4, 6, 7) else 1))))
                 kq = 32 if x6 == 3 else int(os.environ.get('RSCOTR_X6_BK0', 16))  # (lab: the one-stage loop at 32 k per barrier pair)
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
@@ -341,7 +352,8 @@ class _DeferredCombine:
                     klen = K
                 slab = self.reserve(sp * (M * N + M) * 4, dev)
                 rs_slab = slab + sp * M * N * 4 if rs else 0
-                rows.append([a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, 0, max(kper, 1), 0, t * sp])
+                rng = ((RANGES.index(sa) + 1) << 32 | (RANGES.index(sb) + 1)) if x6 == 7 else 0
+                rows.append([a, b, slab, rs_slab, ks, M, N, K, lda, ldb, klen, sp, 0, max(kper, 1), rng, t * sp])
                 ents.append((slab, rs_slab, out, rs, M, N, N, sp))
             if rows:
                 # bundles of 8 problems of similar size, one problem per XCD (the kernel's id layout): largest first
@@ -370,11 +382,12 @@ class _DeferredCombine:
 
     def _upload(self, arr, dev):
         if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
-            assert arr.shape[0] <= 4096 and self.pinned_pool, 'DEFER.prepare_capture() must run before a capture'
+            assert arr.size <= 4096 * 16 and self.pinned_pool, 'DEFER.prepare_capture() must run before a capture'
             host = self.pinned_pool.pop()
-            host[:arr.shape[0]].copy_(torch.from_numpy(arr))
+            stage = host.view(-1)[:arr.size].view(arr.shape)  # (tables of any row width share the (4096, 16) staging buffers)
+            stage.copy_(torch.from_numpy(arr))
             d = torch.empty(arr.shape, dtype=torch.int64, device=dev)
-            d.copy_(host[:arr.shape[0]], non_blocking=True)
+            d.copy_(stage, non_blocking=True)
             self.pinned_live.append(host)
             return d
         return torch.from_numpy(arr).to(dev)
@@ -410,6 +423,7 @@ class _DeferredCombine:
         self.entries, self.notify, self.ln_entries = [], [], []
         self.keep = []
         self.group, self.group_keep = [], []
+        self.group_amax = {}
         self.wattn_entries = []
         self.cur = self.off = 0
 
@@ -443,7 +457,45 @@ class _DeferredCombine:
             lib.call('rscotr_layernorm_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
         self.ln_entries = []
 
+    def group_range(self, t, rows, cols, ld):
+        """Range slot of an operand of a grouped problem: what the tensor carries / the optimizer keeps, else a fresh slot
+        that ONE launch fills for all such operands right before the grouped product (`_flush_group`).  Such a slot is
+        not handed on with the tensor: nothing may read it before the flush."""
+        s = RANGES.slot_of(t)
+        if s:
+            return s
+        sink = STATE.grad_sink
+        if sink is not None and sink.is_param_ptr(t.data_ptr()):
+            return RANGES.of(t, rows, cols, ld)
+        key = (t.data_ptr(), rows, cols, ld)
+        s = self.group_amax.get(key)
+        if s is None:
+            s = self.group_amax[key] = RANGES.new_slot(t.device)
+            if os.environ.get('RSCOTR_TRACE_CALLS') == '1':
+                import sys
+                end = t.storage_offset() * 4 + ((rows - 1) * ld + cols) * 4
+                print(f'[group_range] {tuple(t.shape)} rows={rows} cols={cols} ld={ld} last byte {end} of storage {t.untyped_storage().nbytes()}'
+                      + ('  <-- OUT OF BOUNDS' if end > t.untyped_storage().nbytes() else ''), file=sys.stderr, flush=True)
+        return s
+
+    def _measure_group(self):
+        sig = tuple(self.group_amax.items())
+        hit = self.amax_cache.get(sig)
+        if hit is None:
+            import numpy as np
+            rows_, first = [], 0
+            for (ptr, rows, cols, ld), slot in self.group_amax.items():
+                rows_.append((ptr, rows, cols, ld, slot, first))
+                first += max(1, min(128, rows * cols // 65536))
+            hit = (self._upload(np.asarray(rows_, dtype=np.int64), self.group_keep[0].device), len(rows_), first)
+        self._remember(self.amax_cache, sig, hit)
+        lib.call('rscotr_amax_group', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        RANGES.stats['grouped'] = RANGES.stats.get('grouped', 0) + hit[1]
+        self.group_amax = {}
+
     def _flush_group(self):
+        if self.group_amax:
+            self._measure_group()
         sig = (tuple(self.group), self.cur, self.off)  # (the slab regions continue where this pass's reserves stand)
         hit = self.group_cache.get(sig)
         if hit is None:
@@ -453,7 +505,8 @@ class _DeferredCombine:
             self.cur, self.off = hit[2], hit[3]
         self._remember(self.group_cache, sig, hit)
         for table, n, total, variant, flops in hit[0]:
-            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, flops, _stream())
+            lib.call('rscotr_gemm_dw_group', table.data_ptr(), n, total, variant, flops, RANGES.base if variant == 7 else 0,
+                     _stream())
         self.entries.extend(hit[1])
         self.group, self.group_keep = [], []
 
@@ -529,6 +582,13 @@ def flush_deferred():
     PP.clear()  # (the plane sets of this pass: nothing of them is read after backward)
 
 
+def _dw_ranges(A, B, M, N, K, lda, ldb):
+    """Slots of the two k-major operands of a weight-gradient contraction (0, 0 when the fp16 product is off)."""
+    if not RANGES.enabled:
+        return 0, 0
+    return RANGES.of(A, K, M, lda), RANGES.of(B, K, N, ldb)
+
+
 def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
     """-> True if the contraction was issued as slabs for the deferred combine."""
     sink = STATE.grad_sink
@@ -540,8 +600,15 @@ def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
         return False
     if DEFER.group_enabled and DEFER.grouped_size(M, N, K) and K >= 16:
         # small output: joins the grouped launch at the end of backward (operands stay alive until then)
+        sa = sb = 0
+        if (K >= 512 and K % 16 == 0 and M % 4 == 0 and N % 4 == 0 and min(M, N) >= abs(DEFER.group_edge) and DEFER.group_edge
+                and DEFER.group_x6):  # (a member of the split-product launch, DEFER._plan_group: it wants the value ranges)
+            sa, sb = (DEFER.group_range(A, K, M, lda), DEFER.group_range(B, K, N, ldb)) if RANGES.enabled else (0, 0)
+            lo_r, hi_r = RANGES.base, RANGES.base + 4 * RANGES.STRIDE
+            if not (lo_r <= sa < hi_r and lo_r <= sb < hi_r):
+                sa = sb = 0
         DEFER.group.append((A.data_ptr(), B.data_ptr(), out.data_ptr(), _ptr(rowsum), _ptr(kscale), M, N, K, lda, ldb,
-                            int(krows_per)))
+                            int(krows_per), sa, sb))
         DEFER.group_keep.extend(t for t in (A, B, kscale) if t is not None)
         return True
     if nws == 0:
@@ -549,8 +616,11 @@ def _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws):
     import ctypes
     ptr = DEFER.reserve(nws, A.device)
     splits = ctypes.c_int32(1)
-    lib.call('rscotr_gemm_f32_dw_slabs', A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, _ptr(rowsum),
-             _ptr(kscale), int(krows_per), ptr, nws, ctypes.byref(splits), _stream())
+    sa = sb = 0
+    if RANGES.wanted(M, N, K, lda, ldb, 1, 1, ACT_NONE, False, False, kscale is not None, nws):
+        sa, sb = _dw_ranges(A, B, M, N, K, lda, ldb)
+    lib.call('rscotr_gemm_f32_dw_slabs_r', A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, _ptr(rowsum),
+             _ptr(kscale), int(krows_per), ptr, nws, ctypes.byref(splits), sa, sb, _stream())
     sp = splits.value
     if sp > 1:
         DEFER.entries.append((ptr, ptr + sp * M * N * 4 if rowsum is not None else 0, out.data_ptr(), _ptr(rowsum), M, N, N, sp))
@@ -667,6 +737,18 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
             and _try_defer_dw(A, B, out, M, N, K, lda, ldb, rowsum, kscale, krows_per, nws)):
         return out
     ws = _WS.get(nws, A.device).data_ptr() if nws else 0
+    if RANGES.enabled:
+        if not (amax_a and amax_b) and RANGES.wanted(M, N, K, lda, ldb, a_kmajor, b_kmajor, act, pre is not None,
+                                                     rowscale is not None, kscale is not None, nws):
+            # the split kernels take this product: with the value ranges of both operands it runs as the fp16 split product
+            amax_a = amax_a or (RANGES.of(A, K, M, lda) if a_kmajor else RANGES.of(A, M, K, lda))
+            amax_b = amax_b or (RANGES.of(B, K, N, ldb) if b_kmajor else RANGES.of(B, N, K, ldb))
+        if not amax_out and not _in_arena(out):
+            # the range of what this product stores rides out of its epilogue: whoever multiplies with it next finds it
+            amax_out = RANGES.new_slot(A.device)
+            RANGES.tag(out, amax_out)
+            if out2 is not None:
+                RANGES.tag(out2, amax_out)
     args = (A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, N, int(a_kmajor), int(b_kmajor),
             _ptr(bias), int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowsum),
             int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), _ptr(out2), ws, nws,
@@ -720,7 +802,7 @@ class _MLP(Function):
         n = len(wb) // 2
         ws, bs = wb[0::2], wb[1::2]
         K0 = x.shape[-1]
-        x2 = _f32c(x).reshape(-1, K0)
+        x2 = RANGES.carry(x, _f32c(x).reshape(-1, K0))
         M = x2.shape[0]
         id_is_x = identity is x  # mmcv FFN: identity defaults to the input itself
         rows_per = 0
@@ -753,16 +835,17 @@ class _MLP(Function):
                 hs.append(h)
                 auxs.append(pre if act == ACT_GELU else h)
         ctx.save_for_backward(*hs, *auxs, *ws)
+        ctx.h_slots = [RANGES.slot_of(t) for t in hs]  # (value ranges of the saved activations: the weight gradients want them)
         ctx.out_scale, ctx.rows_per = out_scale, rows_per
         ctx.n, ctx.act, ctx.has_id, ctx.id_is_x = n, act, identity is not None, id_is_x
         ctx.has_bias = [b is not None for b in bs]
         ctx.biases = bs  # parameter handles only (for the gradient sink); not needed as saved tensors
         ctx.x_shape = x.shape
         ctx.id_shape = None if identity is None else identity.shape
-        out = h.view(*x.shape[:-1], h.shape[-1])
+        out = RANGES.carry(h, h.view(*x.shape[:-1], h.shape[-1]))
         if y2 is None:
             return out
-        y2 = y2.view(out.shape)
+        y2 = RANGES.carry(y2, y2.view(out.shape))
         ctx.mark_non_differentiable(y2)
         ctx.set_materialize_grads(False)
         ctx.two_outputs = True
@@ -776,7 +859,9 @@ class _MLP(Function):
         saved = ctx.saved_tensors
         hs, auxs, ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
         M = hs[0].shape[0]
-        g = _f32c(dy).reshape(M, -1)
+        for t, sl in zip(hs, ctx.h_slots):
+            RANGES.tag(t, sl)
+        g = RANGES.carry(dy, _f32c(dy).reshape(M, -1))
         g_out = g
         d_id = g.view(ctx.id_shape) if ctx.has_id and not ctx.id_is_x and ctx.needs_input_grad[1] else None
         grads_wb = [None] * (2 * n)
@@ -822,7 +907,8 @@ class _MLP(Function):
                 g = gemm(g, W, M, K, N, N, K, 0, 1, act=gact, aux=auxs[i - 1], **scr)  # dH = (g W) * act'
             elif ctx.needs_input_grad[0]:
                 # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
-                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr).view(ctx.x_shape)
+                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr)
+                dx = RANGES.carry(dx, dx.view(ctx.x_shape))
         return (dx, d_id, None, None, None, *grads_wb)
 
 

@@ -4,6 +4,7 @@ from torch.autograd import Function
 
 from .core import _WS, _Prof, _chk, _f32c, _ptr, _sink, _stream, lib
 from .matmul import DEFER
+from .ranges import RANGES
 from .state import STATE
 
 LN_EPS = 1e-5
@@ -19,12 +20,13 @@ class _LayerNorm(Function):
         y = torch.empty_like(x2)
         stats = torch.empty((2, M), dtype=torch.float32, device=x2.device)
         with _Prof('layernorm_fwd', 8 * M * C):
+            slot = RANGES.out_slot(x2.device)
             lib.call('rscotr_layernorm_fwd', x2.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
-                     stats[1].data_ptr(), M, C, float(eps), _stream())
+                     stats[1].data_ptr(), M, C, float(eps), slot, _stream())
         ctx.save_for_backward(x2, w, stats)
         ctx.has_b = b is not None
         ctx.bias = b
-        return y.view(x.shape)
+        return RANGES.tag(y.view(x.shape), slot)
 
     @staticmethod
     def backward(ctx, dy, dres=None):
@@ -42,6 +44,7 @@ class _LayerNorm(Function):
         g = _f32c(dy).reshape(M, C)
         r = None if dres is None else _f32c(dres).reshape(M, C)  # residual-branch gradient, added inside the kernel
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        slot = RANGES.out_slot(x2.device) if dx is not None else 0  # (the range of dx: the next backward multiplies with it)
         skw, skb = _sink(w), _sink(ctx.bias)
         direct = skw is not None and (skb is not None or not ctx.has_b)
         dwb = None if direct else torch.zeros((2, C), dtype=torch.float32, device=x2.device)
@@ -53,7 +56,7 @@ class _LayerNorm(Function):
         if merge is not None:
             ws_ptr = DEFER.reserve(nws, x2.device) if defer else _WS.get(nws, x2.device).data_ptr()
             lib.call('rscotr_patch_merge_norm_bwd', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
-                     stats[1].data_ptr(), _ptr(dx), dw_ptr, db_ptr, *merge, ws_ptr, nws, 0 if defer else 1, _stream())
+                     stats[1].data_ptr(), _ptr(dx), dw_ptr, db_ptr, *merge, ws_ptr, nws, 0 if defer else 1, slot, _stream())
             if defer:
                 DEFER.ln_entries.append((ws_ptr, dw_ptr, db_ptr, nws // (8 * C), C))
         elif defer:
@@ -61,19 +64,19 @@ class _LayerNorm(Function):
             # all ~55 LayerNorms of a backward pass instead of one each)
             part = DEFER.reserve(nws, x2.device)
             lib.call('rscotr_layernorm_bwd_partials', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
-                     stats[1].data_ptr(), _ptr(dx), _ptr(r), M, C, part, nws, _stream())
+                     stats[1].data_ptr(), _ptr(dx), _ptr(r), M, C, part, nws, slot, _stream())
             DEFER.ln_entries.append((part, dw_ptr, db_ptr, nws // (8 * C), C))
         else:
             ws = _WS.get(nws, x2.device)
             with _Prof('layernorm_bwd', 12 * M * C):
                 lib.call('rscotr_layernorm_bwd', g.data_ptr(), x2.data_ptr(), _ptr(w), stats[0].data_ptr(),
-                         stats[1].data_ptr(), _ptr(dx), _ptr(r), dw_ptr, db_ptr, M, C, ws.data_ptr(), nws, _stream())
+                         stats[1].data_ptr(), _ptr(dx), _ptr(r), dw_ptr, db_ptr, M, C, ws.data_ptr(), nws, slot, _stream())
         if defer:
             STATE.grad_sink.grad_written(skw[0])
             if ctx.has_b:
                 STATE.grad_sink.grad_written(skb[0])
-            return (None if dx is None else dx.view(dx_shape)), None, None, None
-        dxv = None if dx is None else dx.view(dx_shape)
+            return (None if dx is None else RANGES.tag(dx.view(dx_shape), slot)), None, None, None
+        dxv = None if dx is None else RANGES.tag(dx.view(dx_shape), slot)
         if direct:  # dgamma / dbeta were accumulated straight into the gradient arena
             STATE.grad_sink.grad_written(skw[0])
             if ctx.has_b:
@@ -120,12 +123,13 @@ class _LayerNormSum(Function):
         y, y2 = torch.empty_like(x2), torch.empty_like(x2)
         stats = torch.empty((2, M), dtype=torch.float32, device=x2.device)
         with _Prof('layernorm_fwd', 16 * M * C):
+            slot = RANGES.out_slot(x2.device)
             lib.call('rscotr_layernorm_fwd_sum', x2.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
-                     stats[1].data_ptr(), a2.data_ptr(), rows, y2.data_ptr(), M, C, float(eps), _stream())
+                     stats[1].data_ptr(), a2.data_ptr(), rows, y2.data_ptr(), M, C, float(eps), slot, _stream())
         ctx.save_for_backward(x2, w, stats)
         ctx.has_b = b is not None
         ctx.bias = b
-        y, y2 = y.view(x.shape), y2.view(x.shape)
+        y, y2 = RANGES.tag(y.view(x.shape), slot), RANGES.tag(y2.view(x.shape), slot)  # (one word bounds both outputs)
         ctx.mark_non_differentiable(y2)
         ctx.set_materialize_grads(False)   # (no zero-filled stand-in for the sum's absent gradient)
         ctx.out_shape = tuple(x.shape)
@@ -153,11 +157,12 @@ class _PatchMergeNorm(Function):
         y = torch.empty((B, Ho * Wo, C), dtype=torch.float32, device=x3.device)
         stats = torch.empty((2, M), dtype=torch.float32, device=x3.device)
         with _Prof('layernorm_fwd', 8 * M * C):
+            slot = RANGES.out_slot(x3.device)
             lib.call('rscotr_patch_merge_norm_fwd', x3.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
-                     stats[1].data_ptr(), B, H, W, Cin, float(eps), _stream())
+                     stats[1].data_ptr(), B, H, W, Cin, float(eps), slot, _stream())
         ctx.save_for_backward(x3, w, stats)
         ctx.has_b, ctx.bias, ctx.merge = b is not None, b, (B, H, W, Cin)
-        return y
+        return RANGES.tag(y, slot)
 
     @staticmethod
     def backward(ctx, dy):

@@ -1,0 +1,180 @@
+"""Value ranges of GEMM operands for the fp16 split product (`rscotr_gemm_f32_r`, include/rscotr.h).
+
+The split product scales each operand by a power of two taken from the bit pattern of max |x| over the tensor — a device
+word ("slot") that whoever PRODUCED the tensor writes next to it: the epilogue of the product that computed it (`amax_out`),
+the LayerNorm kernels, the optimizer for parameters (`FlatAdamW.seg_amax`).  A tensor whose producer writes no slot is
+measured by one launch of `rscotr_amax_f32` on first use.
+
+A slot travels WITH the tensor object (attribute `_rs_amax` = (generation, slot address)): a new tensor at a recycled
+address has no attribute, and autograd nodes hand slots on explicitly (ctx fields) — nothing is looked up by address.  Any
+upper bound of the true maximum is a correct range (the scaled maximum sits 8 x below fp16's largest value, 26 binades above
+the point where precision starts to taper), so the slot of a whole tensor also serves its row / column blocks.
+
+Slots are words of ONE device buffer handed out in call order and zeroed by one memset at the start of an iteration
+(`RANGES.begin()`, called by `MTL.forward`): the sequence — and with it every address baked into a captured hipGraph — is
+the same in every iteration of a task.  `begin()` starts a new generation: a tensor that outlives an iteration (cached
+positional encodings, static graph inputs) is measured again in the next one."""
+import os
+
+import torch
+
+from .core import _stream, lib
+from .state import STATE
+
+
+class _Ranges:
+    PLANES, STRIDE = 32, 1 << 14  # RSCOTR_RANGE_PLANES / RSCOTR_RANGE_STRIDE of include/rscotr.h: a word = 32 sub-words
+
+    def __init__(self):
+        # Opt-in (RSCOTR_GEMM_H3=1): measured on the step (profiles/r5_h3_*.txt), the fp16 split product takes 1.2 ms per round
+        # off the GEMM kernels (15.6 against 16.8 ms, 7 %; 15-27 % per launch with cold operands in the lab, 20-45 % with warm
+        # ones) at a lower error than the six-term bf16 product — and the range bookkeeping (about 120 measuring launches, the
+        # grouped measuring launch, the atomics of the producers' epilogues) gives 1.4 ms back: the step's split kernels are
+        # bound by cold-operand latency and epilogue traffic, not by MFMA issue.  Off, every hook below is a no-op.
+        self.enabled = os.environ.get('RSCOTR_GEMM_H3', '0') != '0'
+        self.buf = None
+        self.base = 0
+        self.n = 0
+        self.gen = 1
+        self.route = {}
+        self.check = os.environ.get('RSCOTR_RANGES_CHECK') == '1'
+        self.log = os.environ.get('RSCOTR_RANGES_STATS') == '1'
+        self.sites = {}
+        self.stats = dict(measured=0, carried=0, params=0)
+
+    # ---- slots
+    def _ensure(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros((self.PLANES, self.STRIDE), dtype=torch.int32, device=device)
+            self.base = self.buf.data_ptr()
+            self.n = 0
+            self.dyn = self.STRIDE  # words [dyn, STRIDE) belong to the optimizer (parameters: never zeroed here)
+
+    def param_region(self, n, device):
+        """-> address of n consecutive words that begin() leaves alone (FlatAdamW keeps the parameters' ranges there; their
+        sub-words 1.. stay zero, sub-word 0 is what the optimizer kernels write)."""
+        self._ensure(device)
+        assert n < self.STRIDE // 2, 'too many parameter tensors for the range buffer'
+        self.dyn = self.STRIDE - n
+        self.buf[:, self.dyn:].zero_()
+        return self.base + 4 * self.dyn
+
+    def begin(self, device=None):
+        """Start of an iteration: every slot free and zero (one memset on the current stream)."""
+        if not self.enabled:
+            return
+        if self.log and any(self.stats.values()):
+            import sys
+            print(f'[ranges] previous iteration: {self.stats}, slots {self.n}', file=sys.stderr, flush=True)
+            for k, v in sorted(self.sites.items(), key=lambda kv: -kv[1]):
+                print(f'[ranges]   measured {v:4d} x  {k}', file=sys.stderr, flush=True)
+            self.sites = {}
+            self.stats = {k: 0 for k in self.stats}
+        if self.buf is None:
+            if device is None or device.type != 'cuda':
+                return
+            self._ensure(device)
+        elif self.n:
+            self._zero()
+        self.n = 0
+        self.gen += 1
+
+    def _zero(self):
+        # (one launch: the used words of all planes; at least 1024 so that the shape — and the captured node — is stable)
+        self.buf[:, :min(self.dyn, max(1024, (self.n + 1023) // 1024 * 1024))].zero_()
+
+    def new_slot(self, device):
+        """Address of a fresh (zero) slot."""
+        self._ensure(device)
+        if self.n >= self.dyn:  # (only code that never calls begin(): op-level tests, long eager loops)
+            self._zero()
+            self.n = 0
+            self.gen += 1
+        self.n += 1
+        return self.base + 4 * (self.n - 1)
+
+    def out_slot(self, device):
+        """A fresh slot for a producer's output, or 0 when ranges are off (producers then skip the bookkeeping)."""
+        return self.new_slot(device) if self.enabled else 0
+
+    def index(self, slot):
+        return (slot - self.base) // 4
+
+    # ---- tensors
+    def tag(self, t, slot):
+        """`slot` holds (or will hold, in stream order) an upper bound of max |t|."""
+        if slot and t is not None:
+            t._rs_amax = (self.gen, slot)
+        return t
+
+    def slot_of(self, t):
+        a = getattr(t, '_rs_amax', None)
+        return a[1] if a is not None and a[0] == self.gen else 0
+
+    def carry(self, src, dst):
+        """dst is a view / reshape / alias of src (same values): hand the slot on."""
+        a = getattr(src, '_rs_amax', None)
+        if a is not None and dst is not src:
+            dst._rs_amax = a
+        return dst
+
+    def of(self, t, rows, cols, ld, ptr=None):
+        """-> slot address with an upper bound of max |t[r, c]|, r < rows, c < cols, row stride ld (at `ptr`, default the
+        tensor's first element): carried by the tensor, kept by the optimizer for parameters, or measured now."""
+        s = self.slot_of(t)
+        if s:
+            self.stats['carried'] += 1
+            if self.check:
+                self._verify(t, rows, cols, ld, t.data_ptr() if ptr is None else ptr, s, 'carried')
+            return s
+        p = t.data_ptr() if ptr is None else ptr
+        sink = STATE.grad_sink
+        if sink is not None and sink.is_param_ptr(p):
+            s = sink.amax_slot(p)
+            if s:
+                self.stats['params'] += 1
+                if self.check:
+                    self._verify(t, rows, cols, ld, p, s, 'parameter')
+                return s
+        s = self.new_slot(t.device)
+        lib.call('rscotr_amax_f32', p, rows, cols, ld, s, _stream())
+        self.stats['measured'] += 1
+        if self.log:
+            import traceback
+            fr = [f for f in traceback.extract_stack(limit=12) if 'ranges.py' not in f.filename and f.name not in ('gemm', '_dw_ranges', '_try_defer_dw')]
+            key = ' < '.join(f'{f.name}:{f.lineno}' for f in reversed(fr[-4:]))
+            self.sites[key] = self.sites.get(key, 0) + 1
+        if ptr is None or ptr == t.data_ptr():
+            t._rs_amax = (self.gen, s)
+        return s
+
+    def _verify(self, t, rows, cols, ld, p, slot, what):
+        """RSCOTR_RANGES_CHECK=1 (debugging aid, synchronises): the slot a tensor carries must bound what it holds NOW."""
+        probe = torch.zeros((self.PLANES, self.STRIDE), dtype=torch.int32, device=t.device)
+        lib.call('rscotr_amax_f32', p, rows, cols, ld, probe.data_ptr(), _stream())
+        torch.cuda.current_stream().synchronize()
+        idx = (slot - self.base) // 4
+        assert 0 <= idx < self.STRIDE and self.buf is not None, 'a range word outside the range buffer'
+        bound = max(int(v) & 0xffffffff for v in self.buf[:, idx].tolist())
+        actual = max(int(v) & 0xffffffff for v in probe.view(-1)[::self.STRIDE].tolist())
+        self.stats['checked'] = self.stats.get('checked', 0) + 1
+        if actual > bound:
+            import struct
+            f = lambda u: struct.unpack('f', struct.pack('I', u))[0]
+            raise AssertionError(f'stale value range ({what}): the tensor of shape {tuple(t.shape)} holds max |x| = {f(actual)} '
+                                 f'but its slot says {f(bound)}')
+
+    # ---- routing
+    def wanted(self, M, N, K, lda, ldb, a_kmajor, b_kmajor, act, has_pre, has_rowscale, has_kscale, nws):
+        """Does rscotr_gemm_f32 run this product on the split kernels (where the ranges buy the fp16 product)?"""
+        if not self.enabled:
+            return False
+        key = (M, N, K, lda, ldb, a_kmajor, b_kmajor, act, has_pre, has_rowscale, has_kscale, nws, lib.rscotr_gemm_get_precision())
+        r = self.route.get(key)
+        if r is None:
+            r = self.route[key] = bool(lib.rscotr_gemm_f32_split_route(M, N, K, lda, ldb, int(a_kmajor), int(b_kmajor), int(act),
+                                                                       int(has_pre), int(has_rowscale), int(has_kscale), nws))
+        return r
+
+
+RANGES = _Ranges()

@@ -139,6 +139,13 @@ class FlatAdamW:
         self.seg_dyn = torch.zeros((n, 8), dtype=torch.float32, device=device)
         self._dyn_event = None
         self.sumsq = torch.zeros(1 + 1024, dtype=torch.float32, device=device)  # [0] = total, [1:] = partials
+        # value ranges of the parameters (bit pattern of max |w| per tensor) for the fp16 split product of the GEMMs:
+        # refreshed by the update kernel for every tensor it steps, recomputed from the arena after any other change
+        # (words of the operator layer's range buffer, ops.RANGES: one per parameter tensor, at the top of the buffer)
+        self.seg_amax_ptr = ops.RANGES.param_region(max(n, 1), device) if device.type == 'cuda' else 0
+        self._seg_order = np.argsort(np.asarray(self.offsets, dtype=np.int64), kind='stable')
+        self._seg_starts = np.asarray(self.offsets, dtype=np.int64)[self._seg_order]
+        self.amax_dirty = True
         # gradient-ready notifications: autograd's AccumulateGrad (post hook) or the direct-write path
         # of rscotr_amd.ops (GRAD_SINK) both end in _on_ready(i)
         self.ready_callbacks = []
@@ -165,6 +172,26 @@ class FlatAdamW:
         """Does `ptr` point into the flat parameter arena (a parameter, or a slice of one)?"""
         base = self.flat_p.data_ptr()
         return base <= ptr < base + self.flat_p.numel() * 4
+
+    def params_changed(self):
+        """The arena was written by something other than the update kernel (checkpoint load, restore, state-dict copy)."""
+        self.amax_dirty = True
+
+    def refresh_amax(self):
+        if self.device.type == 'cuda':
+            lib.call('rscotr_param_amax', self.flat_p.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
+                     self.chunk_len.data_ptr(), self.nchunks, self.seg_amax_ptr, len(self.groups), ops._stream())
+        self.amax_dirty = False
+
+    def amax_slot(self, ptr):
+        """Address of the value-range word of the parameter that holds arena address `ptr` (0: not a parameter's memory)."""
+        off = (ptr - self.flat_p.data_ptr()) // 4
+        if not 0 <= off < self.total:
+            return 0
+        if self.amax_dirty:
+            self.refresh_amax()
+        k = int(np.searchsorted(self._seg_starts, off, side='right')) - 1
+        return self.seg_amax_ptr + 4 * int(self._seg_order[k])
 
     def grad_view(self, tensor):
         """-> (index, view of the gradient arena shaped like `tensor`) if `tensor` IS a registered
@@ -248,10 +275,12 @@ class FlatAdamW:
             lib.call('rscotr_grad_sumsq', self.flat_g.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
                      self.chunk_len.data_ptr(), self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), s)
         ops.WPLANES.bump()  # the parameters change: their pre-split planes are stale from here on
-        lib.call('rscotr_adamw_clip_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+        if self.amax_dirty:  # (the words of the tensors this step does not touch must be valid too)
+            self.refresh_amax()
+        lib.call('rscotr_adamw_clip_step_r', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                  self.flat_v.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(), self.chunk_len.data_ptr(),
                  self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), self.max_norm, float(b1), float(b2),
-                 float(self.eps), s)
+                 float(self.eps), self.seg_amax_ptr, len(self.groups), s)
 
     def step(self):
         self.prepare_step()
@@ -280,11 +309,13 @@ class FlatAdamW:
 
     def restore(self, snap):
         ops.WPLANES.bump()
+        self.amax_dirty = True
         self.flat_p.copy_(snap['p'])
         self.flat_m.copy_(snap['m'])
         self.flat_v.copy_(snap['v'])
         self.steps[:] = snap['steps']
         self.live[:] = snap['live']
+        self.refresh_amax()  # (now, not lazily: the next thing may be a hipGraph capture, which would record the refresh)
 
 
 

@@ -50,7 +50,12 @@ def _recover_from_failed_capture(graph, cause=None):
                            f'RSCOTR_DIST_CAPTURE=0 (graph = forward + backward, eager exchange).  Cause: {cause}') from cause
 
 
-def _wait_watchdog_idle(limit=2.0):
+def _sync_works_only(sync):
+    from .dist import INLINE
+    return INLINE or (sync is not None and sync.comm is not None)
+
+
+def _wait_watchdog_idle(limit=2.0, sync_only=None):
     """Block until the RCCL process group's watchdog has RETIRED every collective issued so far (call after a device
     synchronise, before a stream goes into capture).  The watchdog polls the end events of its pending works, and HIP refuses
     an event query ("operation not permitted on an event last recorded in a capturing stream") while the stream the event
@@ -76,8 +81,8 @@ def _wait_watchdog_idle(limit=2.0):
     else:
         cause = None
     from .dist import INLINE
-    if not INLINE:
-        # the overlapped exchange leaves asynchronous works with the watchdog: guessing when it has dropped their events is
+    if not (INLINE if sync_only is None else sync_only):
+        # the overlapped exchange THROUGH c10d leaves asynchronous works with the watchdog: guessing when it has dropped their events is
         # not good enough (a wrong guess aborts the process from the watchdog thread in the middle of a capture)
         raise RuntimeError('capturing the overlapped gradient exchange (RSCOTR_DIST_INLINE=0) needs c10d\'s flight recorder to '
                            'tell when the RCCL watchdog is idle, and it is not available (TORCH_NCCL_TRACE_BUFFER_SIZE=0?'
@@ -116,7 +121,8 @@ class GraphedTask:
                 # collective sequence (see IterBasedRunner._train_iter)
                 import torch.distributed as dist
                 need = torch.tensor([max([int(l.shape[0]) for l in batch['gt_labels']] + [1])], device=batch['img'].device)
-                dist.all_reduce(need, op=dist.ReduceOp.MAX)
+                from .dist import control_all_reduce
+                control_all_reduce(need, dist.ReduceOp.MAX)
                 gcap = _round_up(max(int(need.item()), 32), 32)
             self.det_static = DetStatic(self.model.bbox_head, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
                                         batch['img'].device, gcap=gcap, gt_host=_gt_host(batch))
@@ -180,7 +186,8 @@ class GraphedTask:
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.static['img'].device)
         import torch.distributed as dist
         torch.cuda.synchronize()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        from .dist import control_all_reduce
+        control_all_reduce(ok, dist.ReduceOp.MIN)
         if os.environ.get('RSCOTR_TEST_CAPTURE_VETO') == '1':  # test hook: "another rank's capture failed" (tests/test_dist_gpu.py)
             ok.zero_()
         if int(ok.item()) == 1:
@@ -198,8 +205,8 @@ class GraphedTask:
         self._warm_and_capture()
         steps = torch.tensor([float(self.opt.steps.sum())], dtype=torch.float64, device=self.static['img'].device)
         lo, hi = steps.clone(), steps.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        control_all_reduce(lo, dist.ReduceOp.MIN)
+        control_all_reduce(hi, dist.ReduceOp.MAX)
         if float(lo.item()) != float(hi.item()):
             raise RuntimeError(f'optimizer step counts differ between the ranks after the capture fallback ({lo.item()} / {hi.item()})')
 
@@ -230,7 +237,11 @@ class GraphedTask:
                 side.synchronize()  # the pinned optimizer table is refilled by the next prepare_step()
             torch.cuda.synchronize()
             if self.runner.sync is not None:
-                self.watchdog_wait = _wait_watchdog_idle()
+                # c10d's watchdog must have retired the warm-ups' works (the det normalisers, plan checks: synchronous
+                # collectives whose end events sit on THIS stream) before the stream starts capturing: it may not query them
+                # afterwards.  With the overlapped exchange on its own communicator (dist.DirectComm) these are the only
+                # c10d works there are — as in the inline form.
+                self.watchdog_wait = _wait_watchdog_idle(sync_only=_sync_works_only(self.runner.sync))
             self.opt.restore(snap)
             self.graph = torch.cuda.CUDAGraph()
             self.opt.prepare_step(self.table)
@@ -284,23 +295,30 @@ class GraphedTask:
                 ops.side_join()
                 ops.side_enable(False)
         ops.flush_deferred()  # one combine launch for every split-K weight gradient of this backward pass
-        log_work = None
+        log_work, log_direct = None, False
         if sync is not None:
             sync.finish_step(self.task)  # leftover buckets in the fixed order, then the waits (event edges in the graph)
             import torch.distributed as dist
             # rank-averaged log variables (multitask_learner.py:299-304): same place in the collective sequence as on every
             # other path (after the buckets), but nothing on the compute queue depends on it — clip + AdamW are queued
             # first and the wait comes last, so the queue hand-over to RCCL and back is off the critical path
-            self.packed = self.packed / dist.get_world_size()
             from .dist import INLINE
             if INLINE:
+                self.packed = self.packed / dist.get_world_size()
                 dist.all_reduce(self.packed)  # (on the compute stream: the captured iteration stays one chain)
+            elif sync.comm is not None:
+                self.packed = self.packed.contiguous()
+                sync.allreduce_avg_async(self.packed)  # (the exchange's own communicator: no c10d work inside the capture)
+                log_direct = True
             else:
+                self.packed = self.packed / dist.get_world_size()
                 log_work = dist.all_reduce(self.packed, async_op=True)
         if not self.split:
             self.opt.launch_step(self.table)
         if log_work is not None:
             log_work.wait()
+        if log_direct:
+            sync.wait()
 
     def _finish(self):
         if self.split:
@@ -365,9 +383,9 @@ class IterBasedRunner:
         self.ctrl = None
         if self.sync is not None:
             import torch.distributed as dist
-            if dist.get_world_size() > 1:
-                self.ctrl = dist.new_group(backend='gloo')
-                ops.set_host_group(self.ctrl)  # (the det normalisers are averaged through it too: rscotr_amd.det_head.DetStatic)
+            # (also for the one-rank group of RSCOTR_DIST_SINGLE=1: the control traffic must take the same road as on N ranks)
+            self.ctrl = dist.new_group(backend='gloo')
+            ops.set_host_group(self.ctrl)  # (the det normalisers are averaged through it too: rscotr_amd.det_head.DetStatic)
         self.rnd_fn = rnd_fn
         # tasks whose iteration is replayed from a hipGraph (RSCOTR_GRAPHS=0 disables)
         if graph_tasks is None:

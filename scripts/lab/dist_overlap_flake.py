@@ -13,5 +13,5 @@ for i in range(n):
     print(f'run {i}: {"ok" if ok else "FAILED rc=%d" % r.returncode}', flush=True)
     if not ok:
         bad += 1
-        print(r.stderr[-1500:], flush=True)
+        print('\n'.join(l for l in r.stderr.splitlines() if 'rror' in l or 'HIP' in l)[:3000], flush=True)
 print(f'{bad} of {n} failed')

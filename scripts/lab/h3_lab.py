@@ -9,6 +9,7 @@ from rscotr_amd import ops  # noqa: E402
 from rscotr_amd._lib import lib  # noqa: E402
 
 dev = torch.device('cuda:0')
+ops.RANGES.enabled = False  # (ranges are passed explicitly below)
 
 
 def t(fn, n=30):
@@ -25,9 +26,10 @@ def t(fn, n=30):
 
 
 def amax(x):
-    slot = torch.zeros(1, dtype=torch.int32, device=dev)
-    lib.call('rscotr_amax_f32', x.data_ptr(), x.shape[0], x.shape[1], x.shape[1], slot.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert float(slot.view(torch.float32)) == float(x.abs().max()), (float(slot.view(torch.float32)), float(x.abs().max()))
+    slot = ops.RANGES.new_slot(dev)
+    lib.call('rscotr_amax_f32', x.data_ptr(), x.shape[0], x.shape[1], x.shape[1], slot, torch.cuda.current_stream().cuda_stream)
+    got = ops.RANGES.buf[:, ops.RANGES.index(slot)].view(torch.float32).max()
+    assert float(got) == float(x.abs().max()), (float(got), float(x.abs().max()))
     return slot
 
 
@@ -58,7 +60,7 @@ for M, N, K, ak, bk, tag in shapes:
         def err(o):
             return float((o.double() - ref).abs().max() / ref.abs().max())
         o6 = ops.gemm(A, B, M, N, K, lda, ldb, ak, bk)
-        oh = ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA.data_ptr(), amax_b=sB.data_ptr())
+        oh = ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA, amax_b=sB)
         prev = lib.rscotr_gemm_get_precision()
         lib.rscotr_gemm_set_precision(0)
         o32 = ops.gemm(A, B, M, N, K, lda, ldb, ak, bk)
@@ -66,9 +68,15 @@ for M, N, K, ak, bk, tag in shapes:
         lib.rscotr_gemm_set_precision(prev)
         r['err_x6'], r['err_h3'], r['err_f32'] = err(o6), err(oh), err(o32)
         r['us_x6'] = t(lambda: ops.gemm(A, B, M, N, K, lda, ldb, ak, bk))
-        r['us_h3'] = t(lambda: ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA.data_ptr(), amax_b=sB.data_ptr()))
+        r['us_h3'] = t(lambda: ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA, amax_b=sB))
         r['us_f32'] = t32
-        r['us_amax_a'] = t(lambda: lib.call('rscotr_amax_f32', A.data_ptr(), A.shape[0], A.shape[1], A.shape[1], sA.data_ptr(),
+        so = ops.RANGES.new_slot(dev)
+        r['us_h3_out'] = t(lambda: ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA, amax_b=sB, amax_out=so))
+        def cold():  # (a fresh, zero slot each time: every wavefront's atomic lands)
+            ops.RANGES.buf[:, ops.RANGES.index(so)].zero_()
+            ops.gemm(A, B, M, N, K, lda, ldb, ak, bk, amax_a=sA, amax_b=sB, amax_out=so)
+        r['us_h3_out_cold'] = t(cold) - t(lambda: ops.RANGES.buf[:, ops.RANGES.index(so)].zero_())
+        r['us_amax_a'] = t(lambda: lib.call('rscotr_amax_f32', A.data_ptr(), A.shape[0], A.shape[1], A.shape[1], sA,
                                             torch.cuda.current_stream().cuda_stream))
         r['speedup'] = r['us_x6'] / r['us_h3']
         print(json.dumps({k: (float(f'{v:.3g}') if isinstance(v, float) else v) for k, v in r.items()}), flush=True)

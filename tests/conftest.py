@@ -25,6 +25,15 @@ def cuda():
     return torch.device('cuda:0')
 
 
+@pytest.fixture
+def gemm_precision():
+    """Restores the process-wide precision mode of the tiled GEMM (include/rscotr.h: rscotr_gemm_set_precision)."""
+    from rscotr_amd._lib import lib
+    old = lib.rscotr_gemm_get_precision()
+    yield lambda m: lib.call('rscotr_gemm_set_precision', m)
+    lib.call('rscotr_gemm_set_precision', old)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # The parity suite must test what ships (VERDICT r2, weak item 1: a test that left the MSDA backward strategy changed made
 # every later whole-step test run a non-default kernel).  Before EVERY test — ahead of the test's own fixtures, which may
@@ -43,6 +52,7 @@ def _product_state():
               defer=(ops.DEFER.enabled, ops.DEFER.group_enabled, ops.DEFER.group_x6, ops.DEFER.pin),
               wplanes=(ops.WPLANES.enabled, ops.WPLANES.min_m, ops.WPLANES.min_k),
               pp=(ops.PP.enabled, ops.PP.min_rows, ops.PP.min_work, ops.PP.max_split, ops.PP.min_tiles, ops.PP.min_n),
+              ranges=(ops.RANGES.enabled, ops.RANGES.check),
               env=tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('RSCOTR_'))))
     if os.path.exists(LIB_PATH):
         st['gemm_precision'] = int(lib.rscotr_gemm_get_precision())

@@ -312,15 +312,6 @@ def test_layernorm_fork(cuda, M, C):
     assert torch.equal(x2.grad, gr.to(cuda))
 
 
-@pytest.fixture
-def gemm_precision():
-    """Restores the process-wide precision mode of the tiled GEMM (include/rscotr.h: rscotr_gemm_set_precision)."""
-    from rscotr_amd._lib import lib
-    old = lib.rscotr_gemm_get_precision()
-    yield lambda m: lib.call('rscotr_gemm_set_precision', m)
-    lib.call('rscotr_gemm_set_precision', old)
-
-
 @pytest.mark.parametrize('M,N,K,ak,bk', [(2048, 1024, 256, 0, 0), (2048, 1024, 256, 0, 1), (2048, 1024, 96, 0, 0),
                                          (4096, 512, 2048, 0, 0), (4096, 512, 2048, 0, 1),
                                          (300, 200, 1024, 0, 0), (256, 512, 4096, 1, 1), (1000, 768, 3072, 1, 0), (2048, 1024, 128, 1, 0),
