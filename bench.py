@@ -27,8 +27,9 @@ CFG = os.path.join(ROOT, 'configs', 'multi', 'MTL_slvlcls_swin-t-p4-w7_1x1_resis
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (= fp32 vector) peak, dense
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA peak, dense (no sparsity)
-# gemm_bf16x3_big_kernel issues three bf16 MFMAs per fp32-equivalent product ("count 3x MFMA issue")
-BF16X3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
+# the fp16 split product (opt-in, RSCOTR_GEMM_H3=1: gemm_h3_*_kernel) issues three fp16 MFMAs per fp32-equivalent product
+# (price a split product by its MFMA issues; fp16 and bf16 MFMAs share the 2.5 PFLOP/s dense peak)
+H3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 # gemm_bf16x6_kernel (precision mode 3, fp32-accurate): six bf16 MFMAs per fp32-equivalent product
 BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 PROF_EVERY_GEMM = 1  # every GEMM launch of the roofline rounds carries a pair of HIP events (1 in 4 made the choice of the dominant instantiation depend on which launches were drawn)
@@ -328,7 +329,7 @@ def main():
         name = ctypes.create_string_buffer(128)
         for i in range(n):
             lib.call('rscotr_prof_get', i, ctypes.byref(kind), ctypes.byref(work), ctypes.byref(ms), name, 128)
-            prof.append(dict(kind=('gemm', 'msda_fwd', 'msda_bwd')[kind.value], work=work.value, sec=ms.value * 1e-3,
+            prof.append(dict(kind=('gemm', 'msda_fwd', 'msda_bwd', 'hbm', 'mfma')[kind.value], work=work.value, sec=ms.value * 1e-3,
                              name=name.value.decode()))
         lib.call('rscotr_prof_disable')
     if world > 1:
@@ -362,25 +363,32 @@ def main():
         # dominant kernel of the step = the fp32 MFMA GEMM family; report the instantiation that takes the
         # most time, the whole family next to it
         gg = group('gemm')
+        # (the fused attention core reports through the GEMM kind with DENSE-equivalent flops — fully masked tiles are skipped by
+        # the kernel — and has its own two lines below: it stays out of the GEMM family's sums)
+        ga = {k: v for k, v in gg.items() if 'attn_' in k}
+        gg = {k: v for k, v in gg.items() if 'attn_' not in k}
         r_gemm, fam = None, None
 
         def is_x6(k):  # kernels whose inner product is the six-term bf16 split (priced against 2500 / 6)
-            return ('bf16x6' in k or 'wplanes' in k or 'gemm_pp' in k
-                    or any(f'gemm_f32_group_kernel<{v}>' in k for v in (2, 3, 6)))
+            return 'bf16x6' in k or 'wplanes' in k or 'gemm_f32_group_kernel<6>' in k
+
+        def is_h3(k):  # ... the three-term fp16 split (2500 / 3)
+            return 'gemm_h3' in k
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12
-            x6 = is_x6(name)  # (pre-split weight planes, planes x planes, the grouped launch's bf16x6 bodies: the same six-term product)
-            split = 'bf16x3' in name or x6
-            peak = BF16X6_PEAK_TF if x6 else (BF16X3_PEAK_TF if split else MFMA_F32_PEAK_TF)
+            x6 = is_x6(name)  # (pre-split weight planes, the grouped launch's bf16x6 body: the same six-term product)
+            split = is_h3(name) or x6
+            peak = BF16X6_PEAK_TF if x6 else (H3_PEAK_TF if split else MFMA_F32_PEAK_TF)
             r_gemm = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
                           traffic=None, kernel=name, launches_sampled=d[2], avg_us=d[1] / d[2] * 1e6,
                           flops_per_launch=d[0] / d[2],
                           note=(('fp32 operands split into three bf16 planes in the kernel (all 24 significand bits), six '
                                  'v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate — fp32-FMA-class error: achieved = '
                                  'fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 6; ' if x6 else
-                                 'fp32 operands split into hi + lo bf16 halves in the kernel, three v_mfma_f32_32x32x16_bf16 per '
-                                 'k-step, fp32 accumulate: achieved = fp32-equivalent 2MNK flops, peak = dense bf16 MFMA peak / 3; ')
+                                 'fp32 operands split into two power-of-two-scaled fp16 planes in the kernel (2^-24 relative), three '
+                                 'v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate — fp32-FMA-class error: achieved = fp32-equivalent '
+                                 '2MNK flops, peak = dense fp16 MFMA peak / 3; ')
                                 if split else 'fp32 in / fp32 accumulate MFMA (v_mfma_f32_32x32x2_f32); ') + '1 launch in '
                                f'{PROF_EVERY_GEMM} sampled (events recorded inside the C entry, on the launch stream); ' + (
                                    f'sampled in {a.roofline_rounds} eager round(s) run right after the timed region '
@@ -404,31 +412,63 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
             tf, tt = sum(v[0] for v in gg.values()), sum(v[1] for v in gg.values())
-            sf3 = sum(v[0] for k, v in gg.items() if 'bf16x3' in k)
+            sf3 = sum(v[0] for k, v in gg.items() if is_h3(k))
             sf6 = sum(v[0] for k, v in gg.items() if is_x6(k))
             sf = sf3 + sf6
-            st = sum(v[1] for k, v in gg.items() if 'bf16x3' in k or is_x6(k))
+            st = sum(v[1] for k, v in gg.items() if is_h3(k) or is_x6(k))
             # the family mixes the matrix pipes: its peak is the time the same flops would take at each kernel's own peak
-            fam_peak = tf / (sf3 / BF16X3_PEAK_TF + sf6 / BF16X6_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
+            fam_peak = tf / (sf3 / H3_PEAK_TF + sf6 / BF16X6_PEAK_TF + (tf - sf) / MFMA_F32_PEAK_TF) if tf else MFMA_F32_PEAK_TF
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
-                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_bf16x3_big_kernel<*>, '
-                              'gemm_small_kernel<*>, gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> (the grouped weight-gradient launch), gemm_pp_kernel<*>',
+                       kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_small_kernel<*>, '
+                              'gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> (the grouped weight-gradient launch), gemm_h3_*_kernel (opt-in)',
                        launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
-                            '2500/3 (bf16x3)')
+                            '2500/3 (fp16 split product, opt-in)')
         # the fused attention core (csrc/attn_core.hip) reports through the GEMM kind: its own two lines, fp32 matrix pipe
         def attn(name):
-            d = gg.get(name)
+            d = ga.get(name)
             if not d:
                 return None
             ach = d[0] / d[1] / 1e12
             return dict(bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TF, traffic=None,
                         kernel=name, launches_sampled=d[2], avg_us=d[1] / d[2] * 1e6, flops_per_launch=d[0] / d[2],
-                        note='algorithmic flops (4 Lq Lk 32 per image and head forward, 10 backward; the backward recomputes the '
-                             'scores in both of its passes: 14 issued), v_mfma_f32_32x32x2_f32, all decoder shapes of the round mixed')
+                        note='DENSE-equivalent algorithmic flops (4 Lq Lk 32 per image and head forward, 10 backward; fully masked 32 x 32 '
+                             'tiles are skipped by the kernel, so the issued work is lower; the backward recomputes the scores in both '
+                             'of its passes: 14 issued per kept tile), v_mfma_f32_32x32x2_f32, all decoder shapes of the round mixed')
         r_af, r_ab = attn('rscotr::attn_fwd_kernel'), attn('rscotr::attn_bwd (dq + dkv kernels)')
+        # the other families worth >= 1 ms of a round: LayerNorm, split-K combines, AdamW by their algorithmic
+        # bytes against HBM; Swin window attention by its algorithmic flops against the fp32 matrix pipe
+        def named(kind, names, bound, peak, unit, scale, work_of=None, note=None):
+            w = t = n = 0
+            for p in prof:
+                if p['kind'] == kind and any(x in p['name'] for x in names):
+                    w += p['work'] if work_of is None else work_of
+                    t += p['sec']
+                    n += 1
+            if not n or not t:
+                return None
+            ach = w / t / scale
+            r = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, traffic=None, kernel=' + '.join(names),
+                     launches_sampled=n, avg_us=t / n * 1e6)
+            r['bytes_per_launch' if bound == 'hbm' else 'flops_per_launch'] = w / n
+            if note:
+                r['note'] = note
+            return r
+        r_ln = named('hbm', ['layernorm_fwd_kernel', 'layernorm_bwd_kernel'], 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                     note='8 (12 with the second output) bytes per element forward, 12 (16 with the residual gradient) backward')
+        r_sk = named('hbm', ['gemm_splitk_reduce_kernel', 'splitk_flush_kernel'], 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                     note='slabs read + destination (and epilogue tensors) read / written')
+        opt_ = runner.optimizer
+        live_elems = float(sum((g['param'].numel() + 3) // 4 * 4 for g, l in zip(opt_.groups, opt_.live) if l))
+        r_ad = named('hbm', ['adamw_clip_kernel'], 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9, work_of=28.0 * live_elems,
+                     note='16 bytes read (weight, gradient, two moments) + 12 written per stepped element; '
+                          f'{int(live_elems)} elements stepped per iteration (torch 1.11 semantics: every tensor that has ever '
+                          'received a gradient)')
+        r_wa = named('mfma', ['swin_wattn_fwd_kernel', 'swin_wattn_bwd_kernel'], 'mfma', MFMA_F32_PEAK_TF, 'TFLOP/s', 1e12,
+                     note='4 (forward) / 10 (backward) x 49 x 49 x 32 flop per (image, window, head) on the real tokens, '
+                          'v_mfma_f32_32x32x2_f32; latency-bound per item (49 x 49 x 32 products on 64-row MFMA tiles)')
         r_f = hbm('msda_fwd', 'rscotr::msda_fwd_kernel<32, 4>')
         r_b = hbm('msda_bwd', 'rscotr_msda_bwd (sample + tile + combine kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
@@ -447,21 +487,21 @@ def main():
         out = dict(metric=wl['metric'], value=images / dt, unit='images/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype={0: 'f32', 3: 'f32 (large products as six bf16 MFMAs on three-plane splits of the fp32 operands, fp32 accumulate: '
-                                     'fp32-FMA-class error)'}.get(lib.rscotr_gemm_get_precision(),
-                                                                  'f32 (large products: 3x bf16 MFMA on hi/lo splits, fp32 accumulate)'),
+                                     'fp32-FMA-class error)'}[lib.rscotr_gemm_get_precision()],
                    data='synthetic',
                    config=dict(workload=f'{a.workload}: {wl["name"]}, {a.size}x{a.size} bs={a.batch}/task/GPU',
                                step=('one round-robin round = ' + '+'.join(wl['tasks']) + ' train iterations') if ntask > 1
                                else f'one {wl["tasks"][0]} train iteration',
                                images_per_step=ntask * a.batch * world, parallelism=f'dp{world}',
                                optimizer='AdamW+clip0.1 (fused HIP)', precision='fp32',
-                               gemm_precision_mode={0: 'fp32', 1: 'bf16x3', 2: 'bf16x3-big', 3: 'bf16x6'}[lib.rscotr_gemm_get_precision()],
+                               gemm_precision_mode={0: 'fp32', 3: 'bf16x6'}[lib.rscotr_gemm_get_precision()] + ('+h3' if ops.RANGES.enabled else ''),
                                rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0,
                                exchange=(('inline' if os.environ.get('RSCOTR_DIST_INLINE', '1') != '0' else 'overlap')
                                          if dist.is_initialized() else None),
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
-                   roofline_attn_fwd=r_af, roofline_attn_bwd=r_ab,
+                   roofline_attn_fwd=r_af, roofline_attn_bwd=r_ab, roofline_swin_wattn=r_wa, roofline_layernorm=r_ln,
+                   roofline_splitk=r_sk, roofline_adamw=r_ad,
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)

@@ -120,13 +120,11 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * K % 8 == 0, <= 512 output tiles of 32x32: wavefronts split K, fragments loaded straight from global memory); a
  * direct (LDS-free) kernel for k-major x k-major weight gradients with K >= 16384 and a 3-4 block output. */
 /* Inner product of the tiled GEMM kernel (rscotr_gemm_f32, rscotr_gemm_f32_batched, rscotr_gemm_f32_dw_slabs):
- * 0 = fp32 matrix pipe (v_mfma_f32_32x32x2_f32); 1 = "bf16x3": fp32 operands split into hi + lo bf16 halves while they are
- * staged, three v_mfma_f32_32x32x16_bf16 per k-step (lo*hi + hi*lo + hi*hi), fp32 accumulate -- error ~5e-6 of max|C|
- * against ~1e-6 for fp32 FMA, inside the 1e-3 gate of the path; 2 = bf16x3 only on the large row-major x row-major products
- * (128x128x32 tiles, gemm_bf16x3_big_kernel), fp32 pipe elsewhere; 3 = "bf16x6" (THE START VALUE): the large products as SIX
- * bf16 MFMAs on three-plane splits (h + m + l carry all 24 significand bits) with fp32 accumulation -- 3e-7 of max|C|, the
- * error class of an fp32 FMA chain (gemm_bf16x6_kernel; ragged M / N take its edge instantiations), fp32 pipe for the small
- * ones.  Process-wide; start value 3, or from RSCOTR_GEMM_PREC=fp32|bf16x3|bf16x3-big|bf16x6. */
+ * 0 = fp32 matrix pipe (v_mfma_f32_32x32x2_f32) everywhere; 3 = "bf16x6" (THE START VALUE): the large products as SIX bf16
+ * MFMAs on three-plane splits (h + m + l carry all 24 significand bits) with fp32 accumulation -- 3e-7 of max|C|, the error
+ * class of an fp32 FMA chain (gemm_bf16x6_kernel; ragged M / N take its edge instantiations), fp32 pipe for the small ones.
+ * Process-wide; start value 3, or from RSCOTR_GEMM_PREC=fp32|bf16x6.  (Modes 1 / 2 of rounds 1-4, the two-plane bf16
+ * product at 4-6e-6, are gone.) */
 /* The same product with PRE-SPLIT WEIGHTS.  In y = x W^T and dx = dy W of a Linear layer (torch F.linear behind mmcv's FFN,
  * MultiheadAttention, MultiScaleDeformableAttention, mmdet's WindowMSA / FFN) the B operand is a parameter that changes once
  * per optimizer step; rscotr_gemm_split_weights writes its three bf16 planes once (layout [K/16][npad][3][16], npad = rows
@@ -138,49 +136,13 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  * transposed, the plane set then has K rows).  Plane buffers hold npad * reduction * 6 bytes. */
 int rscotr_gemm_split_weights(const int64_t* table, int n, int total_blocks, void* stream);
 int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K);
-/* 1 if rscotr_gemm_f32_wplanes is worth calling for the shape: the 128-row weight-plane kernel's domain (M >= 4096, K >= 1024)
- * or — only after rscotr_gemm_set_wplanes_tiled(1) / RSCOTR_WPLANES_TILED=1; off by default: built, tested, measured no faster
- * (profiles/r4_planes_b_tiled.txt) — whatever the tiled split-product kernels take with their B operand read from the plane set
- * (K >= 192, enough output tiles); 0: multiply with the fp32 weight (rscotr_gemm_f32).  act_is_gelu: the product carries a GELU
- * epilogue.  rscotr_gemm_set_wplanes_tiled returns the previous setting. */
+/* 1 if rscotr_gemm_f32_wplanes is worth calling for the shape (the weight-plane kernel's domain: M >= 4096 rows, K >= 1024,
+ * N >= 64); 0: multiply with the fp32 weight (rscotr_gemm_f32).  act_is_gelu: reserved. */
 int rscotr_gemm_f32_wplanes_ok(int M, int N, int K, int act_is_gelu);
-int rscotr_gemm_set_wplanes_tiled(int on);
 int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int npad, float* C, int M, int N, int K, int lda, int ldc,
                             const float* bias, int act, const float* aux, float* pre, const float* resid, int accumulate,
                             const float* rowscale, int rows_per_scale, float* out2, float* workspace,
                             int64_t workspace_bytes, void* stream);
-/* The same six-term product with BOTH operands as plane sets, fed by LDS-DMA (csrc/gemm_pp.hip).  A plane set holds the three
- * bf16 planes (h, m, l: x = h + m + l exactly) of a stored fp32 tensor X (rows x cols, cols contiguous) in the ST32 layout: rows
- * and cols padded with zeros to multiples of 32; 32 x 32 super-tiles in row-major order, three planes of 2 KB per super-tile,
- * inside a plane 128 units of 16 bytes, unit (r, c8) = row r, columns 8 c8 .. 8 c8 + 7 at slot 32 c8 + 16 (r / 16) +
- * 4 ((r / 4 + c8) & 3) + (r & 3).  rscotr_planes_bytes(rows, cols) = ceil(rows / 32) * ceil(cols / 32) * 6144.
- * rscotr_split_planes writes the plane set of X; rowscale (may be NULL): row r is multiplied by rowscale[r / rows_per_scale]
- * first (the per-sample DropPath / Mixup factor folded into the Linear: the planes of s * dy serve dx and dW alike);
- * colsum_parts (may be NULL): (rscotr_split_planes_parts(rows), cols) floats, row g = the column sums of the (scaled) rows
- * 256 g .. 256 g + 255 — the bias gradient of the Linear whose dy is being split, as partial rows for rscotr_splitk_flush
- * (its row-sum columns: {0, colsum_parts, 0, db, cols, 0, 0, parts}).
- * rscotr_gemm_pp: C[m, n] = epilogue(sum_k Aop[m, k] Bop[n, k]), epilogue arguments as rscotr_gemm_f32.  ONE plane set serves
- * both uses of a tensor: x_col = 0 ("row mode"): the operand's rows are the stored rows and the reduction runs over the
- * stored columns (x in y = x W^T, dy in dx = dy W, W in y = x W^T); x_col = 1 ("col mode"): the operand's rows are the
- * stored COLUMNS and the reduction runs over the stored rows (dy and x in dW = dy^T x, W in dx = dy W) — read through the
- * LDS transpose read of gfx950.  x_ct = column tiles ceil(cols / 32) of the stored tensor.  Any M, N, K (tiles past the
- * operands are clamped reads / guarded stores; the reduction is zero-padded inside the planes).  Short grids are cut into
- * k-slices through `workspace` (rscotr_gemm_pp_workspace bytes; fixed-order combine); defer != 0: the combine is left to
- * rscotr_splitk_flush (slabs [splits][M][N] stay in `workspace`; *splits_out (HOST int, required then) = slabs written, 1 =
- * C already holds the result).  Replaces torch F.linear and the two backward contractions autograd derives from it, for the
- * large Linears of the step (cfg ...potsdam.py:9-25, 34-50). */
-int64_t rscotr_planes_bytes(int rows, int cols);
-int rscotr_split_planes_parts(int rows);
-int rscotr_split_planes(const float* X, int rows, int cols, int ld, void* planes, const float* rowscale,
-                        int rows_per_scale, float* colsum_parts, void* stream);
-/* many tensors (the parameters a task multiplies with, once per optimizer step) in ONE launch: table = device (n, 8) int64 rows
- * {X, planes, rows, cols, ld, first block, 0, 0}; an entry takes ceil(cols / 32) * ceil(32 ceil(rows / 32) / 256) blocks */
-int rscotr_split_planes_group(const int64_t* table, int n, int total_blocks, void* stream);
-int64_t rscotr_gemm_pp_workspace(int M, int N, int K);
-int rscotr_gemm_pp(const void* a_planes, int a_ct, int a_col, const void* b_planes, int b_ct, int b_col, float* C,
-                   int M, int N, int K, int ldc, const float* bias, int act, const float* aux, float* pre,
-                   const float* resid, int accumulate, const float* rowscale, int rows_per_scale, float* out2,
-                   float* workspace, int64_t workspace_bytes, int defer, int32_t* splits_out, void* stream);
 int rscotr_gemm_set_precision(int prec);
 int rscotr_gemm_get_precision(void);
 int64_t rscotr_gemm_f32_workspace(int M, int N, int K);
@@ -238,7 +200,9 @@ int rscotr_gemm_f32_dw_slabs_r(const float* A, const float* B, float* C, int M, 
                                float* rowsum, const float* kscale, int krows_per_scale, float* slab_region,
                                int64_t slab_bytes, int32_t* splits_out, const uint32_t* amax_a, const uint32_t* amax_b,
                                void* stream);
-int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream);
+/* (bytes: the algorithmic traffic of the launch — slabs read, destinations read and written — stated by the caller who built the
+ * device table, for the launch-site profiler; 0 = not stated) */
+int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, double bytes, void* stream);
 /* Grouped launch of deferred weight gradients: n problems dW_i = A_i^T B_i (both operands k-major) with small outputs run
  * as ONE launch on tiles x k-slices; every problem leaves `splits` slabs (+ row-sum partials when rs_slabs != 0) for
  * rscotr_splitk_flush.  variant 0: fp32 matrix pipe, 64 x 64 tiles with bounds handling (any problem); variant 2 / 3: bf16x6

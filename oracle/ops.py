@@ -14,6 +14,24 @@ FP32_EPS = float(torch.finfo(torch.float32).eps)
 # models/multi/seg_head/pixel_decoder.py:134-146 and models/multi/bbox_head/transformer.py:211-221,
 # 258-269.  Explicit 4-tap gather; autograd provides the backward.
 # ----------------------------------------------------------------------------------------------
+# Tests only (tests/parity.py): with BILINEAR_BAND = d (pixels) a sampling coordinate within d of a cell boundary is
+# evaluated with the NEIGHBOURING cell's bilinear patch (floor moved by one): the sampled value is continuous across the
+# boundary, its derivative with respect to the location is not — a coordinate that close to an integer is a coin toss
+# between two correct fp32 implementations (x = loc * W - 0.5 carries ~1e-5 pixels of rounding at W ~ 100).  At the initial
+# weights the DINO decoder samples exactly ON grid points (proposals at pixel centres, zero-initialised offsets).
+BILINEAR_BAND = None
+
+
+def _cell(x):
+    """-> (x0, lw): lower grid index (float) and the weight of the upper one, with the band rule above."""
+    x0 = torch.floor(x)
+    if BILINEAR_BAND is not None:
+        xd = x.detach()
+        lw = xd - x0
+        x0 = x0 - (lw < BILINEAR_BAND).to(x0.dtype) + (lw > 1 - BILINEAR_BAND).to(x0.dtype)
+    return x0, x - x0
+
+
 def msda_sample(value, spatial_shapes, level_start_index, loc, attn):
     """value (B,Nk,H,D); spatial_shapes [(H_l,W_l)]; loc (B,Nq,H,L,P,2) (x,y); attn (B,Nq,H,L,P)
     -> (B,Nq,H*D)."""
@@ -29,10 +47,8 @@ def msda_sample(value, spatial_shapes, level_start_index, loc, attn):
         x = loc[:, :, :, l, :, 0] * Wl - 0.5  # (B,Nq,H,P)
         y = loc[:, :, :, l, :, 1] * Hl - 0.5
         inside = (y > -1) & (x > -1) & (y < Hl) & (x < Wl)
-        x0 = torch.floor(x)
-        y0 = torch.floor(y)
-        lw = x - x0
-        lh = y - y0
+        x0, lw = _cell(x)
+        y0, lh = _cell(y)
         hw = 1 - lw
         hh = 1 - lh
         x0 = x0.long()

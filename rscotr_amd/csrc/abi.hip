@@ -21,8 +21,8 @@ struct ProfRec {
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 int g_prof_used = 0;
-int g_prof_every[PROF_KINDS] = {0, 0, 0};
-long g_prof_seen[PROF_KINDS] = {0, 0, 0};
+int g_prof_every[PROF_KINDS] = {0, 0, 0, 0, 0};
+long g_prof_seen[PROF_KINDS] = {0, 0, 0, 0, 0};
 }  // namespace
 
 ProfScope::ProfScope(int kind, double work, hipStream_t s, const char* fmt, ...) : slot(-1), stream(s) {
@@ -60,7 +60,8 @@ extern "C" int rscotr_prof_enable(int every_gemm, int every_msda_fwd, int every_
       return rscotr::fail(RSCOTR_E_LAUNCH, "rscotr_prof_enable: hipEventCreate failed");
   }
   rscotr::g_prof_used = 0;
-  const int ev[rscotr::PROF_KINDS] = {every_gemm, every_msda_fwd, every_msda_bwd};
+  const int any = (every_gemm > 0 || every_msda_fwd > 0 || every_msda_bwd > 0) ? 1 : 0;
+  const int ev[rscotr::PROF_KINDS] = {every_gemm, every_msda_fwd, every_msda_bwd, any, any};
   for (int k = 0; k < rscotr::PROF_KINDS; ++k) { rscotr::g_prof_every[k] = ev[k]; rscotr::g_prof_seen[k] = 0; }
   return RSCOTR_OK;
 }

@@ -45,7 +45,9 @@ constexpr int kWave = 64;  // CDNA wavefront width
 // with a pair of HIP events recorded on the launch stream from inside the library (no host code between the
 // event and the launch) and remembers the algorithmic work of the call; rscotr_prof_get() returns the event
 // durations.  Disabled (the default) it costs one branch.  Never enable it while a stream is capturing.
-enum { PROF_GEMM = 0, PROF_MSDA_FWD = 1, PROF_MSDA_BWD = 2, PROF_KINDS = 3 };
+// PROF_HBM / PROF_MFMA (round 5): every other kernel family worth >= 1 ms of a round, priced by its algorithmic bytes / flops
+// under the name of its kernel (LayerNorm, split-K combines, AdamW; Swin window attention) — on whenever any kind is on.
+enum { PROF_GEMM = 0, PROF_MSDA_FWD = 1, PROF_MSDA_BWD = 2, PROF_HBM = 3, PROF_MFMA = 4, PROF_KINDS = 5 };
 struct ProfScope {
   int slot;
   hipStream_t stream;

@@ -144,35 +144,6 @@ struct TileLoader {
     }
   }
 
-  // bf16x3 image (PREC = 1): row-major S[row][40] bf16 = 16 k of the hi half | 16 k of the lo half | 8 pad: 80-byte
-  // rows keep the 16-byte fragment reads of a wavefront on distinct banks.  x = hi + lo + O(2^-17 |x|): hi = rne_bf16(x)
-  // (v_cvt_pk_bf16_f32), lo = rne_bf16(x - hi) with the subtraction exact in fp32.
-  __device__ __forceinline__ void store_bf16(__bf16* S, int tid) const {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < R * 4) {
-        bf16x4 h, l;
-        h[0] = (__bf16)v[i].x; h[1] = (__bf16)v[i].y; h[2] = (__bf16)v[i].z; h[3] = (__bf16)v[i].w;
-        l[0] = (__bf16)(v[i].x - (float)h[0]);
-        l[1] = (__bf16)(v[i].y - (float)h[1]);
-        l[2] = (__bf16)(v[i].z - (float)h[2]);
-        l[3] = (__bf16)(v[i].w - (float)h[3]);
-        if (!KMAJOR) {
-          const int row = idx >> 2, kq = (idx & 3) * 4;
-          *reinterpret_cast<bf16x4*>(S + row * 40 + kq) = h;
-          *reinterpret_cast<bf16x4*>(S + row * 40 + 16 + kq) = l;
-        } else {
-          const int k = idx / (R / 4), c = (idx % (R / 4)) * 4;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            S[(c + u) * 40 + k] = h[u];
-            S[(c + u) * 40 + 16 + k] = l[u];
-          }
-        }
-      }
-    }
-  }
 };
 
 
@@ -186,15 +157,9 @@ struct TileLoader {
 // barrier and fragment latency sit on the critical path with nothing to hide them): KG groups on the same CU
 // interleave their chains.  No extra launch, no slabs in HBM.
 //
-// PREC = 1 ("bf16x3"): same kernel around a different inner product.  The fp32 operands are split into hi + lo bf16
-// halves while they are staged (TileLoader::store_bf16) and every k-tile of 16 is three v_mfma_f32_32x32x16_bf16 per
-// output tile — lo*hi + hi*lo + hi*hi, fp32 accumulate — instead of eight v_mfma_f32_32x32x2_f32: 96 matrix-pipe
-// cycles instead of 512 per tile and k-tile.  The dropped lo*lo term and the residual of the split are ~2^-17 relative
-// per product (measured: 4-5e-6 of max|C| against 4e-7..2e-6 for fp32 FMA; scripts/lab/bf16x3_lab.hip).  Loads,
-// split-K, k-groups, the row sums (taken from the fp32 registers) and the epilogue are shared.
 // SLAB: always leave the result as split-K slabs / row-sum partials, also for a single k-slice (the grouped launch of
 // deferred weight gradients: several problems may share a destination, the combine launch orders them).
-template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC, bool SLAB>
+template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, bool SLAB>
 __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const int gx, const int by) {
   static_assert(WM * WN == 4, "4 wavefronts per group");
   if (p.nb1 > 0) {  // batched: (b0, b1) = e.g. (image, head) of an attention product
@@ -211,9 +176,9 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
   // (offsets, not a pointer array: a runtime-indexed array of pointers loses the LDS address space and the
   // accesses degrade to flat loads)
-  // floats of LDS per k-group: two operand-tile pairs (fp32: k-major [16][LD]; bf16x3: [rows][40] bf16 = 20 floats a row)
-  constexpr int GROUP_FLOATS = PREC ? 2 * 20 * (BM + BN) : 2 * GEMM_BK * (LDA + LDB);
-  constexpr int SA_FLOATS = PREC ? 20 * BM : GEMM_BK * LDA, SB_FLOATS = PREC ? 20 * BN : GEMM_BK * LDB;
+  // floats of LDS per k-group: two operand-tile pairs (k-major [16][LD])
+  constexpr int GROUP_FLOATS = 2 * GEMM_BK * (LDA + LDB);
+  constexpr int SA_FLOATS = GEMM_BK * LDA, SB_FLOATS = GEMM_BK * LDB;
   const int lds0 = grp * GROUP_FLOATS;
   float* const sA0 = gemm_smem + lds0;
   float* const sA1 = sA0 + SA_FLOATS;
@@ -274,13 +239,8 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
   if (grp < nk) {
     load_tiles(kbeg + grp * GEMM_BK);
     if (AK && do_rs) la.accum(rs);
-    if (PREC) {
-      la.store_bf16(reinterpret_cast<__bf16*>(sA0), tid);
-      lb.store_bf16(reinterpret_cast<__bf16*>(sB0), tid);
-    } else {
-      la.store(sA0, tid);
-      lb.store(sB0, tid);
-    }
+    la.store(sA0, tid);
+    lb.store(sB0, tid);
   }
   __syncthreads();
 
@@ -295,30 +255,7 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
       __syncthreads();
       continue;
     }
-    if (PREC) {
-      // fragment of the 32x32x16 bf16 MFMA: row lane % 32, 8 consecutive k at 8 * (lane / 32): one 16-byte read each
-      const __bf16* a = reinterpret_cast<const __bf16*>(cur ? sA1 : sA0) + (wm * TM + fr) * 40 + fk * 8;
-      const __bf16* b = reinterpret_cast<const __bf16*>(cur ? sB1 : sB0) + (wn * TN + fr) * 40 + fk * 8;
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 40);
-        al[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 40 + 16);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 40);
-        bl[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 40 + 16);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {  // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    } else {
+    {
       const float* a = (cur ? sA1 : sA0) + fk * LDA + wm * TM + fr;
       const float* b = (cur ? sB1 : sB0) + fk * LDB + wn * TN + fr;
       // operand fragments double-buffered in registers: the ds_reads of step kk+2 are in flight
@@ -347,13 +284,8 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
     }
     if (more) {
       if (AK && do_rs) la.accum(rs);
-      if (PREC) {
-        la.store_bf16(reinterpret_cast<__bf16*>(cur ? sA0 : sA1), tid);
-        lb.store_bf16(reinterpret_cast<__bf16*>(cur ? sB0 : sB1), tid);
-      } else {
-        la.store(cur ? sA0 : sA1, tid);
-        lb.store(cur ? sB0 : sB1, tid);
-      }
+      la.store(cur ? sA0 : sA1, tid);
+      lb.store(cur ? sB0 : sB1, tid);
     }
     __syncthreads();
   }
@@ -450,281 +382,9 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
   amax_commit(p.amax_out, amx);
 }
 
-template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG, int PREC = 0>
+template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG>
 __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
-  gemm_f32_body<BM, BN, WM, WN, AK, BK_, EDGE, KG, PREC, false>(p, blockIdx.x, gridDim.x, blockIdx.y);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// bf16x3 kernel for the large row-major x row-major products (precision modes 1 and 2): 128x128 output tile, 32 k per
-// barrier, 4 wavefronts x (2 x 2) MFMA tiles -> 24 v_mfma_f32_32x32x16_bf16 (768 matrix-pipe cycles) per wavefront
-// between two barriers; the 64x64x16 tiling of gemm_f32_kernel<..., PREC = 1> leaves 96, which the staging cannot
-// hide (measured: 54.7 vs 52.8 ms/round with PREC = 1 everywhere).  Interior shapes only (M % 128 == N % 128 == 0,
-// k ranges multiples of 32, 16-byte loads legal); the operands are split into hi / lo bf16 halves while they are
-// staged (two 16-k half tiles of [rows][40] bf16 each: TileLoader::store_bf16); next tile's global loads fly under
-// the MFMAs; split-K slabs and the fused epilogue are the tiled kernel's.  scripts/lab/bf16x3_lab.hip is the
-// stand-alone version: 182 TFLOP/s-equivalent on M = 10880, N = 2048, K = 256 (62.7 us against 117 us on the fp32 pipe).
-// Operand staging of gemm_bf16x3_big_kernel: a 128-row x 32-k tile as hi / lo bf16 halves in LDS.
-//   row-major operand (KM = false): two 16-k half tiles of [128][40] bf16 (TileLoader::store_bf16); a fragment (row, 8
-//     consecutive k) is one 16-byte read.
-//   k-major operand (KM = true; the activations / gradients of a weight-gradient product, or a weight read as W^T):
-//     element (k, r) sits r-contiguous in memory, so a thread loads rows k and k + 1 of four consecutive r and packs the
-//     two k of each r into one dword: LDS [hi | lo][16 k-pairs][128 r] dwords, written as 16-byte rows (conflict-free) and
-//     read as 4 dwords per fragment (k-pairs 4g .. 4g + 3 of row r: consecutive lanes, consecutive banks).  Both layouts
-//     give a lane the same k order, so they mix freely.
-template <bool KM>
-struct BigOperand {
-  static constexpr int LDS_WORDS = KM ? 2 * 16 * 128 : 2 * 128 * 20;  // dwords per operand tile (16 KB / 20 KB)
-  TileLoader<128, false> r0, r1;  // row-major: k 0-15, k 16-31
-  float4 e[2], o[2];              // k-major: even / odd k row of two (k-pair, 4 r) items
-
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid) {
-    if (!KM) {
-      r0.load_fast(P, ld, row0, k0, tid);
-      r1.load_fast(P, ld, row0, k0 + 16, tid);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256, kp = idx >> 5, r4 = (idx & 31) * 4;
-        const float* src = P + (long)(k0 + 2 * kp) * ld + row0 + r4;
-        e[i] = *reinterpret_cast<const float4*>(src);
-        o[i] = *reinterpret_cast<const float4*>(src + ld);
-      }
-    }
-  }
-  // k-major only: row k of the staged tile times ks[k / per] (stochastic depth folded into a weight gradient)
-  __device__ __forceinline__ void scale_k(const float* __restrict__ ks, int per, int k0, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = k0 + 2 * ((tid + i * 256) >> 5);
-      const float f0 = ks[k / per], f1 = ks[(k + 1) / per];
-      e[i].x *= f0; e[i].y *= f0; e[i].z *= f0; e[i].w *= f0;
-      o[i].x *= f1; o[i].y *= f1; o[i].z *= f1; o[i].w *= f1;
-    }
-  }
-  // k-major only: running sums over k of the four r this thread stages (r4 = (tid & 31) * 4 for both items)
-  __device__ __forceinline__ void accum(float4& a) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a.x += e[i].x + o[i].x; a.y += e[i].y + o[i].y; a.z += e[i].z + o[i].z; a.w += e[i].w + o[i].w;
-    }
-  }
-  static __device__ __forceinline__ unsigned pack2(float x0, float x1, unsigned& lo) {
-    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-    const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
-    lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-    return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-  }
-  __device__ __forceinline__ void store(unsigned* S, int tid) const {
-    if (!KM) {
-      r0.store_bf16(reinterpret_cast<__bf16*>(S), tid);
-      r1.store_bf16(reinterpret_cast<__bf16*>(S + 128 * 20), tid);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256, kp = idx >> 5, r4 = (idx & 31) * 4;
-        uint4 h, l;
-        h.x = pack2(e[i].x, o[i].x, l.x);
-        h.y = pack2(e[i].y, o[i].y, l.y);
-        h.z = pack2(e[i].z, o[i].z, l.z);
-        h.w = pack2(e[i].w, o[i].w, l.w);
-        *reinterpret_cast<uint4*>(S + kp * 128 + r4) = h;
-        *reinterpret_cast<uint4*>(S + 16 * 128 + kp * 128 + r4) = l;
-      }
-    }
-  }
-  // fragments (hi, lo) of row `row` for k-step ks (0 / 1), k group g = lane / 32
-  static __device__ __forceinline__ void frag(const unsigned* S, int row, int ks, int g, bf16x8& hi, bf16x8& lo) {
-    if (!KM) {
-      const __bf16* q = reinterpret_cast<const __bf16*>(S + ks * 128 * 20) + row * 40 + g * 8;
-      hi = *reinterpret_cast<const bf16x8*>(q);
-      lo = *reinterpret_cast<const bf16x8*>(q + 16);
-    } else {
-      const unsigned* q = S + (ks * 8 + g * 4) * 128 + row;
-      uint4 h, l;
-      h.x = q[0]; h.y = q[128]; h.z = q[256]; h.w = q[384];
-      l.x = q[16 * 128]; l.y = q[16 * 128 + 128]; l.z = q[16 * 128 + 256]; l.w = q[16 * 128 + 384];
-      hi = __builtin_bit_cast(bf16x8, h);
-      lo = __builtin_bit_cast(bf16x8, l);
-    }
-  }
-};
-
-template <bool AK, bool BK_>
-__global__ __launch_bounds__(256) void gemm_bf16x3_big_kernel(GemmParams p) {
-  constexpr int BM = 128, BN = 128;
-  __shared__ __attribute__((aligned(16))) unsigned sA[BigOperand<AK>::LDS_WORDS], sB[BigOperand<BK_>::LDS_WORDS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = p.N / BN;
-  int tile, split = 0;
-  if (p.splits == 1) {
-    tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  } else {  // same order as gemm_f32_kernel: an XCD owns a run of tiles with all their splits
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int q = p.tiles >> 3, r = p.tiles & 7, run = q + (r ? 1 : 0);
-    const int nt = q + (x < r ? 1 : 0);
-    split = j / run;
-    const int tl = j - split * run;
-    if (tl >= nt) return;
-    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + tl;
-  }
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kbeg = split * p.ksplit_len;
-  const int kend = min(p.K, kbeg + p.ksplit_len);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  BigOperand<AK> la;
-  BigOperand<BK_> lb;
-  // bias gradient riding the dW contraction (tile column 0 sums its A tile over k, from the fp32 registers)
-  const bool do_rs = AK && p.rowsum && n0 == 0;
-  float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-  la.load(p.A, p.lda, m0, kbeg, tid);
-  lb.load(p.B, p.ldb, n0, kbeg, tid);
-  if (AK && p.kscale) la.scale_k(p.kscale, p.krows_per, kbeg, tid);
-  const int fr = lane & 31, fk = lane >> 5;
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    __syncthreads();  // the previous tile has been consumed
-    if (AK && do_rs) la.accum(rs);
-    la.store(sA, tid);
-    lb.store(sB, tid);
-    __syncthreads();
-    if (k0 + 32 < kend) {
-      la.load(p.A, p.lda, m0, k0 + 32, tid);
-      lb.load(p.B, p.ldb, n0, k0 + 32, tid);
-      if (AK && p.kscale) la.scale_k(p.kscale, p.krows_per, k0 + 32, tid);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        BigOperand<AK>::frag(sA, wm * 64 + i * 32 + fr, ks, fk, ah[i], al[i]);
-        BigOperand<BK_>::frag(sB, wn * 64 + i * 32 + fr, ks, fk, bh[i], bl[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  }
-
-  if (AK && do_rs) {  // thread t summed r = (t & 31) * 4 .. + 3 over the k-pairs it staged: fold the 8 k-lanes
-    __syncthreads();
-    float4* red = reinterpret_cast<float4*>(sA);
-    red[(tid >> 5) * 32 + (tid & 31)] = rs;
-    __syncthreads();
-    if (tid < BM) {
-      const float* rf = reinterpret_cast<const float*>(sA);
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v += rf[k * BM + tid];
-      const int m = m0 + tid;
-      if (p.splits > 1) p.rs_slabs[(long)split * p.M + m] = v;
-      else p.rowsum[m] = p.rowsum_acc ? p.rowsum[m] + v : v;
-    }
-  }
-
-  if (p.splits > 1) {
-    float* slab = p.slabs + (long)split * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-          slab[(long)m * p.N + n] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-  const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + fr;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      const int mb = m0 + wm * 64 + i * 32 + 4 * fk;
-      float* crow = p.C + (long)mb * p.ldc + n;
-      if (plain) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
-      } else {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          float v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = acc[i][j][4 * g4 + u] + bv;
-          float amx_unused = 0.f;
-          epilogue_rows4<false>(p, v, mb + 8 * g4, n, amx_unused);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-}
-
-// Is the problem one for gemm_bf16x3_big_kernel?  (row-major x row-major, interior for 128 x 128 x 32, enough tiles)
-// k-slices: grids shorter than the chip with a long reduction.  Row-major-output products: two slices (the combine runs
-// the epilogue; a more general rule — up to 256 workgroups, >= 512 k per slice, also for 43..127-tile shapes — was
-// withdrawn in round 1 because the two-term split's rounding (4e-6) flips ReLU gates and seg attention-mask bits of
-// the 512^2 step often enough to leave the 1e-3 gradient tier; the fp64-anchored gate of round 2 shows the same for
-// every two-term routing, which is why the default is the three-term mode 3); weight gradients: ~256 workgroups,
-// >= 256 k per slice.
-static int bf16x3_big_splits(int M, int N, int K, bool dw = false) {
-  // off by default: with the slices on, the 512^2 seg parity depends on what earlier processes left in device memory
-  // (10-12 of 459 gradient tensors outside the tight tier on a fresh box or with the slices off, 140-440 after other
-  // runs on the same box) — some read of an unwritten word on that route that is not found yet.  Costs ~0.3 ms/round.
-  static const int on = getenv("RSCOTR_BF16X3_SPLIT") ? atoi(getenv("RSCOTR_BF16X3_SPLIT")) : 0;
-  const long tiles = std::max<long>(1, (long)(M / 128) * (N / 128));
-  if (!dw) return (on && tiles < 256 && K >= 1024 && K % 64 == 0) ? 2 : 1;
-  const long sp = std::max<long>(1, std::min<long>(256 / tiles, K / 256));
-  if (sp <= 1) return 1;
-  int klen = (int)((K + sp - 1) / sp);
-  klen = (klen + 31) / 32 * 32;
-  return (int)((K + klen - 1) / klen);
-}
-
-static bool bf16x3_big_dims(int M, int N, int K) {
-  if (M % 128 || N % 128 || K % 32 || K < 64) return false;
-  static const long min_tiles = getenv("RSCOTR_BF16X3_MIN_TILES") ? atol(getenv("RSCOTR_BF16X3_MIN_TILES")) : 128;
-  return (long)(M / 128) * (N / 128) >= min_tiles;
-}
-
-static bool bf16x3_big_ok(const GemmParams& p, int a_kmajor, int b_kmajor) {
-  if (!p.vecA || !p.vecB) return false;
-  // GELU epilogues (erff per element, a second output tensor) on a 128x128 tile with 1-2 resident workgroups are not
-  // hidden by anything: the Swin fc1 products measured slower here than on the 64x64 fp32 tiling (39.6 vs 34-37 us)
-  if (p.act == ACT_GELU || p.act == ACT_GELU_GRAD || p.pre) return false;
-  if (a_kmajor && b_kmajor) {  // weight gradients: few tiles, long reductions -> k-slices fill the chip
-    static const int dw_on = getenv("RSCOTR_BF16X3_DW") ? atoi(getenv("RSCOTR_BF16X3_DW")) : 1;
-    // (4 tiles x 38 slices for M = N = 256, K = 10880 measured 26.5 us against 23.0 on the fp32 tiling)
-    return dw_on && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 32 == 0 && p.K >= 2048 && !p.rowscale &&
-           (long)(p.M / 128) * (p.N / 128) >= 16;
-  }
-  if (p.kscale) return false;
-  // one k-major operand (dX = g W, W read k-major): its fragments are four dword reads instead of one 16-byte read; on
-  // a single wave of workgroups with a short reduction that latency shows (M = 10880, N = K = 256: 33.2 vs 23.5 us)
-  if ((a_kmajor || b_kmajor) && (long)(p.M / 128) * (p.N / 128) < 256 && p.K < 1024) return false;
-  return bf16x3_big_dims(p.M, p.N, p.K);
-}
-
-template <bool AK, bool BK_>
-static void launch_bf16x3_big(const GemmParams& p, unsigned nwg, hipStream_t s) {
-  gemm_bf16x3_big_kernel<AK, BK_><<<dim3(nwg), 256, 0, s>>>(p);
+  gemm_f32_body<BM, BN, WM, WN, AK, BK_, EDGE, KG, false>(p, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -940,58 +600,6 @@ struct SplitOperand {
   }
 };
 
-// B operand that ARRIVES as bf16 planes (round 4): a parameter's plane set written once per optimizer step by
-// rscotr_gemm_split_weights (layout [K / 16][npad rows][3 planes][16 k], zero rows behind N: csrc comment of gemm_wplanes_kernel)
-// goes global -> VGPR -> LDS untouched — no conversion, 96 bytes per row and 16-k step instead of 64 bytes of fp32.  In the
-// tiled kernels below a workgroup converted its B tile (a weight: the same values in every one of the M / 64 row tiles and in
-// every launch of the step) again in every k step; with this operand only A, the activation, is split while it is staged.
-// LDS stage = R rows of SBK / 16 x 96 bytes + 16 bytes of padding (112 / 208 bytes: the row strides of the weight-plane kernel
-// and of the split operand at 32 k, conflict-free for 16-byte fragment reads; the 64 x 64 pipelined kernel keeps its 53 248
-// bytes = three workgroups per CU).
-template <int R, int SBK>
-struct PlaneOperand {
-  static constexpr int SUB = SBK / 16;
-  static constexpr int LDRW = SUB * 24 + 4;              // dwords per LDS row
-  static constexpr int WORDS = R * LDRW;                 // dwords per stage
-  static constexpr int ITEMS = SUB * R * 6;              // 16-byte pieces per stage
-  static constexpr int NV = (ITEMS + 255) / 256;
-  static_assert(NV <= 3, "three pieces per thread at most");
-  uint4 v0, v1, v2;  // (named members, not an array: the compiler moved a uint4 array of the non-EDGE instantiations to LDS / scratch)
-  template <bool EDGE>
-  static __device__ __forceinline__ uint4 piece_load(const unsigned short* __restrict__ pl, int ld, int row0, int k0, int idx, int klim) {
-    const int sub = idx / (R * 6), rem = idx - sub * (R * 6), row = rem / 6, piece = rem - row * 6;
-    int kt = (k0 >> 4) + sub;
-    const bool past = EDGE && kt * 16 >= klim;
-    if (EDGE) kt = min(kt, (klim >> 4) - 1);
-    uint4 v = *reinterpret_cast<const uint4*>(pl + ((long)kt * ld + row0 + row) * 48 + piece * 8);
-    if (past) v = make_uint4(0u, 0u, 0u, 0u);
-    return v;
-  }
-  static __device__ __forceinline__ void piece_store(unsigned* S, int idx, const uint4& v) {
-    const int sub = idx / (R * 6), rem = idx - sub * (R * 6), row = rem / 6, piece = rem - row * 6;
-    *reinterpret_cast<uint4*>(S + row * LDRW + sub * 24 + piece * 4) = v;
-  }
-  // P = the plane set (as const float*: the slot of GemmParams.B), ld = npad; rows past N are the set's zero rows; k steps past
-  // klim (EDGE: the reduction's end, a multiple of 16) are zeros
-  template <bool EDGE = false>
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid, int rlast = 0, int klim = 0) {
-    const unsigned short* pl = reinterpret_cast<const unsigned short*>(P);
-    v0 = piece_load<EDGE>(pl, ld, row0, k0, tid, klim);
-    if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) v1 = piece_load<EDGE>(pl, ld, row0, k0, tid + 256, klim);
-    if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) v2 = piece_load<EDGE>(pl, ld, row0, k0, tid + 512, klim);
-  }
-  __device__ __forceinline__ void store(unsigned* S, int tid, const H3Scale& = H3Scale{1.f, 2048.f}) const {
-    piece_store(S, tid, v0);
-    if (NV > 1 && (ITEMS >= 512 || tid + 256 < ITEMS)) piece_store(S, tid + 256, v1);
-    if (NV > 2 && (ITEMS >= 768 || tid + 512 < ITEMS)) piece_store(S, tid + 512, v2);
-  }
-  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) {
-    const unsigned* q = S + row * LDRW + ks * 24 + 4 * g;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) f[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + pl * 8));
-  }
-};
-
 // PIPE: 0 = one LDS stage, two barriers per k-tile of 16; 1 = two LDS stages, one barrier, next tile's loads one step ahead;
 // 2 / 3 = the software-pipelined loop (two LDS stages, one barrier): the loads of tile t + D are issued at the top of step t
 // into the register set step t - 1 freed (D = 2 / 3 sets), and the split / pack / LDS writes of tile t + 1 are interleaved
@@ -1014,27 +622,22 @@ template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : PIPE == 
 #endif
 template <int PIPE> constexpr int bf16x6_depth() { return PIPE == 2 ? RSCOTR_X6_D2 : PIPE == 3 ? 3 : 1; }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool BPL = false, bool H16 = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool H16 = false>
 constexpr int bf16x6_lds_words() {
   constexpr int NPL = H16 ? 2 : 3;
-  if constexpr (BPL)
-    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, 3, bf16x6_bk<PIPE>()>::WORDS + PlaneOperand<BN, bf16x6_bk<PIPE>()>::WORDS);
-  else
-    return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS + SplitOperand<BN, BKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS);
+  return (PIPE ? 2 : 1) * (SplitOperand<BM, AKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS + SplitOperand<BN, BKM, NPL, bf16x6_bk<PIPE>(), H16>::WORDS);
 }
 
 // SLAB: leave the result as split-K slabs / row-sum partials also for a single k-slice (grouped launch, see below).
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
-// BPL: p.B / p.ldb = the pre-split plane set of B and its row count (PlaneOperand above; BKM is then irrelevant)
 // H16: the fp16 split product (split_pair_h above): operands scaled by powers of two from p.amax_a / p.amax_b (both
 // required), three MFMAs per 16 k into two accumulator sets.
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool BPL = false, bool H16 = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool H16 = false>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
-  static_assert(!(H16 && BPL), "pre-split planes are bf16");
   constexpr int NPL = H16 ? 2 : 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
   using OA = SplitOperand<BM, AKM, NPL, SBK, H16>;
-  using OB = std::conditional_t<BPL, PlaneOperand<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK, H16>>;
+  using OB = SplitOperand<BN, BKM, NPL, SBK, H16>;
   H3Scale ha{1.f, 2048.f}, hb{1.f, 2048.f};
   float inva = 1.f, invb = 1.f;
   // The range words are REQUESTED here and reduced (h3_scales) only after the first operand tiles have been requested too:
@@ -1300,23 +903,23 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   amax_commit(p.amax_out, amx);
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, bool BPL = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, BPL>()];
-  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, BPL>(p, blockIdx.x, gridDim.x, lds);
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE>()];
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
 template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, false, true>()];
-  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, false, true>(p, blockIdx.x, gridDim.x, lds);
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, true>()];
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, true>(p, blockIdx.x, gridDim.x, lds);
 }
 // 128 x 128 tiles: two accumulator sets are 128 registers; held to two wavefronts per SIMD (256 registers in all) so that
 // two workgroups per CU cover each other's staging phases in the one-stage loop
 template <bool AKM, bool BKM, bool EDGE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_h3_128_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<128, 128, AKM, BKM, 0, false, true>()];
-  gemm_bf16x6_body<128, 128, AKM, BKM, 0, false, EDGE, false, true>(p, blockIdx.x, gridDim.x, lds);
+  __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<128, 128, AKM, BKM, 0, true>()];
+  gemm_bf16x6_body<128, 128, AKM, BKM, 0, false, EDGE, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1549,12 +1152,11 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const int64_t* __res
 // bundles of 8 (padded with rows of 0 workgroups) that occupy 8 * max(workgroups of the bundle's rows) consecutive ids,
 // row x of a bundle taking the ids = x mod 8 (see the kernel).
 constexpr size_t GROUP_LDS_BYTES = 4 * (size_t)bf16x6_lds_words<128, 128, true, true, 0>();  // 24 KB (>= the fp32 body's 17 KB)
-// X6 = false: fp32 matrix pipe on 64 x 64 tiles with bounds handling (any problem); X6 = true: the bf16x6 split product on
-// 128 x 128 tiles (interior problems: M, N multiples of 128, k-slices multiples of 16, 16-byte aligned operands).  Two
-// instantiations rather than one kernel with both bodies: the 128 x 128 body's registers (114 + 64 accumulators) would
-// halve the residency of the fp32 body's workgroups (measured: 950 -> 1500 us for the launch).
-// VAR: 0 = fp32 64 x 64 (any problem), 2 = bf16x6 128 x 128, 3 = bf16x6 64 x 64 software-pipelined (32 k per step: M, N
-// multiples of 64, k-slices multiples of 32, 16-byte aligned operands)
+// VAR 0: fp32 matrix pipe on 64 x 64 tiles with bounds handling (any problem); VAR 6: the six-term bf16 split product on
+// 128 x 128 tiles with edge handling (M, N, K multiples of 4, 16-byte aligned operands).  Separate instantiations rather than one
+// kernel with both bodies: the 128 x 128 body's registers (114 + 64 accumulators) would halve the residency of the fp32 body's
+// workgroups (measured: 950 -> 1500 us for the launch).  (Variants 2 / 3 / 4 of rounds 3-4 — interior-only 128 x 128, 64 x 64
+// pipelined, fp32 on 128 x 128 — lost every A/B to variant 6 and left the library in round 5.)
 // VAR 7 (round 5): the fp16 split product on the 128 x 128 edge body; table column 14 = (slot of A + 1) << 32 | slot of B + 1,
 // indices into `amax_base` (the value-range words of the two operands).
 template <int VAR>
@@ -1594,8 +1196,7 @@ __device__ __forceinline__ void gemm_group_dispatch(const int64_t* __restrict__ 
     p.amax_a = amax_base + (unsigned)((uint64_t)t[14] >> 32) - 1;
     p.amax_b = amax_base + (unsigned)((uint64_t)t[14] & 0xffffffffu) - 1;
   }
-  p.tiles = VAR == 2 ? (p.M / 128) * (p.N / 128) : VAR == 3 ? (p.M / 64) * (p.N / 64)
-            : (VAR == 4 || VAR == 6 || VAR == 7) ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  p.tiles = (VAR == 6 || VAR == 7) ? ((p.M + 127) / 128) * ((p.N + 127) / 128) : ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // the bodies decode (tile, k-slice) from a workgroup id laid out for XCD runs (x = id & 7 owns a run of tiles, id >> 3 =
   // slice * run + position in the run): build the id whose decoding is (tile = jwg % tiles, slice = jwg / tiles)
   const int tl_ = jwg % p.tiles, sl_ = jwg / p.tiles;
@@ -1605,22 +1206,14 @@ __device__ __forceinline__ void gemm_group_dispatch(const int64_t* __restrict__ 
   else { const int u_ = tl_ - r_ * (q_ + 1); x_ = r_ + u_ / q_; pos_ = u_ - (x_ - r_) * q_; }
   const int bx = 8 * (sl_ * run_ + pos_) + x_;
   const int gx = p.splits > 1 ? 8 * run_ * p.splits : p.tiles;  // (one k-slice: the single-slice tile order, result still as slab 0)
-  if constexpr (VAR == 2) {
-    gemm_bf16x6_body<128, 128, true, true, 0, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
-  } else if constexpr (VAR == 3) {
-    gemm_bf16x6_body<64, 64, true, true, 2, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
-  } else if constexpr (VAR == 6) {
-    // bf16x6 on 128 x 128 tiles with edge handling: the ragged members (Swin stage 1 / 2: 96, 192, 288, 576 rows or columns) —
-    // on the fp32 pipe of variant 0 they ran at 41 TFLOP/s
+  if constexpr (VAR == 6) {
+    // bf16x6 on 128 x 128 tiles with edge handling: every member with min(M, N) >= 48 — interior or ragged (Swin stage 1 / 2:
+    // 96, 192, 288, 576 rows or columns); on the fp32 pipe of variant 0 the ragged ones ran at 41 TFLOP/s
     gemm_bf16x6_body<128, 128, true, true, 0, true, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else if constexpr (VAR == 7) {
-    gemm_bf16x6_body<128, 128, true, true, 0, true, true, false, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
-  } else if constexpr (VAR == 4) {
-    // fp32 pipe on 128 x 128 tiles: a 256 x 256 output is 4 tiles instead of 16 — each k-major operand panel is read twice
-    // instead of four times (the 64 x 64 launch moved 2.1 GB of HBM traffic for 0.7 GB of operands)
-    gemm_f32_body<128, 128, 2, 2, true, true, true, 1, 0, true>(p, bx, gx, 0);
+    gemm_bf16x6_body<128, 128, true, true, 0, true, true, true>(p, bx, gx, reinterpret_cast<unsigned*>(gemm_smem));
   } else {
-    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, 0, true>(p, bx, gx, 0);
+    gemm_f32_body<64, 64, 2, 2, true, true, true, 1, true>(p, bx, gx, 0);
   }
 }
 
@@ -1717,12 +1310,12 @@ static void launch_h3(const GemmParams& p, int a_kmajor, int b_kmajor, unsigned 
     else if (!a_kmajor) gemm_h3_128_kernel<false, true, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else if (!b_kmajor) gemm_h3_128_kernel<true, false, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else gemm_h3_128_kernel<true, true, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
-    return;
+  } else {
+    if (!a_kmajor && !b_kmajor) gemm_h3_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (!a_kmajor) gemm_h3_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (!b_kmajor) gemm_h3_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    else gemm_h3_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
   }
-  if (!a_kmajor && !b_kmajor) gemm_h3_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
-  else if (!a_kmajor) gemm_h3_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
-  else if (!b_kmajor) gemm_h3_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
-  else gemm_h3_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2124,21 +1717,18 @@ static int colsum_gy(int M, int N) {
   return std::min(gy, 256);
 }
 
-template <int BM, int BN, int KG, int PREC = 0>
+template <int BM, int BN, int KG>
 constexpr size_t gemm_lds_bytes() {
-  return sizeof(float) * std::max<size_t>((size_t)KG * (PREC ? 2 * 20 * (BM + BN) : 2 * GEMM_BK * (BM + 4 + BN + 4)),
-                                          KG > 1 ? (size_t)(KG - 1) * 16 * 256 : 0);
+  return sizeof(float) * std::max<size_t>((size_t)KG * (2 * GEMM_BK * (BM + 4 + BN + 4)), KG > 1 ? (size_t)(KG - 1) * 16 * 256 : 0);
 }
 
-// 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32), 1: bf16x3 (three bf16 MFMAs on hi / lo splits, fp32 accumulate).
-// RSCOTR_GEMM_PREC=fp32|bf16x3 sets the start value, rscotr_gemm_set_precision() changes it (tests, A/B runs).
-// 2: bf16x3 only where it pays — gemm_bf16x3_big_kernel on the large row-major products, fp32 pipe elsewhere.
-// 3: bf16x6 (three planes, six MFMAs: fp32-accurate) where it pays — gemm_bf16x6_kernel, fp32 pipe elsewhere.
+// 0: fp32 matrix pipe (v_mfma_f32_32x32x2_f32) everywhere; 3: the split product (three bf16 planes, six MFMAs: fp32-accurate —
+// or, with the operands' value ranges, two fp16 planes and three MFMAs) where it pays, fp32 pipe elsewhere.
+// RSCOTR_GEMM_PREC=fp32|bf16x6 sets the start value, rscotr_gemm_set_precision() changes it (tests, A/B runs).  (Modes 1 / 2,
+// round 1's two-plane bf16 product at 4-6e-6, lost their A/B in rounds 2 and 3 and left the library in round 5.)
 static std::atomic<int> g_gemm_prec{[] {
   const char* e = getenv("RSCOTR_GEMM_PREC");
   if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) return 0;
-  if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) return 1;
-  if (e && (!strcmp(e, "bf16x3-big") || !strcmp(e, "2"))) return 2;
   if (e && (!strcmp(e, "bf16x6") || !strcmp(e, "3"))) return 3;
   return RSCOTR_GEMM_PREC_DEFAULT;
 }()};
@@ -2156,25 +1746,17 @@ static void launch_kernel(Kern kern, dim3 grid, int threads, size_t lds, hipStre
   kern<<<grid, threads, lds, s>>>(p);
 }
 
-template <int BM, int BN, int WM, int WN, bool EDGE, int KG, int PREC>
-static void launch_gemm_prec(const GemmParams& p, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = gemm_lds_bytes<BM, BN, KG, PREC>();
-  if (!a_kmajor && !b_kmajor)
-    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, false, false, EDGE, KG, PREC>, grid, 256 * KG, lds, s, p);
-  else if (!a_kmajor && b_kmajor)
-    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, false, true, EDGE, KG, PREC>, grid, 256 * KG, lds, s, p);
-  else if (a_kmajor && !b_kmajor)
-    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, true, false, EDGE, KG, PREC>, grid, 256 * KG, lds, s, p);
-  else
-    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, true, true, EDGE, KG, PREC>, grid, 256 * KG, lds, s, p);
-}
-
 template <int BM, int BN, int WM, int WN, bool EDGE, int KG>
 static void launch_gemm_edge(const GemmParams& p, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
-  if (g_gemm_prec.load(std::memory_order_relaxed) == 1)
-    launch_gemm_prec<BM, BN, WM, WN, EDGE, KG, 1>(p, a_kmajor, b_kmajor, grid, s);
+  constexpr size_t lds = gemm_lds_bytes<BM, BN, KG>();
+  if (!a_kmajor && !b_kmajor)
+    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, false, false, EDGE, KG>, grid, 256 * KG, lds, s, p);
+  else if (!a_kmajor && b_kmajor)
+    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, false, true, EDGE, KG>, grid, 256 * KG, lds, s, p);
+  else if (a_kmajor && !b_kmajor)
+    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, true, false, EDGE, KG>, grid, 256 * KG, lds, s, p);
   else
-    launch_gemm_prec<BM, BN, WM, WN, EDGE, KG, 0>(p, a_kmajor, b_kmajor, grid, s);
+    launch_kernel(gemm_f32_kernel<BM, BN, WM, WN, true, true, EDGE, KG>, grid, 256 * KG, lds, s, p);
 }
 
 // kgroups: wavefront groups per workgroup sharing the k loop (1, 2 or 4; > 1 only for the one-tile-per-wavefront
@@ -2290,6 +1872,8 @@ static void launch_splitk_reduce(const GemmParams& p, const float* workspace, hi
   const bool vec = (N % 4 == 0) && aligned16(workspace) && (total % 4 == 0);
   const long work = vec ? total / 4 : total;
   const int blocks = (int)std::min<long>((std::max<long>(work, M) + 255) / 256, 2048);
+  ProfScope prof(PROF_HBM, (p.splits + 1.0 + (p.resid ? 1.0 : 0.0) + (p.aux ? 1.0 : 0.0) + (p.accumulate ? 1.0 : 0.0)) * 4.0 * total, s,
+                 "rscotr::gemm_splitk_reduce_kernel");
   static const int sg_ok = getenv("RSCOTR_GEMM_REDUCE_SG") ? atoi(getenv("RSCOTR_GEMM_REDUCE_SG")) : 1;
   if (vec && sg_ok && p.splits >= 8 && blocks < 512 && (work + 63) / 64 * 256 >= M)
     gemm_splitk_reduce_sg_kernel<<<(unsigned)((work + 63) / 64), 256, 0, s>>>(p);
@@ -2354,7 +1938,7 @@ static thread_local int tl_last_splits = 1;
 
 // Workspace the split-K path wants for this problem (bytes; 0 = never splits): slabs + row-sum partials.
 extern "C" int rscotr_gemm_set_precision(int prec) {
-  if (prec < 0 || prec > 3) return fail(RSCOTR_E_ARG, "rscotr_gemm_set_precision: 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x3 on the large row-major products) or 3 (bf16x6: fp32-accurate split product)");
+  if (prec != 0 && prec != 3) return fail(RSCOTR_E_ARG, "rscotr_gemm_set_precision: 0 (fp32 matrix pipe everywhere) or 3 (the fp32-accurate split product where it pays)");
   g_gemm_prec.store(prec);
   return RSCOTR_OK;
 }
@@ -2372,11 +1956,6 @@ extern "C" int64_t rscotr_gemm_f32_workspace(int M, int N, int K) {
     sp = std::max<int64_t>(sp, std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, K / 256)));  // as a weight gradient
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (t64 >= 128 && t64 < 512) sp = std::max<int64_t>(sp, std::min<long>((512 + t64 - 1) / t64, K / 256));  // mid-size k-slices
-  }
-  const int pm = g_gemm_prec.load(std::memory_order_relaxed);
-  if ((pm == 1 || pm == 2) && M % 128 == 0 && N % 128 == 0 && K % 32 == 0) {
-    if (bf16x3_big_dims(M, N, K)) sp = std::max<int64_t>(sp, bf16x3_big_splits(M, N, K));
-    if (K >= 2048 && (long)(M / 128) * (N / 128) >= 16) sp = std::max<int64_t>(sp, bf16x3_big_splits(M, N, K, true));  // as a weight gradient
   }
   return sp * ((int64_t)M * N + M) * 4;
 }
@@ -2530,40 +2109,6 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
       return RSCOTR_OK;
     }
   }
-  if ((prec_mode == 1 || prec_mode == 2) && bf16x3_big_ok(p, a_kmajor, b_kmajor)) {
-    const bool dw = a_kmajor && b_kmajor;
-    int sp = bf16x3_big_splits(M, N, K, dw);
-    if (sp > 1 && (!workspace || workspace_bytes < sp * ((int64_t)M * N + M) * 4))
-      sp = (int)std::max<int64_t>(1, std::min<int64_t>(sp, workspace ? workspace_bytes / (((int64_t)M * N + M) * 4) : 1));
-    p.tiles = (M / 128) * (N / 128);
-    int klen = K;
-    if (sp > 1) {
-      klen = (K + sp - 1) / sp;
-      klen = (klen + 31) / 32 * 32;
-      sp = (K + klen - 1) / klen;
-    }
-    p.splits = sp; p.ksplit_len = klen;
-    p.slabs = sp > 1 ? workspace : nullptr;
-    p.rs_slabs = sp > 1 ? workspace + sp * (int64_t)M * N : nullptr;
-    static const bool prof_shapes_b = getenv("RSCOTR_PROF_SHAPES") != nullptr;
-    char bname[112];
-    if (prof_shapes_b) snprintf(bname, sizeof(bname), "M=%d N=%d K=%d %d%d bf16x3 splits=%d", M, N, K, a_kmajor, b_kmajor, sp);
-    else snprintf(bname, sizeof(bname), "rscotr::gemm_bf16x3_big_kernel<%s, %s>", a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
-    ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", bname);
-    const unsigned nwg = sp > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sp) : (unsigned)p.tiles;
-    if (!a_kmajor && !b_kmajor) launch_bf16x3_big<false, false>(p, nwg, s);
-    else if (!a_kmajor) launch_bf16x3_big<false, true>(p, nwg, s);
-    else if (!b_kmajor) launch_bf16x3_big<true, false>(p, nwg, s);
-    else launch_bf16x3_big<true, true>(p, nwg, s);
-    if (int e = check_launch("rscotr_gemm_f32 (bf16x3 big)")) return e;
-    if (sp > 1) {
-      if (tl_defer) { tl_last_splits = sp; return RSCOTR_OK; }
-      launch_splitk_reduce(p, workspace, s);
-      return check_launch("rscotr_gemm_f32 (bf16x3 big, split-K reduce)");
-    }
-    return RSCOTR_OK;
-  }
-
   const GemmCfg cfg = choose_cfg(M, N, K);
   const int BM = cfg.BM, BN = cfg.BN;
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -2702,63 +2247,26 @@ static void wplanes_cfg(int M, int N, int K, int* bn_out, int* splits_out) {
   *bn_out = bbn; *splits_out = bsp;
 }
 
-// Which kernel multiplies with a plane set: the 128-row weight-plane kernel above where it wins (long reductions over many rows:
-// the encoder's FFN2 / its dX), else the TILED split-product kernels with their B operand from planes (gemm_bf16x6_kernel<...,
-// BPL = true>: the 64 x 64 pipelined and the 128 x 128 tiles, k-slices, EDGE instantiations — every shape choose_split6 takes).
+// Where the weight-plane kernel above wins: long reductions over many rows (the encoder's FFN2 / its dX).  (Round 4's tiled
+// split-product kernels with their B operand from planes gained 15-28 % per dispatch and lost the round to the per-iteration
+// re-split of every weight — profiles/r4_planes_b_tiled.txt — and left the library in round 5.)
 static bool wplanes_classic(int M, int K) {
   static const int min_m = getenv("RSCOTR_WPLANES_MIN_M") ? atoi(getenv("RSCOTR_WPLANES_MIN_M")) : 4096;
   static const int min_k = getenv("RSCOTR_WPLANES_MIN_K") ? atoi(getenv("RSCOTR_WPLANES_MIN_K")) : 1024;
   return M >= min_m && K >= min_k;
 }
 
-// OFF by default (RSCOTR_WPLANES_TILED=1 / 2, rscotr_gemm_set_wplanes_tiled): per dispatch the 64 x 64 kernels gain 15-28 % with
-// their B operand from planes (10880 x 256 x 256: 17.3 us against 20.4), the 128 x 128 one-stage kernel loses 4 %, and the
-// per-iteration split of ~23 M weights in both orientations costs ~0.3 ms per round: the round measures 35.7 ms against 35.4
-// (profiles/r4_planes_b_tiled.txt).
-static std::atomic<int> g_wplanes_tiled{[] {
-  const char* e = getenv("RSCOTR_WPLANES_TILED");
-  return e ? atoi(e) : 0;
-}()};
-
-static Split6Cfg wplanes_tiled_cfg(GemmParams p, int64_t ws_bytes) {
-  Split6Cfg none{0, 1, p.K};
-  static const int max_m = getenv("RSCOTR_WPLANES_TILED_MAXM") ? atoi(getenv("RSCOTR_WPLANES_TILED_MAXM")) : (1 << 30);
-  if (!g_wplanes_tiled.load(std::memory_order_relaxed) || p.K % 16 || p.M > max_m) return none;
-  p.vecA = 1; p.vecB = 1; p.kscale = nullptr;
-  const Split6Cfg sc = choose_split6(p, 0, 0, ws_bytes);
-  // mode 1: the 64 x 64 tiles only (17.3 / 22.3 / 26.7 us against 20.4 / 31 / 33 on the 680 / 576 / 768-workgroup shapes of the
-  // step; the 128 x 128 one-stage kernel measures 4 % SLOWER with its B from planes: 96.9 against 93 us on the encoder's FFN1);
-  // mode 2: both
-  if (sc.bm == 128 && g_wplanes_tiled.load(std::memory_order_relaxed) < 2) return none;
-  return sc;
-}
-
-extern "C" int rscotr_gemm_set_wplanes_tiled(int on) { return g_wplanes_tiled.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
-
-/* 1: rscotr_gemm_f32_wplanes takes (M, N, K) — either kernel; 0: the caller multiplies with the fp32 weight (rscotr_gemm_f32) */
+/* 1: rscotr_gemm_f32_wplanes is worth calling for (M, N, K); 0: the caller multiplies with the fp32 weight (rscotr_gemm_f32) */
 extern "C" int rscotr_gemm_f32_wplanes_ok(int M, int N, int K, int act_is_gelu) {
   if (M <= 0 || N <= 0 || K < 16 || K % 16) return 0;
-  if (wplanes_classic(M, K)) return N >= 64;
-  GemmParams p{};
-  p.M = M; p.N = N; p.K = K; p.act = act_is_gelu ? ACT_GELU : ACT_NONE;
-  return wplanes_tiled_cfg(p, INT64_MAX / 4).bm != 0;
+  (void)act_is_gelu;
+  return wplanes_classic(M, K) && N >= 64;
 }
 
 extern "C" int64_t rscotr_gemm_f32_wplanes_workspace(int M, int N, int K) {
-  if (!wplanes_classic(M, K)) {
-    GemmParams p{};
-    p.M = M; p.N = N; p.K = K; p.act = ACT_NONE;
-    const Split6Cfg sc = wplanes_tiled_cfg(p, INT64_MAX / 4);
-    if (sc.bm) return sc.splits > 1 ? (int64_t)sc.splits * ((int64_t)M * N + M) * 4 : 0;
-  }
   int bn, splits;
   wplanes_cfg(M, N, K, &bn, &splits);
   return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
-}
-
-template <int BM, int PIPE, bool EDGE = false>
-static void launch_split6_planes(const GemmParams& p, unsigned nwg, hipStream_t s) {
-  gemm_bf16x6_kernel<BM, BM, false, false, PIPE, EDGE, true><<<dim3(nwg), 256, 0, s>>>(p);
 }
 
 // C = epilogue(A x Bplanes): A (M, K) fp32 row-major (lda), planes = the pre-split B of rscotr_gemm_split_weights (N rows,
@@ -2786,45 +2294,6 @@ extern "C" int rscotr_gemm_f32_wplanes(const float* A, const void* planes, int n
   p.nb1 = 0; p.nb2 = 1;
   p.rowscale = rowscale; p.rows_per = rows_per_scale; p.kscale = nullptr; p.krows_per = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (!wplanes_classic(M, K)) {  // tiled split-product kernels, B from the plane set
-    const Split6Cfg sc = wplanes_tiled_cfg(p, workspace ? workspace_bytes : 0);
-    if (sc.bm) {
-    p.B = reinterpret_cast<const float*>(planes); p.ldb = npad;
-    p.tiles = ((M + sc.bm - 1) / sc.bm) * ((N + sc.bm - 1) / sc.bm);
-    if ((long)((N + sc.bm - 1) / sc.bm) * sc.bm > npad) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32_wplanes: npad %d too small for N = %d", npad, N);
-    const bool ragged = M % sc.bm || N % sc.bm || (sc.bm == 128 && K % RSCOTR_X6_BK0);
-    p.splits = sc.splits; p.ksplit_len = sc.klen;
-    p.slabs = sc.splits > 1 ? workspace : nullptr;
-    p.rs_slabs = sc.splits > 1 ? workspace + sc.splits * (int64_t)M * N : nullptr;
-    static const bool prof_shapes_t = getenv("RSCOTR_PROF_SHAPES") != nullptr;
-    char tname[112];
-    if (prof_shapes_t) snprintf(tname, sizeof(tname), "M=%d N=%d K=%d 0p bf16x6-%d-planes splits=%d", M, N, K, sc.bm, sc.splits);
-    else snprintf(tname, sizeof(tname), "rscotr::gemm_bf16x6_kernel<%d, %d, false, planes, *>", sc.bm, sc.bm);
-    ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", tname);
-    const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
-    const bool k32 = K % 32 == 0 && sc.klen % 32 == 0;
-#if RSCOTR_X6_BK0 == 16  // (lab builds with 32 k per barrier pair: the plane operand is written for three pieces per thread)
-    if (ragged && sc.bm == 128) launch_split6_planes<128, 0, true>(p, nwg, s);
-    else if (sc.bm == 128) launch_split6_planes<128, 0>(p, nwg, s);
-    else
-#else
-    if (sc.bm == 128) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_wplanes: no 128 x 128 plane kernel in this build");
-#endif
-    if (ragged) {
-      if (k32) launch_split6_planes<64, 2, true>(p, nwg, s);
-      else launch_split6_planes<64, 1, true>(p, nwg, s);
-    } else {
-      if (k32) launch_split6_planes<64, 2>(p, nwg, s);
-      else launch_split6_planes<64, 1>(p, nwg, s);
-    }
-    if (int e = check_launch("rscotr_gemm_f32_wplanes (tiled)")) return e;
-    if (sc.splits > 1) {
-      launch_splitk_reduce(p, workspace, s);
-      return check_launch("rscotr_gemm_f32_wplanes (tiled, split-K reduce)");
-    }
-    return RSCOTR_OK;
-    }  // (shapes the tiled kernels do not take: the 128-row kernel below handles any M, N)
-  }
   int bn, splits;
   wplanes_cfg(M, N, K, &bn, &splits);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4))
@@ -2872,17 +2341,11 @@ extern "C" int rscotr_gemm_dw_group(const int64_t* table, int n, int total_wgs, 
     if (!amax_base) return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant 7 needs the value-range words (amax_base)");
     gemm_h3_group_kernel<<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n, amax_base);
   } else if (variant == 0) {
-    gemm_f32_group_kernel<0><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1, 0>(), (hipStream_t)stream>>>(table, n);
-  } else if (variant == 2) {
-    gemm_f32_group_kernel<2><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
-  } else if (variant == 3) {
-    gemm_f32_group_kernel<3><<<dim3((unsigned)total_wgs), 256, 4 * (size_t)bf16x6_lds_words<64, 64, true, true, 2>(), (hipStream_t)stream>>>(table, n);
+    gemm_f32_group_kernel<0><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<64, 64, 1>(), (hipStream_t)stream>>>(table, n);
   } else if (variant == 6) {
     gemm_f32_group_kernel<6><<<dim3((unsigned)total_wgs), 256, GROUP_LDS_BYTES, (hipStream_t)stream>>>(table, n);
-  } else if (variant == 4) {
-    gemm_f32_group_kernel<4><<<dim3((unsigned)total_wgs), 256, gemm_lds_bytes<128, 128, 1, 0>(), (hipStream_t)stream>>>(table, n);
   } else {
-    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 64 x 64 tiles), 2 (bf16x6 128 x 128), 3 (bf16x6 64 x 64), 4 (fp32 128 x 128), 6 (bf16x6 128 x 128 with edges) or 7 (fp16 split product, 128 x 128 with edges)");
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_dw_group: variant must be 0 (fp32 matrix pipe, 64 x 64 tiles, any problem), 6 (six-term bf16 split product, 128 x 128 tiles with edges) or 7 (fp16 split product on the same tiles)");
   }
   return check_launch("rscotr_gemm_dw_group");
 }
@@ -2924,10 +2387,11 @@ __global__ __launch_bounds__(256) void splitk_flush_kernel(const int64_t* __rest
 // table: device (n, 8) int64 rows {slabs, row-sum slabs | 0, C, rowsum | 0, M, N, ldc, splits} (N % 4 == 0, ldc % 4 == 0,
 // 16-byte aligned pointers: caller-checked); wgmap: device (nwg, 2) int32 rows {table row, chunk of 256 float4s}, with
 // ceil(max(M * N / 4, M) / 256) chunks per row.
-extern "C" int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, void* stream) {
+extern "C" int rscotr_splitk_flush(const int64_t* table, const int32_t* wgmap, int nwg, double bytes, void* stream) {
   if (nwg < 0) return fail(RSCOTR_E_SHAPE, "rscotr_splitk_flush: negative workgroup count");
   if (nwg == 0) return RSCOTR_OK;
   if (!table || !wgmap) return fail(RSCOTR_E_ARG, "rscotr_splitk_flush: null pointer");
+  ProfScope prof(PROF_HBM, bytes, (hipStream_t)stream, "rscotr::splitk_flush_kernel");
   splitk_flush_kernel<<<dim3((unsigned)nwg), 256, 0, (hipStream_t)stream>>>(table, wgmap);
   return check_launch("rscotr_splitk_flush");
 }

@@ -346,6 +346,7 @@ extern "C" int rscotr_layernorm_fwd(const float* x, const float* weight, const f
   if (!aligned16(x) || !aligned16(y) || (weight && !aligned16(weight)) || (bias && !aligned16(bias)))
     return fail(RSCOTR_E_ALIGN, "rscotr_layernorm_fwd: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_HBM, 8.0 * M * C, s, "rscotr::layernorm_fwd_kernel");
 #define CALL(G, NV)                                                                                       \
   layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps, nullptr, 1, \
                                                                          nullptr, MergeGeom{}, amax_out)
@@ -365,6 +366,7 @@ extern "C" int rscotr_layernorm_fwd_sum(const float* x, const float* weight, con
       (bias && !aligned16(bias)))
     return fail(RSCOTR_E_ALIGN, "rscotr_layernorm_fwd_sum: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_HBM, 12.0 * M * C, s, "rscotr::layernorm_fwd_kernel");
 #define CALL(G, NV)                                                                                                  \
   layernorm_fwd_kernel<G, NV><<<ln_blocks(M, 4 * (64 / G)), 256, 0, s>>>(x, weight, bias, y, mean, rstd, M, C, eps, add, \
                                                                          add_rows, y2, MergeGeom{}, amax_out)
@@ -405,6 +407,7 @@ extern "C" int rscotr_layernorm_bwd(const float* dy, const float* x, const float
     return fail(RSCOTR_E_ARG, "rscotr_layernorm_bwd: workspace of rscotr_layernorm_bwd_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
   float* part = params ? workspace : nullptr;
+  ProfScope prof(PROF_HBM, (dx_add ? 16.0 : 12.0) * M * C, s, "rscotr::layernorm_bwd_kernel");
 #define CALL(G, NV) \
   layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);
@@ -431,6 +434,7 @@ extern "C" int rscotr_layernorm_bwd_partials(const float* dy, const float* x, co
   if (part_bytes < (int64_t)nb * 2 * C * 4)
     return fail(RSCOTR_E_ARG, "rscotr_layernorm_bwd_partials: region of rscotr_layernorm_bwd_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_HBM, (dx_add ? 16.0 : 12.0) * M * C, s, "rscotr::layernorm_bwd_kernel");
 #define CALL(G, NV) \
   layernorm_bwd_kernel<G, NV><<<nb, 256, 0, s>>>(dy, x, weight, mean, rstd, dx, dx_add, part, M, C, MergeGeom{}, amax_out)
   RSCOTR_LN_DISPATCH(C, CALL);

@@ -195,6 +195,8 @@ extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* 
     return fail(RSCOTR_E_ALIGN, "rscotr_adamw_clip_step: arenas must be 16-byte aligned");
   if (seg_amax && nseg > 0)
     amax_reset_kernel<<<dim3((nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(seg_dyn, seg_amax, nseg);
+  // (work 0: which segments are live is device data — the caller prices the launch: 28 bytes per stepped element)
+  ProfScope prof(PROF_HBM, 0.0, (hipStream_t)stream, "rscotr::adamw_clip_kernel");
   adamw_clip_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, chunk_seg, chunk_off, chunk_len, seg_dyn, sumsq, max_norm, beta1,
       beta2, eps, seg_amax);

@@ -91,99 +91,141 @@ __global__ __launch_bounds__(256) void upsample_ce_sums_kernel(const float* __re
   if (threadIdx.x < 3) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// grid = B*h*w low-resolution cells, 128 threads: lane = class; gathers
-//   dlogit[b,c,cy,cx] = scale * sum over output pixels p touching the cell of  wt(p->cell) * (softmax_c(p) - [c == label_p])
-// Every tap of such a pixel lies in the 3x3 cell neighbourhood of (cy, cx): the neighbourhood of all classes is
-// staged once in LDS ([9][class], conflict-free) — read straight from the (C, h, w) planes each lane would touch a
-// different 16 KB-strided plane on every one of the ~1000 taps of the pixel loop (1.85 ms at 2x100x64x64 -> 512^2).
-constexpr int UCE_F = 24;  // staged footprint (output pixels per axis that can touch one cell); larger -> direct loads
+// Backward: dlogit[b,c,cy,cx] = scale * sum over output pixels p touching the cell of  wt(p->cell) * (softmax_c(p) - [c == label_p]).
+// Round 5: one workgroup per BLOCK of UCE_TB x UCE_TB low-resolution cells instead of one per cell.  The output pixels whose
+// 2 x 2 tap footprint meets the block — (UCE_TB + 1) * 8 = 40 per axis at the step's x8 resize, 1.56 x the pixels the block
+// owns — are visited ONCE per class (the per-cell kernel visited every pixel from each of the four cells it touches and
+// re-interpolated its logits each time: 245 us at 2 x 100 x 64 x 64 -> 512^2).  512 threads = 4 row groups x 128 class lanes:
+// group g takes the footprint rows y_lo + g, + 4, ...; a lane keeps the four cell sums of the current (row pair, column
+// pair) in registers and folds them into its private LDS column when the column pair changes (every ~8 pixels); the
+// (UCE_TB + 2)^2 cell neighbourhood of all classes, the labels and log-sum-exps of the footprint and the row / column
+// interpolation tables are staged in LDS once.  The four groups meet in fixed order: no atomics, bit-reproducible.
+constexpr int UCE_TB = 4;    // cells per block edge
+constexpr int UCE_NB = UCE_TB + 2;
+constexpr int UCE_FP = 48;   // staged footprint rows / columns (40 at x8); larger footprints read labels / lse from global memory
 
-__global__ __launch_bounds__(128) void upsample_ce_bwd_kernel(const float* __restrict__ logit,
+__global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __restrict__ logit,
                                                               const int64_t* __restrict__ label,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ gscale, float* __restrict__ dlogit,
                                                               int B, int C, int h, int w, int H, int W, int ignore) {
-  __shared__ float sN[9][128];
-  // per-cell tables shared by all classes: labels / lse of the footprint pixels and the column interpolation
-  // (the pixel loop below runs ~256 times per class lane: without them every iteration redoes the index arithmetic and
-  // two global loads that are the same for all 100 lanes — 261 us at 2x100x64x64 -> 512^2)
-  __shared__ int sLab[UCE_F * UCE_F];
-  __shared__ float sLse[UCE_F * UCE_F];
-  __shared__ float sWx[UCE_F], sXl0[UCE_F], sXl1[UCE_F];
-  __shared__ int sKx0[UCE_F], sKx1[UCE_F];
-  const int cell = blockIdx.x;
-  const int cx = cell % w, cy = (cell / w) % h, b = cell / (w * h);
+  extern __shared__ __attribute__((aligned(16))) float uce_smem[];
+  float* sN = uce_smem;                                  // [UCE_NB * UCE_NB][128]   neighbourhood logits of the 128 classes of a pass
+  float* sAcc = sN + UCE_NB * UCE_NB * 128;              // [4 groups][UCE_TB * UCE_TB][128]
+  float* sLse = sAcc + 4 * UCE_TB * UCE_TB * 128;        // [UCE_FP * UCE_FP]
+  int* sLab = reinterpret_cast<int*>(sLse + UCE_FP * UCE_FP);
+  float* sYl = reinterpret_cast<float*>(sLab + UCE_FP * UCE_FP);   // [UCE_FP][2]  l0, l1 of a footprint row
+  float* sXl = sYl + 2 * UCE_FP;
+  int* sYi = reinterpret_cast<int*>(sXl + 2 * UCE_FP);   // [UCE_FP][2]  i0, i1 relative to the block's first cell - 1
+  int* sXi = sYi + 2 * UCE_FP;
+  const int bw = (w + UCE_TB - 1) / UCE_TB, bh = (h + UCE_TB - 1) / UCE_TB;
+  const int blk = blockIdx.x;
+  const int cx0 = (blk % bw) * UCE_TB, cy0 = ((blk / bw) % bh) * UCE_TB, b = blk / (bw * bh);
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  // output rows / columns whose 2-tap footprint can include this cell: source coord in (c-1, c+1)
-  const int y_lo = max(0, (int)floorf(((float)cy - 1.f + 0.5f) / sy - 0.5f));
-  const int y_hi = min(H - 1, (int)ceilf(((float)cy + 1.f + 0.5f) / sy - 0.5f));
-  const int x_lo = max(0, (int)floorf(((float)cx - 1.f + 0.5f) / sx - 0.5f));
-  const int x_hi = min(W - 1, (int)ceilf(((float)cx + 1.f + 0.5f) / sx - 0.5f));
+  // output rows / columns whose taps can include a cell of the block: source coordinate in (c0 - 1, c0 + TB)
+  const int y_lo = max(0, (int)floorf(((float)cy0 - 1.f + 0.5f) / sy - 0.5f));
+  const int y_hi = min(H - 1, (int)ceilf(((float)(cy0 + UCE_TB) + 0.5f) / sy - 0.5f));
+  const int x_lo = max(0, (int)floorf(((float)cx0 - 1.f + 0.5f) / sx - 0.5f));
+  const int x_hi = min(W - 1, (int)ceilf(((float)(cx0 + UCE_TB) + 0.5f) / sx - 0.5f));
   const int ny = y_hi - y_lo + 1, nx = x_hi - x_lo + 1;
-  const bool staged = ny <= UCE_F && nx <= UCE_F;  // uniform
+  const bool staged = ny <= UCE_FP && nx <= UCE_FP;  // uniform
+  const int tid = threadIdx.x, lane = tid & 127, grp = tid >> 7;
   const float* base = logit + (long)b * C * h * w;
   const float scale = gscale[0];
   if (staged) {
-    for (int i = threadIdx.x; i < ny * nx; i += 128) {
+    for (int i = tid; i < ny * nx; i += 512) {
       const long p = ((long)b * H + y_lo + i / nx) * W + x_lo + i % nx;
       sLab[i] = (int)label[p];
       sLse[i] = lse[p];
     }
-    for (int i = threadIdx.x; i < nx; i += 128) {
-      const Interp ix = src_index(x_lo + i, sx, w);
-      sWx[i] = (ix.i0 == cx ? ix.l0 : 0.f) + (ix.i1 == cx ? ix.l1 : 0.f);
-      sXl0[i] = ix.l0; sXl1[i] = ix.l1;
-      sKx0[i] = ix.i0 - cx + 1; sKx1[i] = ix.i1 - cx + 1;
-    }
+  }
+  for (int i = tid; i < min(ny, UCE_FP); i += 512) {
+    const Interp iy = src_index(y_lo + i, sy, h);
+    sYl[2 * i] = iy.l0; sYl[2 * i + 1] = iy.l1;
+    sYi[2 * i] = iy.i0 - cy0 + 1; sYi[2 * i + 1] = iy.i1 - cy0 + 1;
+  }
+  for (int i = tid; i < min(nx, UCE_FP); i += 512) {
+    const Interp ix = src_index(x_lo + i, sx, w);
+    sXl[2 * i] = ix.l0; sXl[2 * i + 1] = ix.l1;
+    sXi[2 * i] = ix.i0 - cx0 + 1; sXi[2 * i + 1] = ix.i1 - cx0 + 1;
   }
   for (int c0 = 0; c0 < C; c0 += 128) {
-    const int c = c0 + threadIdx.x;
+    const int c = c0 + lane;
     __syncthreads();
+    // neighbourhood (cells cy0 - 1 .. cy0 + TB, cx0 - 1 .. cx0 + TB; zeros outside the map: never weighted) of this pass's classes
+    for (int k = grp; k < UCE_NB * UCE_NB; k += 4) {
+      const int ny_ = cy0 + k / UCE_NB - 1, nx_ = cx0 + k % UCE_NB - 1;
+      sN[k * 128 + lane] = (c < C && ny_ >= 0 && ny_ < h && nx_ >= 0 && nx_ < w) ? base[(long)c * h * w + ny_ * w + nx_] : 0.f;
+    }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int ny_ = cy + k / 3 - 1, nx_ = cx + k % 3 - 1;
-      sN[k][threadIdx.x] = (c < C && ny_ >= 0 && ny_ < h && nx_ >= 0 && nx_ < w) ? base[(long)c * h * w + ny_ * w + nx_] : 0.f;
+    for (int k = 0; k < UCE_TB * UCE_TB; ++k) sAcc[(grp * UCE_TB * UCE_TB + k) * 128 + lane] = 0.f;
+    __syncthreads();
+    if (c < C) {
+      float* acc = sAcc + grp * UCE_TB * UCE_TB * 128 + lane;
+      for (int r = grp; r < ny; r += 4) {
+        int ky0, ky1;
+        float yl0, yl1;
+        if (r < UCE_FP) { ky0 = sYi[2 * r]; ky1 = sYi[2 * r + 1]; yl0 = sYl[2 * r]; yl1 = sYl[2 * r + 1]; }
+        else { const Interp iy = src_index(y_lo + r, sy, h); ky0 = iy.i0 - cy0 + 1; ky1 = iy.i1 - cy0 + 1; yl0 = iy.l0; yl1 = iy.l1; }
+        // (a row whose both taps lie outside the block contributes nothing; the footprint bounds are conservative)
+        const bool in0 = ky0 >= 1 && ky0 <= UCE_TB && cy0 + ky0 - 1 < h, in1 = ky1 >= 1 && ky1 <= UCE_TB && cy0 + ky1 - 1 < h;
+        if (!in0 && !in1) continue;
+        float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
+        int cur0 = -100, cur1 = -100;
+        auto flush = [&]() {
+          if (cur0 == -100) return;
+          const bool jx0 = cur0 >= 1 && cur0 <= UCE_TB && cx0 + cur0 - 1 < w, jx1 = cur1 >= 1 && cur1 <= UCE_TB && cx0 + cur1 - 1 < w;
+          if (in0 && jx0) acc[((ky0 - 1) * UCE_TB + cur0 - 1) * 128] += t00;
+          if (in0 && jx1) acc[((ky0 - 1) * UCE_TB + cur1 - 1) * 128] += t01;
+          if (in1 && jx0) acc[((ky1 - 1) * UCE_TB + cur0 - 1) * 128] += t10;
+          if (in1 && jx1) acc[((ky1 - 1) * UCE_TB + cur1 - 1) * 128] += t11;
+          t00 = t01 = t10 = t11 = 0.f;
+        };
+        float n00 = 0.f, n01 = 0.f, n10 = 0.f, n11 = 0.f;
+        for (int xx = 0; xx < nx; ++xx) {
+          int kx0, kx1;
+          float xl0, xl1;
+          if (xx < UCE_FP) { kx0 = sXi[2 * xx]; kx1 = sXi[2 * xx + 1]; xl0 = sXl[2 * xx]; xl1 = sXl[2 * xx + 1]; }
+          else { const Interp ix = src_index(x_lo + xx, sx, w); kx0 = ix.i0 - cx0 + 1; kx1 = ix.i1 - cx0 + 1; xl0 = ix.l0; xl1 = ix.l1; }
+          if (kx0 != cur0 || kx1 != cur1) {  // a new column pair: fold the finished one, fetch this one's four cell logits
+            flush();
+            cur0 = kx0; cur1 = kx1;
+            const int a0 = min(max(kx0, 0), UCE_NB - 1), a1 = min(max(kx1, 0), UCE_NB - 1);
+            const int b0 = min(max(ky0, 0), UCE_NB - 1), b1 = min(max(ky1, 0), UCE_NB - 1);
+            n00 = sN[(b0 * UCE_NB + a0) * 128 + lane]; n01 = sN[(b0 * UCE_NB + a1) * 128 + lane];
+            n10 = sN[(b1 * UCE_NB + a0) * 128 + lane]; n11 = sN[(b1 * UCE_NB + a1) * 128 + lane];
+          }
+          int lab;
+          float ls;
+          if (staged) { lab = sLab[r * nx + xx]; ls = sLse[r * nx + xx]; }
+          else { const long p = ((long)b * H + y_lo + r) * W + x_lo + xx; lab = (int)label[p]; ls = lse[p]; }
+          if (lab == ignore) continue;
+          const float v = yl0 * (xl0 * n00 + xl1 * n01) + yl1 * (xl0 * n10 + xl1 * n11);
+          const float gq = __expf(v - ls) - (c == lab ? 1.f : 0.f);
+          t00 += yl0 * xl0 * gq; t01 += yl0 * xl1 * gq; t10 += yl1 * xl0 * gq; t11 += yl1 * xl1 * gq;
+        }
+        flush();
+      }
     }
     __syncthreads();
-    if (c >= C) continue;
-    float acc = 0.f;
-    for (int y = y_lo; y <= y_hi; ++y) {
-      const Interp iy = src_index(y, sy, h);
-      const float wy = (iy.i0 == cy ? iy.l0 : 0.f) + (iy.i1 == cy ? iy.l1 : 0.f);
-      if (wy == 0.f) continue;
-      const int ky0 = (iy.i0 - cy + 1) * 3, ky1 = (iy.i1 - cy + 1) * 3;
-      if (staged) {
-        const int row = (y - y_lo) * nx;
-        for (int xx = 0; xx < nx; ++xx) {
-          const float wx = sWx[xx];
-          if (wx == 0.f) continue;
-          const int lab = sLab[row + xx];
-          if (lab == ignore) continue;
-          const int kx0 = sKx0[xx], kx1 = sKx1[xx];
-          const float l0 = sXl0[xx], l1 = sXl1[xx];
-          const float v = iy.l0 * (l0 * sN[ky0 + kx0][threadIdx.x] + l1 * sN[ky0 + kx1][threadIdx.x]) +
-                          iy.l1 * (l0 * sN[ky1 + kx0][threadIdx.x] + l1 * sN[ky1 + kx1][threadIdx.x]);
-          const float prob = __expf(v - sLse[row + xx]);
-          acc += wy * wx * (prob - (c == lab ? 1.f : 0.f));
-        }
-      } else {
-        for (int x = x_lo; x <= x_hi; ++x) {
-          const Interp ix = src_index(x, sx, w);
-          const float wx = (ix.i0 == cx ? ix.l0 : 0.f) + (ix.i1 == cx ? ix.l1 : 0.f);
-          if (wx == 0.f) continue;
-          const long p = ((long)b * H + y) * W + x;
-          const long lab = label[p];
-          if (lab == ignore) continue;
-          const int kx0 = ix.i0 - cx + 1, kx1 = ix.i1 - cx + 1;
-          const float v = iy.l0 * (ix.l0 * sN[ky0 + kx0][threadIdx.x] + ix.l1 * sN[ky0 + kx1][threadIdx.x]) +
-                          iy.l1 * (ix.l0 * sN[ky1 + kx0][threadIdx.x] + ix.l1 * sN[ky1 + kx1][threadIdx.x]);
-          const float prob = __expf(v - lse[p]);
-          acc += wy * wx * (prob - (c == lab ? 1.f : 0.f));
+    // the four row groups meet in fixed order; thread (grp, lane) writes block rows grp of class lane
+    if (c < C && cy0 + grp < h) {
+      float* drow = dlogit + ((long)b * C + c) * h * w + (long)(cy0 + grp) * w + cx0;
+#pragma unroll
+      for (int k = 0; k < UCE_TB; ++k) {
+        if (cx0 + k < w) {
+          float v = 0.f;
+#pragma unroll
+          for (int g2 = 0; g2 < 4; ++g2) v += sAcc[((g2 * UCE_TB + grp) * UCE_TB + k) * 128 + lane];
+          drow[k] = v * scale;
         }
       }
     }
-    dlogit[((long)b * C + c) * h * w + cy * w + cx] = acc * scale;
   }
+}
+
+constexpr size_t uce_bwd_lds_bytes() {
+  return (size_t)(UCE_NB * UCE_NB * 128 + 4 * UCE_TB * UCE_TB * 128 + 2 * UCE_FP * UCE_FP + 8 * UCE_FP) * 4;
 }
 
 // Masked-attention mask of the Mask2Former-style decoder (models/multi/seg_head/mask2former_head.py:126-136 and
@@ -261,7 +303,15 @@ extern "C" int rscotr_upsample_ce_bwd(const float* logit, const int64_t* label, 
     return fail(RSCOTR_E_SHAPE, "rscotr_upsample_ce_bwd: bad shape");
   if (B == 0) return RSCOTR_OK;
   if (!logit || !label || !lse || !grad_scale || !dlogit) return fail(RSCOTR_E_ARG, "rscotr_upsample_ce_bwd: null pointer");
-  upsample_ce_bwd_kernel<<<B * h * w, 128, 0, (hipStream_t)stream>>>(logit, label, lse, grad_scale, dlogit, B, C, h, w, H,
-                                                                   W, ignore_index);
+  static_assert(UCE_TB == 4, "four row groups write the four cell rows of a block");
+  static const bool attr_set = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_ce_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)uce_bwd_lds_bytes());
+    return true;
+  }();
+  (void)attr_set;
+  const int nblk = B * ((h + UCE_TB - 1) / UCE_TB) * ((w + UCE_TB - 1) / UCE_TB);
+  upsample_ce_bwd_kernel<<<nblk, 512, uce_bwd_lds_bytes(), (hipStream_t)stream>>>(logit, label, lse, grad_scale, dlogit, B, C, h,
+                                                                                 w, H, W, ignore_index);
   return check_launch("rscotr_upsample_ce_bwd");
 }

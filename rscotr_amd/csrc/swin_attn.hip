@@ -1124,6 +1124,9 @@ extern "C" int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, co
   // 25 vs 31 us); the matrix-core kernel has the shorter per-item chain (stages 3-4: 16.5 vs 21 us).
   static const int force = getenv("RSCOTR_WATTN_IMPL") ? atoi(getenv("RSCOTR_WATTN_IMPL")) : -1;  // 0 VALU, 1 MFMA
   const int impl = force >= 0 ? force : 2;  // 2: four wavefronts per item
+  // algorithmic work: q k^T and P v of every (image, window, head) on the 49 real tokens: 4 * 49 * 49 * 32 flop
+  const double items = (double)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws) * heads;
+  ProfScope prof(PROF_MFMA, items * 4.0 * 49 * 49 * 32, (hipStream_t)stream, "rscotr::swin_wattn_fwd_kernel");
   if (impl == 0)
     swin_wattn_fwd_kernel<<<wattn_grid(g, B, 8), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
   else if (impl == 1)
@@ -1230,6 +1233,9 @@ extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, co
   static const int phases = getenv("RSCOTR_WATTN_PHASES") ? atoi(getenv("RSCOTR_WATTN_PHASES")) : 4;
   static const int impl = getenv("RSCOTR_WATTN_BWD_IMPL") ? atoi(getenv("RSCOTR_WATTN_BWD_IMPL")) : 2;  // 0 VALU, 1 MFMA, 2 MFMA x 4 waves
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic work: S = q k^T (recomputed), dP = dO v^T, dV = P^T dO, dQ = dS k, dK = dS^T q: 10 * 49 * 49 * 32 flop per item
+  const double items = (double)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws) * heads;
+  ProfScope prof(PROF_MFMA, items * 10.0 * 49 * 49 * 32, s, "rscotr::swin_wattn_bwd_kernel");
   if (impl == 0)
     swin_wattn_bwd_kernel<<<nwg, 64, 0, s>>>(qkv, qkv_bias, bias_table, dout, dqkv, workspace, g, B, phases);
   else if (impl == 1)

@@ -253,7 +253,6 @@ class MTL(nn.Module):
 
     def forward(self, task, img, img_metas, return_loss=True, dataset_name=None, **kwargs):
         ops.WPLANES.begin(task)  # (the weight-plane sets this task uses are refreshed together)
-        ops.PP.clear()           # (activation plane sets live for one forward + backward pass)
         ops.RANGES.begin(img.device)  # (value-range slots of the GEMM operands: one generation per iteration)
         if return_loss:
             return self.forward_train(task=task, img=img, img_metas=img_metas, **kwargs)

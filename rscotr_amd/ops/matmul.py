@@ -24,8 +24,6 @@ class _WeightPlanes:
         # (round 5: with the fp16 split product on, the tiled kernels are as fast as the 128-row weight-plane kernel on its own
         # shapes — 10880 x 256 x 2048: 72 us against 70 — and need no plane sets: the route is only taken with RSCOTR_GEMM_H3=0)
         self.enabled = os.environ.get('RSCOTR_WPLANES', '1') != '0' and not RANGES.enabled
-        self.min_m = int(os.environ.get('RSCOTR_WPLANES_MIN_M', 4096))
-        self.min_k = int(os.environ.get('RSCOTR_WPLANES_MIN_K', 1024))
         self.version = 1
         self.entries, self.groups, self.tables = {}, {}, {}
         self.shape_ok = {}
@@ -38,7 +36,6 @@ class _WeightPlanes:
         """Forget every plane set (a new optimizer arena: addresses may be reused by other parameters)."""
         self.entries, self.groups, self.tables = {}, {}, {}
         self.version += 1
-        PP.reset_weights()
 
     def bump(self):
         self.version += 1
@@ -50,9 +47,8 @@ class _WeightPlanes:
             return False
         if lib.rscotr_gemm_get_precision() != 3:
             return False
-        # the shape: the 128-row weight-plane kernel's domain or, round 4, whatever the tiled split-product kernels take with
-        # their B operand read from the plane set (the library decides: rscotr_gemm_f32_wplanes_ok)
-        key = (M, N, K, bool(gelu))  # (the tiled route is a process-start switch, RSCOTR_WPLANES_TILED: the answer is cached)
+        # the shape: the 128-row weight-plane kernel's domain (the library decides: rscotr_gemm_f32_wplanes_ok)
+        key = (M, N, K, bool(gelu))
         ok = self.shape_ok.get(key)
         if ok is None:
             ok = self.shape_ok[key] = bool(lib.rscotr_gemm_f32_wplanes_ok(M, N, K, int(bool(gelu))))
@@ -94,170 +90,6 @@ class _WeightPlanes:
 WPLANES = _WeightPlanes()
 
 
-class PlaneSet:
-    """The three bf16 planes (ST32 layout, include/rscotr.h) of a stored fp32 tensor (rows x cols).  `src` keeps the tensor the
-    planes were split from alive while the set sits in the cache (its address then cannot be handed to another tensor)."""
-    __slots__ = ('buf', 'rows', 'cols', 'ct', 'src')
-
-    def __init__(self, buf, rows, cols, src=None):
-        self.buf, self.rows, self.cols, self.ct, self.src = buf, rows, cols, (cols + 31) // 32, src
-
-    def ptr(self):
-        return self.buf.data_ptr()
-
-
-def split_planes(X, rows, cols, ld, rowscale=None, rows_per=0, colsum=False, colsum_ptr=0):
-    """rscotr_split_planes: -> (PlaneSet of the (rows, cols) matrix at X with row stride ld [times rowscale per row block],
-    column-sum partial rows (parts, cols) | None).  colsum_ptr: write the partial rows there instead of allocating them."""
-    _chk(X, rowscale)
-    buf = torch.empty(lib.rscotr_planes_bytes(rows, cols) // 2, dtype=torch.int16, device=X.device)
-    parts = None
-    if colsum and not colsum_ptr:
-        parts = torch.empty((lib.rscotr_split_planes_parts(rows), cols), dtype=torch.float32, device=X.device)
-        colsum_ptr = parts.data_ptr()
-    lib.call('rscotr_split_planes', X.data_ptr(), rows, cols, ld, buf.data_ptr(), _ptr(rowscale), int(rows_per), colsum_ptr,
-             _stream())
-    return PlaneSet(buf, rows, cols, X), parts
-
-
-def gemm_pp(a, a_col, b, b_col, M, N, K, out=None, bias=None, act=ACT_NONE, aux=None, pre=None, resid=None, accumulate=False,
-            rowscale=None, rows_per=0, out2=None, defer=False, slab_ptr=0, slab_bytes=0):
-    """rscotr_gemm_pp on two PlaneSets (x_col: the operand's rows are the stored COLUMNS, include/rscotr.h).  defer: a
-    deferred weight gradient — k-slices stay as slabs at slab_ptr; -> (out, slabs written) then."""
-    _chk(out, bias, aux, pre, resid, out2, rowscale)
-    dev = a.buf.device
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    import ctypes
-    splits = ctypes.c_int32(1)
-    if defer:
-        ws, nws = slab_ptr, slab_bytes
-    else:
-        nws = lib.rscotr_gemm_pp_workspace(M, N, K)
-        ws = _WS.get(nws, dev).data_ptr() if nws else 0
-    lib.call('rscotr_gemm_pp', a.ptr(), a.ct, int(a_col), b.ptr(), b.ct, int(b_col), out.data_ptr(), M, N, K, N, _ptr(bias),
-             int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowscale), int(rows_per), _ptr(out2), ws, nws,
-             int(bool(defer)), ctypes.byref(splits), _stream())
-    return (out, splits.value) if defer else out
-
-
-class _PlaneRoute:
-    """Which products run as planes x planes (rscotr_gemm_pp) and where their plane sets come from.
-
-    * parameters: one ST32 set per weight, re-split once per optimizer step for all weights a task multiplies with, in one
-      grouped launch (`WPLANES.version`, shared with the fp32-A weight-plane route);
-    * activations / gradients: split on first use and cached for the rest of the iteration under (address, shape, stride,
-      tensor version, scale) — x serves y = x W^T and dW = dy^T x, dy serves dx = dy W and dW — with the source tensor kept alive
-      by the entry (a hit is therefore the same memory with the same content).  `clear()` at the start of every forward and
-      after every backward: nothing survives from a warm-up iteration into a captured one.
-    A product takes the route when both operands are eligible: precision mode 3, a large enough problem, and no operand that
-    would cost more to split than the product saves (`max_split`: tensors above it only if their planes exist already)."""
-
-    def __init__(self):
-        self.enabled = os.environ.get('RSCOTR_PP', '0') != '0'  # opt-in: in the step it measures no gain yet (class docstring)
-        self.min_rows = int(os.environ.get('RSCOTR_PP_MIN_ROWS', 2048))      # rows of the token-side dimension
-        self.min_work = float(os.environ.get('RSCOTR_PP_MIN_WORK', 4e8))     # M * N * K
-        self.max_split = int(os.environ.get('RSCOTR_PP_MAX_SPLIT', 1 << 23))  # elements of an operand split on the fly
-        self.min_tiles = int(os.environ.get('RSCOTR_PP_MIN_TILES', 512))     # 128 x 128 output tiles (x k-slices for weight gradients)
-        self.min_n = int(os.environ.get('RSCOTR_PP_MIN_N', 1024))            # output columns of a row-major product
-        self.cache = {}
-        self.wentries, self.wgroups, self.wtables = {}, {}, {}
-        self.stats = dict(products=0, splits=0, hits=0)
-
-    def clear(self):
-        self.cache.clear()
-
-    def reset_weights(self):
-        self.wentries, self.wgroups, self.wtables = {}, {}, {}
-
-    # ---- activations
-    def _key(self, t, rows, cols, ld, rowscale, rows_per):
-        return (t.data_ptr(), rows, cols, ld, t._version, _ptr(rowscale), int(rows_per) if rowscale is not None else 0)
-
-    def cached(self, t, rows, cols, ld, rowscale=None, rows_per=0):
-        return self.cache.get(self._key(t, rows, cols, ld, rowscale, rows_per))
-
-    def planes(self, t, rows, cols, ld, rowscale=None, rows_per=0, colsum_ptr=0):
-        key = self._key(t, rows, cols, ld, rowscale, rows_per)
-        e = self.cache.get(key)
-        if e is not None and not colsum_ptr:
-            self.stats['hits'] += 1
-            return e
-        e, _ = split_planes(t, rows, cols, ld, rowscale, rows_per, colsum=bool(colsum_ptr), colsum_ptr=colsum_ptr)
-        if rowscale is not None:
-            e.src = (t, rowscale)
-        self.cache[key] = e
-        self.stats['splits'] += 1
-        return e
-
-    def put(self, t, rows, cols, ld, planeset):
-        """Planes that a producer kernel wrote next to (or instead of) its fp32 output."""
-        planeset.src = t
-        self.cache[self._key(t, rows, cols, ld, None, 0)] = planeset
-
-    # ---- parameters
-    def weight(self, W, rows, cols, ld):
-        key = (W.data_ptr(), rows, cols, ld)
-        e = self.wentries.get(key)
-        if e is None:
-            RT, CT = (rows + 31) // 32, (cols + 31) // 32
-            e = self.wentries[key] = dict(set=PlaneSet(torch.empty(lib.rscotr_planes_bytes(rows, cols) // 2, dtype=torch.int16,
-                                                                   device=W.device), rows, cols),
-                                          version=0, blocks=CT * ((RT * 32 + 255) // 256))
-        keys = self.wgroups.setdefault(WPLANES.current, [])
-        if key not in keys:
-            keys.append(key)
-        if e['version'] != WPLANES.version:
-            stale = tuple(k for k in keys if self.wentries[k]['version'] != WPLANES.version)
-            hit = self.wtables.get(stale)
-            if hit is None:
-                import numpy as np
-                rows_, first = [], 0
-                for (ptr, r, c, l) in stale:
-                    we = self.wentries[(ptr, r, c, l)]
-                    rows_.append((ptr, we['set'].ptr(), r, c, l, first, 0, 0))
-                    first += we['blocks']
-                hit = self.wtables[stale] = (torch.from_numpy(np.asarray(rows_, dtype=np.int64)).to(W.device), len(rows_), first)
-            lib.call('rscotr_split_planes_group', hit[0].data_ptr(), hit[1], hit[2], _stream())
-            for k in stale:
-                self.wentries[k]['version'] = WPLANES.version
-        return e['set']
-
-    # ---- routing
-    def operand(self, T, rows_op, red, ld, kmajor, scale=None, scale_per=0, colsum_ptr=0):
-        """PlaneSet of an operand (rows_op operand rows, reduction length red; k-major: stored (red, rows_op)) or None when the
-        tensor is not worth splitting."""
-        rows, cols = (red, rows_op) if kmajor else (rows_op, red)
-        if scale is None and not colsum_ptr and STATE.grad_sink is not None and STATE.grad_sink.is_param_ptr(T.data_ptr()):
-            return self.weight(T, rows, cols, ld)
-        if rows * cols > self.max_split and self.cached(T, rows, cols, ld, scale, scale_per) is None:
-            return None
-        return self.planes(T, rows, cols, ld, scale, scale_per, colsum_ptr)
-
-    def wanted(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
-        if not self.enabled or STATE.profile is not None or STATE.side is not None:
-            return False
-        if lib.rscotr_gemm_get_precision() != 3:
-            return False
-        tokens = K if (a_kmajor and b_kmajor) else M
-        if tokens < self.min_rows or float(M) * N * K < self.min_work or K < 64 or N < 64 or M < 64:
-            return False
-        # Measured in the step (profiles/r4_pp_in_step.txt): with HBM-cold operands and one workgroup per CU the 128 x 128 ring
-        # is latency-bound — short grids and narrow outputs run no faster than the in-kernel split while paying for the split
-        # passes; the wide, tall products (FFN 256 -> 2048 and its dH: 1360 tiles) gain 20 %.
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        if a_kmajor and b_kmajor:
-            tiles *= max(1, min(-(-384 // tiles), (K // 16) // 16)) if tiles < 192 else 1
-        elif N < self.min_n:
-            return False
-        if tiles < self.min_tiles:
-            return False
-        return A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
-
-
-PP = _PlaneRoute()
-
-
 class _DeferredCombine:
     """Split-K weight-gradient contractions whose result is ACCUMULATED into the gradient arena leave their slabs in a
     private region and are combined by ONE launch at the end of the backward pass (`flush_deferred`, called by the
@@ -272,7 +104,6 @@ class _DeferredCombine:
         self.enabled = os.environ.get('RSCOTR_DEFER_SPLITK', '1') != '0'
         self.blocks, self.cur, self.off = [], 0, 0
         self.entries, self.notify, self.cache = [], [], {}
-        self.keep = []  # plane sets of deferred products: alive until the flush
         self.ln_entries, self.ln_cache = [], {}
         # flush tables are addressed by raw pointer from captured hipGraphs: a table that was looked up while a graph
         # was being warmed up / captured (`pin = True`, set by runner.GraphedTask) is never evicted; the others are
@@ -282,9 +113,8 @@ class _DeferredCombine:
         # weight gradients with small outputs are not launched one by one: their operands are kept alive and ONE grouped
         # launch at the end of backward computes them all (rscotr_gemm_dw_group), then the combine below folds the slabs
         self.group_enabled = os.environ.get('RSCOTR_DW_GROUP', '1') != '0'
-        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '1'))  # 0: fp32 64 x 64 tiles only, 1 / 2: bf16x6 128 x 128 tiles for interior problems, 3: bf16x6 64 x 64, 4: fp32 128 x 128
-        self.group_edge = int(os.environ.get('RSCOTR_DW_GROUP_EDGE', -48))  # members with min(M, N) >= |this| on the bf16x6 edge body: > 0 only the ragged ones (interior ones in a launch of their own), < 0 all of them in one launch, 0 none
-        self.group_big_out = int(os.environ.get('RSCOTR_DW_GROUP_BIG_OUT', 32768))  # (variant 4: outputs from this many elements on)
+        self.group_x6 = int(os.environ.get('RSCOTR_DW_GROUP_X6', '1'))  # 0: every member on the fp32 pipe's 64 x 64 tiles
+        self.group_edge = int(os.environ.get('RSCOTR_DW_GROUP_EDGE', 48))  # members with min(M, N) >= this on the split product's 128 x 128 edge body
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.group_amax, self.amax_cache = {}, {}  # operands of grouped problems whose value range is measured at the flush
         self.pinned_pool, self.pinned_live = [], []
@@ -314,22 +144,13 @@ class _DeferredCombine:
 
         def kind6(p):
             a, b, _, _, _, M, N, K, lda, ldb, _ = p[:11]
-            if self.group_x6 == 4:  # fp32 pipe on 128 x 128 tiles where the output holds at least a few of them
-                return 4 if min(M, N) >= 96 and M * N >= self.group_big_out else 0
-            ok = self.group_x6 and K % 16 == 0 and K >= 64 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
-            if self.group_x6 == 3:  # bf16x6 on 64 x 64 tiles, 32 k per step
-                return 3 if ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512 else 0
-            if self.group_edge and ok and M % 4 == 0 and N % 4 == 0 and min(M, N) >= abs(self.group_edge) and K >= 512:
-                if self.group_edge < 0 or M % 128 or N % 128:
-                    return 6  # ragged (< 0: every member, one launch): the edge instantiation of the same body
-            if ok and M % 128 == 0 and N % 128 == 0:
-                return 2
-            if self.group_x6 == 5 and ok and M % 64 == 0 and N % 64 == 0 and K % 32 == 0 and K >= 512:
-                return 3
-            return 0
+            ok = (self.group_x6 and K % 16 == 0 and K >= 512 and lda % 4 == 0 and ldb % 4 == 0 and a % 16 == 0 and b % 16 == 0
+                  and M % 4 == 0 and N % 4 == 0)
+            # members with min(M, N) >= group_edge on the split product's 128 x 128 edge body (one launch), the rest on the fp32
+            # pipe's 64 x 64 tiles
+            return 6 if ok and self.group_edge and min(M, N) >= abs(self.group_edge) else 0
         kinds = [kind(p) for p in probs]
-        tiles = [(M // 128) * (N // 128) if k == 2 else (M // 64) * (N // 64) if k == 3 else
-                 ((M + 127) // 128) * ((N + 127) // 128) if k in (4, 6, 7) else ((M + 63) // 64) * ((N + 63) // 64)
+        tiles = [((M + 127) // 128) * ((N + 127) // 128) if k in (6, 7) else ((M + 63) // 64) * ((N + 63) // 64)
                  for k, (_, _, _, _, _, M, N, K, _, _, _, _, _) in zip(kinds, probs)]
         # k-slices of about equal WORK per workgroup (a 128 x 128 tile does four times the work of a 64 x 64 one per k), per
         # LAUNCH: with one target for the whole pass the few fp32 64 x 64 members of a det backward (the 4- and 20-row
@@ -337,15 +158,15 @@ class _DeferredCombine:
         # K = 3632 each: 260 us for 0.1 GFLOP
         dev = self.group_keep[0].device
         launches, ents = [], []
-        for variant in (0, 2, 3, 4, 6, 7):
-            work = sum(t * p[7] * (4 if k in (2, 4, 6, 7) else 1) for t, k, p in zip(tiles, kinds, probs) if k == variant)
+        for variant in (0, 6, 7):
+            work = sum(t * p[7] * (4 if k in (6, 7) else 1) for t, k, p in zip(tiles, kinds, probs) if k == variant)
             klen_t = max(256, -(-work // self.GROUP_TARGET_WGS))
             rows = []
             for t, x6, (a, b, out, rs, ks, M, N, K, lda, ldb, kper, sa, sb) in zip(tiles, kinds, probs):
                 if x6 != variant:
                     continue
-                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (2, 4, 6, 7) else 1))))
-                kq = 32 if x6 == 3 else int(os.environ.get('RSCOTR_X6_BK0', 16))  # (lab: the one-stage loop at 32 k per barrier pair)
+                sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (6, 7) else 1))))
+                kq = 16
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
                 if sp == 1:
@@ -421,7 +242,6 @@ class _DeferredCombine:
 
     def drop(self):
         self.entries, self.notify, self.ln_entries = [], [], []
-        self.keep = []
         self.group, self.group_keep = [], []
         self.group_amax = {}
         self.wattn_entries = []
@@ -558,13 +378,13 @@ class _DeferredCombine:
                     for r, e in enumerate(ents):
                         M, N = e[4], e[5]
                         wg.extend((r, c) for c in range((max(M * N // 4, M) + 255) // 256))
-                    hit.append((torch.from_numpy(tab).to(dev), torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg)))
+                    nbytes = float(sum((e[7] + 2) * (e[4] * e[5] + e[4]) * 4 for e in ents))  # slabs read, destination read + written
+                    hit.append((torch.from_numpy(tab).to(dev), torch.from_numpy(np.asarray(wg, dtype=np.int32)).to(dev), len(wg), nbytes))
             self._remember(self.cache, sig, hit)
-            for tab, wg, nwg in hit:
-                lib.call('rscotr_splitk_flush', tab.data_ptr(), wg.data_ptr(), nwg, _stream())
+            for tab, wg, nwg, nbytes in hit:
+                lib.call('rscotr_splitk_flush', tab.data_ptr(), wg.data_ptr(), nwg, nbytes, _stream())
         notify, self.notify = self.notify, []
         self.entries = []
-        self.keep = []
         self.cur = self.off = 0
         if STATE.grad_sink is not None:
             for i in notify:
@@ -579,7 +399,6 @@ def flush_deferred():
     gradients into the arena (no-op when nothing is pending)."""
     if DEFER.pending() or DEFER.notify:
         DEFER.flush()
-    PP.clear()  # (the plane sets of this pass: nothing of them is read after backward)
 
 
 def _dw_ranges(A, B, M, N, K, lda, ldb):
@@ -635,68 +454,6 @@ def _in_arena(t):
     return lo <= t.data_ptr() < lo + sink.flat_g.numel() * 4
 
 
-def _gemm_pp_route(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out, bias, act, aux, pre, resid, accumulate, rowsum,
-                   rowsum_accumulate, rowscale, rows_per, kscale, krows_per, out2):
-    """The product as planes x planes (rscotr_gemm_pp) -> out, or None when an operand is not worth splitting.  The per-sample
-    scale of a DropPath / Mixup rides the SPLIT of dy (planes of s * dy: dx = (s dy) W and dW = (s dy)^T x read the same set), the
-    bias gradient (row sums of the k-major A) the split pass too (column-sum partial rows, folded by the deferred combine)."""
-    a_scale, a_per, ep_scale, ep_per = None, 0, rowscale, rows_per
-    if kscale is not None:
-        a_scale, a_per = kscale, krows_per
-    elif (rowscale is not None and not a_kmajor and bias is None and pre is None
-          and act in (ACT_NONE, ACT_RELU_GRAD, ACT_GELU_GRAD)):
-        a_scale, a_per, ep_scale, ep_per = rowscale, rows_per, None, 0  # (multiplicative epilogues commute with the row factor)
-    dev = A.device
-    deferred = (accumulate and a_kmajor and b_kmajor and bias is None and act == ACT_NONE and resid is None and pre is None
-                and rowscale is None and (rowsum is None or rowsum_accumulate) and DEFER.enabled and _in_arena(out)
-                and N % 4 == 0 and out.data_ptr() % 16 == 0 and (rowsum is None or _in_arena(rowsum)))
-    cs_ptr, parts = 0, 0
-    if rowsum is not None:
-        if not a_kmajor:
-            return None
-        parts = lib.rscotr_split_planes_parts(K)
-        cs_ptr = DEFER.reserve(parts * M * 4, dev) if deferred else _WS_PARTS.get(parts * M * 4, dev)
-    pb = PP.operand(B, N, K, ldb, b_kmajor)
-    if pb is None:
-        return None
-    pa = PP.operand(A, M, K, lda, a_kmajor, a_scale, a_per, cs_ptr)
-    if pa is None:
-        return None
-    PP.stats['products'] += 1
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    if deferred:
-        nws = lib.rscotr_gemm_pp_workspace(M, N, K)
-        slab = DEFER.reserve(nws, dev) if nws else 0
-        _, sp = gemm_pp(pa, a_kmajor, pb, b_kmajor, M, N, K, out=out, accumulate=True, defer=True, slab_ptr=slab, slab_bytes=nws)
-        if sp > 1:
-            DEFER.entries.append((slab, 0, out.data_ptr(), 0, M, N, N, sp))
-        if rowsum is not None:
-            DEFER.entries.append((0, cs_ptr, 0, rowsum.data_ptr(), M, 0, 0, parts))
-        DEFER.keep.append((pa, pb))
-        return out
-    gemm_pp(pa, a_kmajor, pb, b_kmajor, M, N, K, out=out, bias=bias, act=act, aux=aux, pre=pre, resid=resid,
-            accumulate=accumulate, rowscale=ep_scale, rows_per=ep_per, out2=out2)
-    if rowsum is not None:  # fold the partial rows now: (parts, M) column sums
-        part_t = _WS_PARTS.last
-        colsum(part_t, parts, M, out=rowsum, accumulate=rowsum_accumulate)
-    return out
-
-
-class _PartsWS:
-    """Scratch for the column-sum partial rows of a split pass that is folded right away (not deferred)."""
-
-    def __init__(self):
-        self.last = None
-
-    def get(self, nbytes, dev):
-        self.last = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        return self.last.data_ptr()
-
-
-_WS_PARTS = _PartsWS()
-
-
 def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=ACT_NONE, aux=None, pre=None,
          resid=None, accumulate=False, rowsum=None, rowsum_accumulate=False, rowscale=None, rows_per=0, kscale=None,
          krows_per=0, out2=None, amax_a=0, amax_b=0, amax_out=0):
@@ -706,15 +463,6 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     contraction).  `out2` (M,N): second output out + resid, `out` itself then stays without the residual.
     Returns out."""
     _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
-    if PP.wanted(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor):
-        # grouped weight gradients (small outputs) keep their one launch per backward pass
-        grouped = (a_kmajor and b_kmajor and accumulate and DEFER.enabled and DEFER.group_enabled and DEFER.grouped_size(M, N, K)
-                   and _in_arena(out))
-        if not grouped:
-            r = _gemm_pp_route(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out, bias, act, aux, pre, resid, accumulate, rowsum,
-                               rowsum_accumulate, rowscale, rows_per, kscale, krows_per, out2)
-            if r is not None:
-                return r
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     if (rowsum is None and kscale is None and STATE.profile is None

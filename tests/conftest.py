@@ -50,8 +50,7 @@ def _product_state():
     st = dict(switches=tuple(sorted(ops.STATE.changed().items())),
               hooks=(ops.STATE.side is None, ops.STATE.profile is None),
               defer=(ops.DEFER.enabled, ops.DEFER.group_enabled, ops.DEFER.group_x6, ops.DEFER.pin),
-              wplanes=(ops.WPLANES.enabled, ops.WPLANES.min_m, ops.WPLANES.min_k),
-              pp=(ops.PP.enabled, ops.PP.min_rows, ops.PP.min_work, ops.PP.max_split, ops.PP.min_tiles, ops.PP.min_n),
+              wplanes=(ops.WPLANES.enabled,),
               ranges=(ops.RANGES.enabled, ops.RANGES.check),
               env=tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('RSCOTR_'))))
     if os.path.exists(LIB_PATH):
@@ -89,7 +88,7 @@ def pytest_terminal_summary(terminalreporter):
         tr.write_line(f"{r['test']}: {r['tensors'] - r['over_tight']}/{r['tensors']} tensors within 1e-3 of the fp32 oracle; "
                       f"decided_by_fp64_anchor={r['decided_by_fp64_anchor']}"
                       + ('' if a is None else f"; anchor {a['within']}/{a['of']} within bound, worst ratio {a['worst_ratio']} "
-                                               f"({a['worst_tensor']}), median ep {a['ep_med']} / eo {a['eo_med']}"
+                                               f"({a['worst_tensor']}), median ep {a['ep_med']} / eo {a['eo_med']} / amb {a.get('amb_med')}"
                                                + ('' if not a.get('loose_explained') else
                                                   f"; tensors outside the 1e-3 tier explained by the fp64 evaluation / coin-toss "
                                                   f"band: {a['loose_explained'][0]}/{a['loose_explained'][1]}")))

@@ -34,7 +34,7 @@ def cast_tree(obj, dt):
     return obj
 
 
-def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None, relu_band=None):
+def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None, relu_band=None, bilinear_band=None):
     """The oracle's train step evaluated in fp64 on the same weights, batch and draws, under the SAME hard decisions the
     fp32 evaluation took where they are injectable (seg attention masks and det top-k ride in rnd_cpu already; the 7*B
     assignments come from the fp32 record): the reference point that tells rounding error from wrong arithmetic.
@@ -45,13 +45,13 @@ def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None, relu_band=No
     if orec32 is not None and orec32.get('match'):
         rnd64['det_match'] = orec32['match']
     from oracle import ops as O
-    O.RELU_BAND = relu_band
+    O.RELU_BAND, O.BILINEAR_BAND = relu_band, bilinear_band
     try:
         with default_dtype(torch.float64):
             out = OM.train_step(P64, model_cfg, cast_tree(batch_cpu, torch.float64), rnd64, {})
             out['loss'].backward()
     finally:
-        O.RELU_BAND = None
+        O.RELU_BAND = O.BILINEAR_BAND = None
     return P64, out
 
 
@@ -81,8 +81,10 @@ def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2
     oout['loss'].backward()
     def fp64_anchor():
         orec['P64'], orec['out64'] = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec)
-        # the same step with every ReLU gate within RELU_BAND of zero flipped: how far coin-toss gates can move a gradient
-        orec['P64b'], _ = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec, relu_band=RELU_BAND)
+        # the same step with every ReLU gate within RELU_BAND of zero flipped and every deformable-attention sample within
+        # BILINEAR_BAND of a cell boundary taken from the neighbouring cell: how far coin-toss decisions can move a gradient
+        orec['P64b'], _ = oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec, relu_band=RELU_BAND,
+                                           bilinear_band=BILINEAR_BAND)
 
     if fp64:
         fp64_anchor()
@@ -114,6 +116,7 @@ def grad_report(model, P):
 
 
 RELU_BAND = 3e-6  # gates within 3e-6 of the mean |pre-activation| of zero count as coin tosses (fp32 products: ~1e-6)
+BILINEAR_BAND = 2e-5  # sampling coordinates within 2e-5 pixels of a cell boundary (fp32 rounding of loc * W - 0.5 at W ~ 100: ~1e-5)
 
 
 def anchor_report(model, P, P64, P64b=None):
@@ -180,7 +183,10 @@ ANCHOR_EO_CLEAN = 10.0
 PARITY_LOG = []
 
 
-def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LOOSE_MAX):
+def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LOOSE_MAX, median_rel=False):
+    """median_rel: the median tensor may be ANCHOR_K_MED x as far from the fp64 evaluation as the fp32 oracle's own median /
+    the step's median coin-toss ambiguity where those exceed 1e-4 — only for the cases named in ANCHOR_K_MED's comment
+    (everywhere else the absolute 1e-4 holds)."""
     if 'topk_idx' in rec and 'topk_idx' in orec:
         # proposal selection: the product's top-k vs the oracle's own.  Order and membership must agree
         # except where the scores involved are within fp32 rounding of each other.
@@ -257,7 +263,8 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
                                  unexplained[:5])
         assert within >= ANCHOR_FRACTION * len(rep), out['anchor_report']
         assert ratio[0][0] <= (1.0 if decided else ANCHOR_K_ALL), out['anchor_report']
-        assert ep_med <= max(ANCHOR_EP_MEDIAN, ANCHOR_K_MED * max(eo_med, amb_med)), out['anchor_report']
+        assert ep_med <= (max(ANCHOR_EP_MEDIAN, ANCHOR_K_MED * max(eo_med, amb_med)) if median_rel else ANCHOR_EP_MEDIAN), \
+            out['anchor_report']
     import os
     PARITY_LOG.append(dict(test=os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], tensors=len(rows),
                            over_tight=len(loose), decided_by_fp64_anchor=decided,
@@ -267,7 +274,8 @@ def check_step_pair(model, out, oout, rec, orec, P, grad_rtol=None, loose_max=LO
                                worst_ratio=round(out['anchor_report']['worst'][0][0], 3),
                                worst_tensor=out['anchor_report']['worst'][0][1],
                                ep_med=float(f"{out['anchor_report']['ep_med']:.3g}"),
-                               eo_med=float(f"{out['anchor_report']['eo_med']:.3g}"))))
+                               eo_med=float(f"{out['anchor_report']['eo_med']:.3g}"),
+                               amb_med=float(f"{out['anchor_report']['amb_med']:.3g}"))))
     if 'attn_masks' in rec and 'attn_masks' in orec:
         # masked-attention decisions: the oracle's own masks vs the product's, bit for bit; a logit
         # within fp32 rounding of 0 may land on either side, nothing else may differ

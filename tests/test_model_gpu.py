@@ -60,41 +60,6 @@ def test_train_step_main_config_512(task, prec, cuda):
     check_step_pair(model, out, oout, rec, orec, P)
 
 
-@pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
-def test_train_step_512_bf16x3_mode(task, cuda):
-    """The opt-in precision mode 2 (large products as three bf16 MFMAs on hi / lo splits, fp32 accumulate) at the same
-    size: log keys, every loss within 1e-3 of the oracle's, Hungarian indices as the oracle's, and every gradient tensor
-    within 1e-1 in relative L2 (3e-2 for all but the two tensors of a single FFN layer whose ReLU gates
-    flip: 4.6e-2 with this build, deterministic).  The tight gradient tier (1e-3 per tensor) is NOT asserted: the split product moves
-    pre-activations by ~5e-6 of their maximum, ten times the fp32 pipe, and the hard decisions of the step (ReLU gates, the
-    seg attention masks) that flip with it change upstream gradients by 0.1-2 % (seg: 10 to 440 of 459 tensors outside the
-    tight tier from run to run; fp32 pipe: 0-2) — the reason the mode is not the default (profiles/README.md)."""
-    from parity import RTOL, grad_report
-    from util import rel_err
-    from rscotr_amd._lib import lib
-    old = lib.rscotr_gemm_get_precision()
-    lib.call('rscotr_gemm_set_precision', 2)
-    try:
-        cfg, mcfg = load_model_cfg(tiny=False)
-        model = build_model(mcfg, seed=4).to(cuda)
-        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda)
-    finally:
-        lib.call('rscotr_gemm_set_precision', old)
-    assert list(out['log_vars'].keys()) == list(oout['log_vars'].keys())
-    for k, v in out['log_vars'].items():
-        ref = oout['log_vars'][k]
-        assert abs(v - ref) <= RTOL * max(abs(ref), 1e-3), (k, v, ref)
-    assert rel_err(out['loss'], oout['loss']) <= RTOL
-    if 'match' in rec:  # assignment indices of all 7*B matchings, as in parity.check_step_pair
-        for (s_, i), (r, c) in rec['match'].items():
-            o = orec['match']['interm' if s_ == 0 else f'dec{s_ - 1}'][i]
-            assert torch.equal(torch.from_numpy(r), o['pos_inds']) and torch.equal(torch.from_numpy(c), o['pos_assigned_gt_inds']), (s_, i)
-    gmax = max(float(p.grad.abs().max()) for p in P.values() if p.grad is not None)
-    bad = [(n, c) for n, a, b, c in grad_report(model, P)
-           if c > 1e-1 and float(P[n].grad.abs().max()) > 1e-4 * gmax]  # (tensors whose exact gradient is ~0 only hold noise)
-    assert not bad, bad[:5]
-
-
 def test_det_static_path_equals_dynamic_path_full_size(cuda):
     """BASELINE configs[1] size (512x512, B=2, 600 queries, 100 CDN): the shape-static det iteration (padded ground
     truth, masked extra denoising slots, device-side assignment) against the reference-shaped dynamic path (host
@@ -147,4 +112,6 @@ def test_mlvl_cls_head_variant(cuda, scheme, size):
     mcfg['cls_head']['scheme'] = scheme
     model = build_model(mcfg, seed=scheme).to(cuda)
     out, oout, rec, orec, P = run_step_pair(model, mcfg, 'cls', size, seed=13, device=cuda)
-    check_step_pair(model, out, oout, rec, orec, P)
+    # (scheme 7 at 224^2: every tensor within 1.2 x max(eo, amb), the median inside the step's coin-toss band — the one case of
+    # this file where the median gate is the relative one: tests/parity.py, ANCHOR_K_MED)
+    check_step_pair(model, out, oout, rec, orec, P, median_rel=scheme == 7)

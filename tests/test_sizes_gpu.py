@@ -30,7 +30,7 @@ def test_det_step_800_bs4_matches_oracle(cuda):
     out, oout, rec, orec, P = run_step_pair(model, mcfg, 'det', 800, seed=29, device=cuda, batch_size=4, max_gt=50)
     assert len(rec['match']) == 7 * 4
     assert max(len(r) for r, c in rec['match'].values()) > 20  # the batch really holds more ground truths than configs[1]'s 20
-    check_step_pair(model, out, oout, rec, orec, P, loose_max=None)
+    check_step_pair(model, out, oout, rec, orec, P)
 
 
 @pytest.mark.timeout(2400)
@@ -42,7 +42,8 @@ def test_swin_b_1024_step_matches_oracle(task, cuda):
     cfg, mcfg = swin_b_cfg()
     model = build_model(mcfg, seed=7).to(cuda)
     out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 1024, seed=31, device=cuda, batch_size=1)
-    check_step_pair(model, out, oout, rec, orec, P, loose_max=None)
+    # (median gate relative to the fp32 oracle's own distance from fp64: at this size the ORACLE's median is 2.4e-4 for det)
+    check_step_pair(model, out, oout, rec, orec, P, median_rel=True)
 
 
 def _losses_and_grads(model, batch, rnd):
