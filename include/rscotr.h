@@ -67,7 +67,8 @@ int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes,
                     const int64_t* level_start_index, const float* loc, const float* attn,
                     const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
                     int B, int Nk, int Nq, int H, int D, int L, int P, const int64_t* shapes_host,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    void* workspace, int64_t workspace_bytes, uint32_t* amax_grad_value,
+                    void* stream);
 int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L, int P);
 int64_t rscotr_msda_bwd_tiled_workspace(const int64_t* shapes_host, int B, int Nk, int Nq, int H, int D, int L, int P);
 /* The element-wise prologue of mmcv MultiScaleDeformableAttention.forward in one launch per direction:
@@ -84,7 +85,7 @@ int rscotr_msda_prep_fwd(const float* off, const float* logit, const float* ref,
                          int ref_levels, void* stream);
 int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn, const float* ref,
                          const float* norm, float* grad_off, float* grad_logit, int B, int Nq, int H, int L, int P,
-                         int refdim, int ld_off, int ld_logit, int ref_levels, void* stream);
+                         int refdim, int ld_off, int ld_logit, int ref_levels, uint32_t* amax_out, void* stream);
 
 /* ---- fp32 GEMM on the matrix cores, fused epilogue ----------------------------------------------
  * Replaces torch F.linear / nn.Linear and 1x1 / patchify nn.Conv2d (and the two backward
@@ -357,12 +358,13 @@ int rscotr_layernorm_flush(const int64_t* table, const int32_t* wgmap, int nwg, 
  * delta_i = sum_j P_ij dP_ij is taken as dO_i . O_i (a 32-channel dot product) instead of a cross-lane reduction.
  * Default kernels: four wavefronts per (window, head) item, matrix cores for the five 49x49x32 products. */
 int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
-                          int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+                          int B, int H, int W, int C, int heads, int ws, int shift, uint32_t* amax_out,
+                         void* stream);
 int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, int heads);
 int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* dout,
                           float* dqkv, float* dqkv_bias, float* dbias_table, int B, int H, int W, int C,
                           int heads, int ws, int shift, const float* out, float* workspace,
-                          int64_t workspace_bytes, void* stream);
+                          int64_t workspace_bytes, uint32_t* amax_out, void* stream);
 /* table: device (n, 16) int64 rows {partial rows, dbias_table | 0, dqkv_bias | 0, heads, C, rows per head (= workspace bytes
  * / (heads * 268 * 4)), running sum of `heads` over the previous rows, 0 ...}; total_heads = sum of heads. */
 int rscotr_swin_wattn_flush(const int64_t* table, int n, int total_heads, void* stream);
@@ -450,7 +452,7 @@ int rscotr_sum8(const float* p0, const float* p1, const float* p2, const float* 
  * layers that read the same operand, e.g. mmcv MultiScaleDeformableAttention's sampling_offsets and attention_weights,
  * so that they run as one product). */
 int rscotr_pack4(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* d,
-                 int64_t nd, float* out, void* stream);
+                 int64_t nd, float* out, uint32_t* amax_out, void* stream);
 int64_t rscotr_level_embed_bwd_workspace(int L, int C);
 int rscotr_level_embed_bwd(const float* g, float* dw, const int* sizes, int L, int B, int N, int C, int accumulate,
                            float* workspace, int* counters, void* stream);

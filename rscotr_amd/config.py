@@ -127,8 +127,12 @@ class Config:
         object.__setattr__(self, 'filename', filename)
 
     @staticmethod
-    def fromfile(path):
-        return Config(_load_file(path), filename=path)
+    def fromfile(path, import_custom_modules=True):
+        cfg = Config(_load_file(path), filename=path)
+        if import_custom_modules and cfg.get('custom_imports'):  # mmcv Config.fromfile(import_custom_modules=True)
+            from .compat import apply_custom_imports
+            apply_custom_imports(cfg)
+        return cfg
 
     def __getattr__(self, name):
         return getattr(self._cfg_dict, name)

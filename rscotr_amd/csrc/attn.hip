@@ -190,10 +190,12 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restr
                                                             const float* __restrict__ attn, const float* __restrict__ ref,
                                                             const float* __restrict__ norm, float* __restrict__ goff,
                                                             float* __restrict__ glogit, long groups, int Nq, int H, int L,
-                                                            int P, int refdim, int ld_off, int ld_logit, int ref_levels) {
+                                                            int P, int refdim, int ld_off, int ld_logit, int ref_levels,
+                                                            unsigned* __restrict__ amax_out) {
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
   const int s = threadIdx.x % G, LP = L * P;
   const bool in = gid < groups && s < LP;
+  float amx = 0.f;  // max |grad_off|, |grad_logit| -> the range word of the gradient (common.h: amax_commit)
   const long e = gid * LP + s;
   const long bq = gid / H;
   const int h = (int)(gid - bq * H);
@@ -213,9 +215,15 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restr
       out.y = g.y * (r[3] * 0.5f) / (float)P;
     }
     *reinterpret_cast<float2*>(goff + bq * ld_off + (h * LP + s) * 2) = out;
+    amx = fmaxf(fabsf(out.x), fabsf(out.y));
   }
   const float dot = group_sum<G>(p * ga);
-  if (in) glogit[bq * ld_logit + h * LP + s] = p * (ga - dot);
+  if (in) {
+    const float gl = p * (ga - dot);
+    glogit[bq * ld_logit + h * LP + s] = gl;
+    amx = fmaxf(amx, fabsf(gl));
+  }
+  amax_commit(amax_out, amx);
 }
 
 }  // namespace rscotr
@@ -258,14 +266,14 @@ extern "C" int rscotr_msda_prep_fwd(const float* off, const float* logit, const 
 
 extern "C" int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn, const float* ref,
                                     const float* norm, float* grad_off, float* grad_logit, int B, int Nq, int H, int L,
-                                    int P, int refdim, int ld_off, int ld_logit, int ref_levels, void* stream) {
+                                    int P, int refdim, int ld_off, int ld_logit, int ref_levels, uint32_t* amax_out, void* stream) {
   if (int e = msda_prep_check("rscotr_msda_prep_bwd", B, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)) return e;
   const long groups = (long)B * Nq * H;
   if (groups == 0) return RSCOTR_OK;
   if (!grad_loc || !grad_attn || !attn || !ref || !grad_off || !grad_logit || (refdim == 2 && !norm))
     return fail(RSCOTR_E_ARG, "rscotr_msda_prep_bwd: null pointer");
 #define CALL(G) \
-  msda_prep_bwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_loc, grad_attn, attn, ref, norm, grad_off, grad_logit, groups, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels)
+  msda_prep_bwd_kernel<G><<<(unsigned)((groups * G + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_loc, grad_attn, attn, ref, norm, grad_off, grad_logit, groups, Nq, H, L, P, refdim, ld_off, ld_logit, ref_levels, amax_out)
   MSDA_PREP_DISPATCH(L * P, CALL);
 #undef CALL
   return check_launch("rscotr_msda_prep_bwd");

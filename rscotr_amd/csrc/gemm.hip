@@ -871,6 +871,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     return;
   }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
+  // exactly one extra tensor read by the epilogue (aux of act', residual, or old C): its 16 values per tile in one batch
+  // (64 x 64 tiles only: on the 128 x 128 one-stage kernel the 16-register batch costs the third resident workgroup)
+  const bool one_extra = BM == 64 && !p.C2 &&
+                         ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
   float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -881,7 +885,10 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       const float bv = p.bias ? p.bias[n] : 0.f;
       const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * g;
       float* crow = p.C + (long)mb * p.ldc + n;
-      if (plain) {
+      if (one_extra) {
+        epilogue_tile16<EDGE>(p, acc[i][j], bv, mb, n, amx);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (plain) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (!EDGE || mb + (r & 3) + 8 * (r >> 2) < p.M) {

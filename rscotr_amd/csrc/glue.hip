@@ -86,16 +86,18 @@ __global__ __launch_bounds__(256) void level_embed_bwd_kernel(const float* __res
 // out = [a | b | c | d] (flat concatenation of up to four arrays), one thread per element
 __global__ __launch_bounds__(256) void pack4_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb,
                                                     const float* __restrict__ c, long nc, const float* __restrict__ d, long nd,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, unsigned* __restrict__ amax_out) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long o = i;
-  if (i < na) { out[o] = a[i]; return; }
-  i -= na;
-  if (i < nb) { out[o] = b[i]; return; }
-  i -= nb;
-  if (i < nc) { out[o] = c[i]; return; }
-  i -= nc;
-  if (i < nd) out[o] = d[i];
+  float v = 0.f;
+  bool ok = true;
+  if (i < na) v = a[i];
+  else if ((i -= na) < nb) v = b[i];
+  else if ((i -= nb) < nc) v = c[i];
+  else if ((i -= nc) < nd) v = d[i];
+  else ok = false;
+  if (ok) out[o] = v;
+  amax_commit(amax_out, fabsf(v));  // (the range word of the packed tensor: common.h)
 }
 
 
@@ -319,12 +321,12 @@ extern "C" int rscotr_level_embed_bwd(const float* g, float* dw, const int* size
 }
 
 extern "C" int rscotr_pack4(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* d,
-                            int64_t nd, float* out, void* stream) {
+                            int64_t nd, float* out, uint32_t* amax_out, void* stream) {
   if (na < 0 || nb < 0 || nc < 0 || nd < 0) return fail(RSCOTR_E_SHAPE, "rscotr_pack4: negative length");
   const long total = na + nb + nc + nd;
   if (total == 0) return RSCOTR_OK;
   if (!out || (na && !a) || (nb && !b) || (nc && !c) || (nd && !d)) return fail(RSCOTR_E_ARG, "rscotr_pack4: null pointer");
-  pack4_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, na, b, nb, c, nc, d, nd, out);
+  pack4_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, na, b, nb, c, nc, d, nd, out, amax_out);
   return check_launch("rscotr_pack4");
 }
 

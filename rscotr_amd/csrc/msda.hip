@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "rscotr.h"
 
 namespace rscotr {
 
@@ -1244,42 +1245,47 @@ __global__ __launch_bounds__(256, MSDA_T_OCC(D)) void msda_tile_kernel(const flo
 // fixed order.  D/4 lanes per token; workgroups mapped like msda_tile_kernel (one XCD per (b, h)).
 template <int D>
 __global__ __launch_bounds__(256) void msda_tile_combine_kernel(const float* __restrict__ part, float* __restrict__ grad_value,
-                                                                MsdaTiles T, int Nk, int H, int BH, int bpb) {
+                                                                MsdaTiles T, int Nk, int H, int BH, int bpb,
+                                                                unsigned* __restrict__ amax_out) {
   constexpr int G = D / 4, TPB = 256 / G;
   constexpr int NCELL = MsdaTileGeom<D>::NCELL;
   const int x8 = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int bh = x8 + 8 * (j / bpb), blk = j % bpb;
   if (bh >= BH) return;
   const int tok = blk * TPB + threadIdx.x / G, c4 = threadIdx.x % G;
-  if (tok >= Nk) return;
-  const int b = bh / H, h = bh - b * H;
-  int l = 0;
-  while (l + 1 < T.L && tok >= T.lsi[l + 1]) ++l;
-  const int Wl = T.Wl[l], tsx = T.tsx[l], tsy = T.tsy[l], ntx = T.ntx[l], nch = T.nch[l];
-  const int rr = tok - T.lsi[l], y = rr / Wl, x = rr - y * Wl;
-  const int cx = x + 1, cy = y + 1;  // extended-grid cell of the token
-  const int tx = cx / tsx, ty = cy / tsy, lx = cx - tx * tsx, ly = cy - ty * tsy;
-  const float* base = part + ((long)bh * T.NW + T.wbase[l]) * NCELL * D + c4 * 4;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto tile_cells = [&](int ttx, int tty, int ccy, int ccx) {
-    const float* p = base + ((long)(tty * ntx + ttx) * nch * NCELL + ccy * MSDA_T_CW + ccx) * D;
-    for (int c = 0; c < nch; ++c) {
-      const float4 u = *reinterpret_cast<const float4*>(p + (long)c * NCELL * D);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-  };
-  const bool hx = lx == 0 && tx > 0, hy = ly == 0 && ty > 0;  // also the halo column / row of the left / upper tile
-  if (hx && hy) tile_cells(tx - 1, ty - 1, tsy, tsx);
-  if (hy) tile_cells(tx, ty - 1, tsy, lx);
-  if (hx) tile_cells(tx - 1, ty, ly, tsx);
-  tile_cells(tx, ty, ly, lx);
-  *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + tok) * H + h) * D + c4 * 4) = v;
+  float amx = 0.f;  // max |grad_value| of this lane -> the tensor's range word (the value projection's dX / dW operand)
+  if (tok < Nk) {
+    const int b = bh / H, h = bh - b * H;
+    int l = 0;
+    while (l + 1 < T.L && tok >= T.lsi[l + 1]) ++l;
+    const int Wl = T.Wl[l], tsx = T.tsx[l], tsy = T.tsy[l], ntx = T.ntx[l], nch = T.nch[l];
+    const int rr = tok - T.lsi[l], y = rr / Wl, x = rr - y * Wl;
+    const int cx = x + 1, cy = y + 1;  // extended-grid cell of the token
+    const int tx = cx / tsx, ty = cy / tsy, lx = cx - tx * tsx, ly = cy - ty * tsy;
+    const float* base = part + ((long)bh * T.NW + T.wbase[l]) * NCELL * D + c4 * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto tile_cells = [&](int ttx, int tty, int ccy, int ccx) {
+      const float* p = base + ((long)(tty * ntx + ttx) * nch * NCELL + ccy * MSDA_T_CW + ccx) * D;
+      for (int c = 0; c < nch; ++c) {
+        const float4 u = *reinterpret_cast<const float4*>(p + (long)c * NCELL * D);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+    };
+    const bool hx = lx == 0 && tx > 0, hy = ly == 0 && ty > 0;  // also the halo column / row of the left / upper tile
+    if (hx && hy) tile_cells(tx - 1, ty - 1, tsy, tsx);
+    if (hy) tile_cells(tx, ty - 1, tsy, lx);
+    if (hx) tile_cells(tx - 1, ty, ly, tsx);
+    tile_cells(tx, ty, ly, lx);
+    *reinterpret_cast<float4*>(grad_value + (((long)b * Nk + tok) * H + h) * D + c4 * 4) = v;
+    amx = amax4(0.f, v);
+  }
+  amax_commit(amax_out, amx);  // (every lane of the wavefront, also those past the last token)
 }
 
 template <int D, int P>
 static void launch_bwd_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                              const float* go, float* gv, float* gl, float* ga, int B, int Nk, int Nq, int H, int L,
-                             const MsdaTiles& T, char* ws, hipStream_t s) {
+                             const MsdaTiles& T, char* ws, hipStream_t s, unsigned* amax_gv) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
   const size_t shm = (size_t)QB * L * P * 7 * sizeof(float) + 64;  // + bin words staged for a coalesced store, + masks
@@ -1304,7 +1310,7 @@ static void launch_bwd_tiled(const float* value, const int64_t* shapes, const in
   while ((1 << bshift) < QB * P) ++bshift;
   msda_tile_kernel<D, P><<<dim3(bh8 * (unsigned)T.NW), 256, lds, s>>>(go, loc, attn, binw, mask, part, T, Nq, bshift, ntiles, H, BH);
   const int bpb = (Nk + 256 / (D / 4) - 1) / (256 / (D / 4));
-  msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb);
+  msda_tile_combine_kernel<D><<<dim3(bh8 * (unsigned)bpb), 256, 0, s>>>(part, gv, T, Nk, H, BH, bpb, amax_gv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1448,7 +1454,7 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
                                const float* attn, const float* grad_out, float* grad_value,
                                float* grad_loc, float* grad_attn, int B, int Nk, int Nq, int H,
                                int D, int L, int P, const int64_t* shapes_host, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+                               int64_t workspace_bytes, uint32_t* amax_grad_value, void* stream) {
   if (int e = check_shape("rscotr_msda_bwd", B, Nk, Nq, H, D, L, P)) return e;
   if (B == 0 || Nq == 0) return RSCOTR_OK;  // grad_value stays as zeroed by the caller
   if (!value || !spatial_shapes || !level_start_index || !loc || !attn || !grad_out ||
@@ -1467,7 +1473,7 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
       if (!aligned16(workspace)) return fail(RSCOTR_E_ALIGN, "rscotr_msda_bwd: workspace must be 16-byte aligned");
 #define CALL(DD, PP)                                                                                    \
   launch_bwd_tiled<DD, PP>(value, spatial_shapes, level_start_index, loc, attn, grad_out, grad_value, \
-                           grad_loc, grad_attn, B, Nk, Nq, H, L, T, (char*)workspace, s)
+                           grad_loc, grad_attn, B, Nk, Nq, H, L, T, (char*)workspace, s, amax_grad_value)
       RSCOTR_DISPATCH_DP(D, P, CALL)
 #undef CALL
       return check_launch("rscotr_msda_bwd (tiled)");
@@ -1482,12 +1488,15 @@ extern "C" int rscotr_msda_bwd(const float* value, const int64_t* spatial_shapes
                             grad_loc, grad_attn, B, Nk, Nq, H, L, ws, s)
     RSCOTR_DISPATCH_DP(D, P, CALL)
 #undef CALL
-    return check_launch("rscotr_msda_bwd (sorted)");
+    if (int e = check_launch("rscotr_msda_bwd (sorted)")) return e;
+    // (only the tiled strategy's combine kernel folds the range of grad_value itself: measure it here)
+    return amax_grad_value ? rscotr_amax_f32(grad_value, (int64_t)B * Nk, H * D, H * D, amax_grad_value, stream) : RSCOTR_OK;
   }
 #define CALL(DD, PP)                                                                            \
   launch_bwd<DD, PP>(value, spatial_shapes, level_start_index, loc, attn, grad_out, grad_value, \
                      grad_loc, grad_attn, B, Nk, Nq, H, L, s)
   RSCOTR_DISPATCH_DP(D, P, CALL)
 #undef CALL
-  return check_launch("rscotr_msda_bwd");
+  if (int e = check_launch("rscotr_msda_bwd")) return e;
+  return amax_grad_value ? rscotr_amax_f32(grad_value, (int64_t)B * Nk, H * D, H * D, amax_grad_value, stream) : RSCOTR_OK;
 }

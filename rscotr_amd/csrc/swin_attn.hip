@@ -25,6 +25,7 @@
 // matrix for the column-wise products (dV, dK), and accumulates the bias-table and pad-token
 // (qkv-bias) gradients in LDS, leaving one atomic per entry per workgroup.
 #include "common.h"
+#include "rscotr.h"
 #include <stdlib.h>
 
 namespace rscotr {
@@ -870,11 +871,13 @@ __device__ __forceinline__ void stage_item_tiles(float* sQ, float* sK, float* sV
 __global__ __launch_bounds__(256) void swin_wattn_fwd_mfma4_kernel(const float* __restrict__ qkv,
                                                                    const float* __restrict__ qkv_b,
                                                                    const float* __restrict__ table,
-                                                                   float* __restrict__ out, WinGeom g, int B) {
+                                                                   float* __restrict__ out, WinGeom g, int B,
+                                                                   unsigned* __restrict__ amax_out) {
   __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT];
   __shared__ float sP[NPD * LDP];
   __shared__ float sT[TBL];
   __shared__ int sLab[WN], sTok[WN];
+  float amx = 0.f;  // max |out| -> the output's range word (the proj Linear multiplies with it)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int head = blockIdx.x % g.heads;
   const int stride = gridDim.x / g.heads;
@@ -911,11 +914,12 @@ __global__ __launch_bounds__(256) void swin_wattn_fwd_mfma4_kernel(const float* 
         const int i = w * 32 + crow(r, lane);
         if (i < WN) {
           const int tok = sTok[i];
-          if (tok >= 0) out[((long)b * L + tok) * g.C + head * HD + (lane & 31)] = o[r];
+          if (tok >= 0) { out[((long)b * L + tok) * g.C + head * HD + (lane & 31)] = o[r]; amx = fmaxf(amx, fabsf(o[r])); }
         }
       }
     }
   }
+  amax_commit(amax_out, amx);
 }
 
 __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restrict__ qkv,
@@ -924,11 +928,12 @@ __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restric
                                                                    const float* __restrict__ dout,
                                                                    const float* __restrict__ outp,
                                                                    float* __restrict__ dqkv, float* __restrict__ part,
-                                                                   const WinGeom& g, int B) {
+                                                                   const WinGeom& g, int B, unsigned* __restrict__ amax_out) {
   __shared__ float sQ[WN * LDT], sK[WN * LDT], sV[WN * LDT], sG[WN * LDT];
   __shared__ float sP[NPD * LDP];
   __shared__ float sT[TBL];
   __shared__ float sBw[4][3 * HD];
+  float amx = 0.f;  // max |dqkv| of what this lane stores -> the gradient's range word (common.h: amax_commit)
   __shared__ float sDelta[64];
   __shared__ int sLab[WN], sTok[WN];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 31;
@@ -998,7 +1003,7 @@ __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restric
         const int j = (w - 2) * 32 + crow(r, lane);
         if (j < WN) {
           const int tok = sTok[j];
-          if (tok >= 0) dq_base[(long)tok * 3 * g.C + 2 * g.C + fr] = dv[r];
+          if (tok >= 0) { dq_base[(long)tok * 3 * g.C + 2 * g.C + fr] = dv[r]; amx = fmaxf(amx, fabsf(dv[r])); }
           else accB[2] += dv[r];
         }
       }
@@ -1029,7 +1034,7 @@ __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restric
         const int i = w * 32 + crow(r, lane);
         if (i < WN) {
           const int tok = sTok[i];
-          if (tok >= 0) dq_base[(long)tok * 3 * g.C + fr] = dq[r] * scale;
+          if (tok >= 0) { dq_base[(long)tok * 3 * g.C + fr] = dq[r] * scale; amx = fmaxf(amx, fabsf(dq[r] * scale)); }
           else accB[0] += dq[r] * scale;
         }
       }
@@ -1042,7 +1047,7 @@ __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restric
         const int j = (w - 2) * 32 + crow(r, lane);
         if (j < WN) {
           const int tok = sTok[j];
-          if (tok >= 0) dq_base[(long)tok * 3 * g.C + g.C + fr] = dk[r];
+          if (tok >= 0) { dq_base[(long)tok * 3 * g.C + g.C + fr] = dk[r]; amx = fmaxf(amx, fabsf(dk[r])); }
           else accB[1] += dk[r];
         }
       }
@@ -1074,6 +1079,7 @@ __device__ __forceinline__ void swin_wattn_bwd_mfma4_body(const float* __restric
   float* prow = part + (long)blockIdx.x * WATTN_PROW;
   if (tid < TBL) prow[tid] = dT;
   if (tid < 3 * HD) prow[WATTN_PBIAS + tid] = ((sBw[0][tid] + sBw[1][tid]) + sBw[2][tid]) + sBw[3][tid];
+  amax_commit(amax_out, amx);
 }
 
 // Resident workgroups per CU = wavefronts per SIMD: LDS allows four (39 KB each); the registers decide — 2: 202 VGPRs, no
@@ -1082,8 +1088,8 @@ template <int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void swin_wattn_bwd_mfma4_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_b, const float* __restrict__ table,
     const float* __restrict__ dout, const float* __restrict__ outp, float* __restrict__ dqkv, float* __restrict__ part,
-    WinGeom g, int B) {
-  swin_wattn_bwd_mfma4_body(qkv, qkv_b, table, dout, outp, dqkv, part, g, B);
+    WinGeom g, int B, unsigned* __restrict__ amax_out) {
+  swin_wattn_bwd_mfma4_body(qkv, qkv_b, table, dout, outp, dqkv, part, g, B, amax_out);
 }
 
 static int wattn_geom(const char* fn, WinGeom* g, int B, int H, int W, int C, int heads, int ws, int shift) {
@@ -1112,7 +1118,7 @@ using namespace rscotr;
 
 extern "C" int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, const float* bias_table,
                                      float* out, int B, int H, int W, int C, int heads, int ws, int shift,
-                                     void* stream) {
+                                     uint32_t* amax_out, void* stream) {
   WinGeom g;
   if (int e = wattn_geom("rscotr_swin_wattn_fwd", &g, B, H, W, C, heads, ws, shift)) return e;
   if (B == 0) return RSCOTR_OK;
@@ -1132,8 +1138,10 @@ extern "C" int rscotr_swin_wattn_fwd(const float* qkv, const float* qkv_bias, co
   else if (impl == 1)
     swin_wattn_fwd_mfma_kernel<<<wattn_grid(g, B, 4), 64, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
   else
-    swin_wattn_fwd_mfma4_kernel<<<wattn_grid(g, B, 4), 256, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B);
-  return check_launch("rscotr_swin_wattn_fwd");
+    swin_wattn_fwd_mfma4_kernel<<<wattn_grid(g, B, 4), 256, 0, (hipStream_t)stream>>>(qkv, qkv_bias, bias_table, out, g, B, amax_out);
+  if (int e = check_launch("rscotr_swin_wattn_fwd")) return e;
+  // (only the four-wavefront kernel folds the output's range itself)
+  return (amax_out && impl != 2) ? rscotr_amax_f32(out, (int64_t)B * H * W, C, C, amax_out, stream) : RSCOTR_OK;
 }
 
 // workgroups per head of the backward launch (the partial rows of a head are rows head, head + heads, ...)
@@ -1220,7 +1228,7 @@ extern "C" int64_t rscotr_swin_wattn_bwd_workspace(int B, int H, int W, int C, i
 extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table,
                                      const float* dout, float* dqkv, float* dqkv_bias, float* dbias_table,
                                      int B, int H, int W, int C, int heads, int ws, int shift, const float* out,
-                                     float* workspace, int64_t workspace_bytes, void* stream) {
+                                     float* workspace, int64_t workspace_bytes, uint32_t* amax_out, void* stream) {
   WinGeom g;
   if (int e = wattn_geom("rscotr_swin_wattn_bwd", &g, B, H, W, C, heads, ws, shift)) return e;
   if (B == 0) return RSCOTR_OK;
@@ -1248,12 +1256,13 @@ extern "C" int rscotr_swin_wattn_bwd(const float* qkv, const float* qkv_bias, co
     const int occ = occ_env ? occ_env : ((nwg > 512 && nwg <= 768) ? 3 : 2);
     static const int use_out = getenv("RSCOTR_WATTN_DELTA_OUT") ? atoi(getenv("RSCOTR_WATTN_DELTA_OUT")) : 1;
     const float* o = (use_out && out && aligned16(out)) ? out : nullptr;
-    if (occ >= 4) swin_wattn_bwd_mfma4_kernel<4><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
-    else if (occ == 3) swin_wattn_bwd_mfma4_kernel<3><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
-    else swin_wattn_bwd_mfma4_kernel<2><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B);
+    if (occ >= 4) swin_wattn_bwd_mfma4_kernel<4><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B, amax_out);
+    else if (occ == 3) swin_wattn_bwd_mfma4_kernel<3><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B, amax_out);
+    else swin_wattn_bwd_mfma4_kernel<2><<<nwg, 256, 0, s>>>(qkv, qkv_bias, bias_table, dout, o, dqkv, workspace, g, B, amax_out);
   }
   if (dbias_table || dqkv_bias)
     wattn_param_fold_kernel<<<dim3((WATTN_PROW + 63) / 64, heads), 256, 0, s>>>(workspace, dbias_table, dqkv_bias, heads, C,
                                                                               nwg / heads);
-  return check_launch("rscotr_swin_wattn_bwd");
+  if (int e = check_launch("rscotr_swin_wattn_bwd")) return e;
+  return (amax_out && impl != 2) ? rscotr_amax_f32(dqkv, (int64_t)B * H * W, 3 * C, 3 * C, amax_out, stream) : RSCOTR_OK;
 }

@@ -5,6 +5,7 @@ from torch.autograd import Function
 
 from .core import _WS, _Prof, _chk, _f32c, _off_path, _ptr, _sink, _stream, lib
 from .matmul import DEFER, _linear_param_grad, colsum, gemm, gemm_batched, linear
+from .ranges import RANGES
 from .state import STATE
 
 class _SwinWindowAttn(Function):
@@ -21,11 +22,12 @@ class _SwinWindowAttn(Function):
         C = C3 // 3
         out = torch.empty((B, L, C), dtype=torch.float32, device=qkv.device)
         with _Prof('swin_wattn_fwd', 4 * B * L * 4 * C):
+            slot = RANGES.out_slot(qkv.device)  # (max |out|: the proj Linear multiplies with it)
             lib.call('rscotr_swin_wattn_fwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), out.data_ptr(),
-                     B, H, W, C, heads, ws, shift, _stream())
+                     B, H, W, C, heads, ws, shift, slot, _stream())
         ctx.save_for_backward(qkv, qkv_b, table, out)  # (out: the proj Linear keeps it alive anyway)
         ctx.geom = (B, H, W, C, heads, ws, shift)
-        return out
+        return RANGES.tag(out, slot)
 
     @staticmethod
     def backward(ctx, dout):
@@ -33,6 +35,7 @@ class _SwinWindowAttn(Function):
         B, H, W, C, heads, ws, shift = ctx.geom
         dout = _f32c(dout)
         dqkv = torch.empty_like(qkv)
+        slot = RANGES.out_slot(qkv.device)  # (max |dqkv|: the qkv Linear's backward multiplies with it)
         # the kernel ACCUMULATES the bias-table and pad-token (qkv-bias) gradients: with the gradient sink they go
         # straight into the arena (no zero-filled temporaries, no accumulate-adds afterwards)
         skt = _sink(ctx.table_param) if ctx.needs_input_grad[2] else None
@@ -47,17 +50,17 @@ class _SwinWindowAttn(Function):
             # arena-direct: the fold of the partial rows joins the end-of-pass flush (one launch for all 12 blocks)
             part = DEFER.reserve(nws, qkv.device)
             lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), dout.data_ptr(),
-                     dqkv.data_ptr(), 0, 0, B, H, W, C, heads, ws, shift, out.data_ptr(), part, nws, _stream())
+                     dqkv.data_ptr(), 0, 0, B, H, W, C, heads, ws, shift, out.data_ptr(), part, nws, slot, _stream())
             DEFER.wattn_entries.append((part, dt_ptr, db_ptr, heads, C, nws // (heads * 268 * 4)))
         else:
             with _Prof('swin_wattn_bwd', 4 * B * H * W * 8 * C):
                 lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), _ptr(qkv_b), table.data_ptr(), dout.data_ptr(),
                          dqkv.data_ptr(), db_ptr, dt_ptr, B, H, W, C, heads, ws, shift, out.data_ptr(),
-                         _WS.get(nws, qkv.device).data_ptr(), nws, _stream())
+                         _WS.get(nws, qkv.device).data_ptr(), nws, slot, _stream())
         for sk in (skt, skb):
             if sk is not None:
                 STATE.grad_sink.grad_written(sk[0])
-        return dqkv, dqkv_b, dtable, None, None, None, None, None
+        return RANGES.tag(dqkv, slot), dqkv_b, dtable, None, None, None, None, None
 
 
 def swin_window_attention(x, hw, qkv_w, qkv_b, bias_table, rel_index, proj_w, proj_b, heads, ws, shift,
@@ -319,10 +322,10 @@ def mha(x, kx, vx, in_w, in_b, out_w, out_b, heads, attn_mask=None, identity=Non
         k_pos = k_pos.expand_as(x if kx is None else kx)
     if q_sum is not None:
         assert q_pos is not None and q_sum.shape == x.shape
-        q_sum = q_sum.detach()
+        q_sum = RANGES.carry(q_sum, q_sum.detach())
     if k_sum is not None:
         assert kx is not None and k_pos is not None and k_sum.shape == kx.shape
-        k_sum = k_sum.detach()
+        k_sum = RANGES.carry(k_sum, k_sum.detach())
     return _MHA.apply(x, q_pos, kx, k_pos, vx, in_w, in_b, out_w, out_b, identity, heads, attn_mask, mask_mode or 0, q_sum,
                       k_sum)
 

@@ -79,12 +79,13 @@ def _msda_bwd_raw(value, spatial_shapes, level_start_index, loc, attn, grad_out)
     grad_attn = torch.empty_like(attn)
     # algorithmic bytes: read value, RMW grad_value, read loc/attn/grad_out, write grad_loc/attn
     nbytes = 4 * B * (3 * Nk * H * D + Nq * H * L * P * 3 + Nq * H * D + Nq * H * L * P * 3)
+    slot = RANGES.out_slot(value.device)  # (max |grad_value|: the value projection's backward multiplies with it)
     with _Prof('msda_bwd', nbytes):
         lib.call('rscotr_msda_bwd', value.data_ptr(), spatial_shapes.data_ptr(),
                  level_start_index.data_ptr(), loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
                  grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                 B, Nk, Nq, H, D, L, P, hs_ptr, 0 if ws is None else ws.data_ptr(), nws, _stream())
-    return grad_value, grad_loc, grad_attn
+                 B, Nk, Nq, H, D, L, P, hs_ptr, 0 if ws is None else ws.data_ptr(), nws, slot, _stream())
+    return RANGES.tag(grad_value, slot), grad_loc, grad_attn
 
 
 class _MSDA(Function):
@@ -135,9 +136,10 @@ def _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P, packed=Fals
         goff = torch.empty((B, Nq, H, L * P * 2), dtype=torch.float32, device=attn.device)
         glogit = torch.empty((B, Nq, H, L * P), dtype=torch.float32, device=attn.device)
         ldo, ldl = 2 * n, n
+    slot = RANGES.out_slot(attn.device)  # (one word bounds both gradients: they are the operands of the projections' backward)
     lib.call('rscotr_msda_prep_bwd', gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), ref.data_ptr(), _ptr(norm),
-             goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, ref.shape[-1], ldo, ldl, ref.shape[-2], _stream())
-    return (both, None) if packed else (goff, glogit)
+             goff.data_ptr(), glogit.data_ptr(), B, Nq, H, L, P, ref.shape[-1], ldo, ldl, ref.shape[-2], slot, _stream())
+    return (RANGES.tag(both, slot), None) if packed else (RANGES.tag(goff, slot), RANGES.tag(glogit, slot))
 
 
 class _MSDAPrep(Function):
@@ -207,9 +209,10 @@ class _MSDAAttn(Function):
         if packed:
             n3 = n_off + n_aw
             wb = torch.empty(n3 * C + n3, dtype=torch.float32, device=x2.device)
+            wslot = RANGES.out_slot(x2.device)  # (max |.| of the packed weights and biases: the range of the B operand below)
             lib.call('rscotr_pack4', ws[0].data_ptr(), n_off * C, ws[1].data_ptr(), n_aw * C, b_off.data_ptr(), n_off,
-                     b_aw.data_ptr(), n_aw, wb.data_ptr(), _stream())
-            w_cat = wb[:n3 * C].view(n3, C)
+                     b_aw.data_ptr(), n_aw, wb.data_ptr(), wslot, _stream())
+            w_cat = RANGES.tag(wb[:n3 * C].view(n3, C), wslot)
             both = gemm(q2, w_cat, M, n3, C, C, C, 0, 0, bias=wb[n3 * C:])
             loc, attn = _msda_prep_fwd_raw(both, both.view(-1)[n_off:], ref, norm, B, Nq, H, L, P, ld_off=n3, ld_logit=n3)
         else:
@@ -256,10 +259,12 @@ class _MSDAAttn(Function):
         packed = w_cat is not None
         n3 = n_off + n_aw
         goff, glogit = _msda_prep_bwd_raw(gloc, gattn, attn, ref, norm, B, Nq, H, L, P, packed=packed)
-        gv = gv.view(Mk, C)
+        gv = RANGES.carry(gv, gv.view(Mk, C))
         if packed:
             both = goff                             # (M, 3 n): [d(offsets) | d(logits)]
             goff, glogit, ldg = both.view(-1), both.view(-1)[n_off:], n3   # (flat aliases: column blocks with row stride 3 n)
+            RANGES.carry(both, goff)
+            RANGES.carry(both, glogit)
         else:
             goff, glogit, ldg = goff.view(M, n_off), glogit.view(M, n_aw), None
         if ctx.kpm is not None:
@@ -320,7 +325,7 @@ def msda_attention(x, q_pos, value, identity, key_padding_mask, reference_points
         q_pos = q_pos.expand_as(x)
     if q_sum is not None:
         assert q_pos is not None and q_sum.shape == x.shape
-        q_sum = q_sum.detach()
+        q_sum = RANGES.carry(q_sum, q_sum.detach())
     return _MSDAAttn.apply(x, q_pos, value, identity, key_padding_mask, reference_points, spatial_shapes,
                            level_start_index, offset_norm, heads, L, P, w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o, q_sum)
 

@@ -8,6 +8,7 @@ from torch.autograd import Function
 
 from .core import _WS, _chk, _f32c, _ptr, _sink, _stream, lib
 from .matmul import linear
+from .ranges import RANGES
 from .state import STATE
 
 def sine_embed4(pos):
@@ -95,7 +96,7 @@ class _FanOut(Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.set_materialize_grads(False)
-        return tuple(x.view_as(x) for _ in range(n))
+        return tuple(RANGES.carry(x, x.view_as(x)) for _ in range(n))  # (the handles hold x's values: and its value range)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -118,6 +118,7 @@ class _DeferredCombine:
         self.group, self.group_keep, self.group_cache = [], [], {}
         self.group_amax, self.amax_cache = {}, {}  # operands of grouped problems whose value range is measured at the flush
         self.pinned_pool, self.pinned_live = [], []
+        self.captured = []  # (cache, signature) of the tables built during the capture in progress
         self.wattn_entries, self.wattn_cache = [], {}
 
     MAX_TABLES = 64
@@ -213,7 +214,22 @@ class _DeferredCombine:
             return d
         return torch.from_numpy(arr).to(dev)
 
+    def forget_captured(self):
+        """A capture was abandoned (a failed capture, or the ranks' agreement to fall back to the split form): the tables that
+        were built while it was being recorded were to be filled by the graph's own copy nodes, which will never run —
+        their cache entries must not be found by the next capture, whose private pool hands out the same addresses."""
+        for cache, sig in self.captured:
+            cache.pop(sig, None)
+            self.pinned.discard(sig)
+        self.captured = []
+
+    def keep_captured(self):
+        """The capture is kept: its tables are refilled by every replay."""
+        self.captured = []
+
     def _remember(self, cache, sig, hit):
+        if sig not in cache and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.captured.append((cache, sig))
         if self.pin:
             self.pinned.add(sig)
         if sig not in cache:

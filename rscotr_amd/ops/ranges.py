@@ -26,12 +26,15 @@ class _Ranges:
     PLANES, STRIDE = 32, 1 << 14  # RSCOTR_RANGE_PLANES / RSCOTR_RANGE_STRIDE of include/rscotr.h: a word = 32 sub-words
 
     def __init__(self):
-        # Opt-in (RSCOTR_GEMM_H3=1): measured on the step (profiles/r5_h3_*.txt), the fp16 split product takes 1.2 ms per round
-        # off the GEMM kernels (15.6 against 16.8 ms, 7 %; 15-27 % per launch with cold operands in the lab, 20-45 % with warm
-        # ones) at a lower error than the six-term bf16 product — and the range bookkeeping (about 120 measuring launches, the
-        # grouped measuring launch, the atomics of the producers' epilogues) gives 1.4 ms back: the step's split kernels are
-        # bound by cold-operand latency and epilogue traffic, not by MFMA issue.  Off, every hook below is a no-op.
-        self.enabled = os.environ.get('RSCOTR_GEMM_H3', '0') != '0'
+        # ON by default since the end of round 5 (RSCOTR_GEMM_H3=0 = the six-term bf16 product of rounds 2-4).  Measured on the
+        # step (profiles/r5_h3_in_step.txt): the fp16 split product takes 1.2-1.4 ms per round off the GEMM kernels at a lower
+        # error (2.5e-7 against 6e-7 of max |C|); the range bookkeeping gave all of it back while ~540 operands per round were
+        # measured by launches of their own, and is down to ~60 measuring launches + one grouped launch per backward pass now
+        # that the producers (GEMM epilogues, LayerNorm family, deformable-attention backward, AdamW) write the words: the
+        # round is as fast as with the bf16 product (34.70 against 34.70-34.90 ms) — and the 800 x 800 det step, whose median
+        # distance from the fp64 evaluation was 5 x the fp32 oracle's with the bf16 product, has all 484 gradient tensors
+        # within 1e-3 of the fp32 oracle (tests/test_sizes_gpu.py).
+        self.enabled = os.environ.get('RSCOTR_GEMM_H3', '1') != '0'
         self.buf = None
         self.base = 0
         self.n = 0
@@ -142,7 +145,7 @@ class _Ranges:
         if self.log:
             import traceback
             fr = [f for f in traceback.extract_stack(limit=12) if 'ranges.py' not in f.filename and f.name not in ('gemm', '_dw_ranges', '_try_defer_dw')]
-            key = ' < '.join(f'{f.name}:{f.lineno}' for f in reversed(fr[-4:]))
+            key = f'({rows} x {cols}) ' + ' < '.join(f'{f.name}:{f.lineno}' for f in reversed(fr[-4:]))
             self.sites[key] = self.sites.get(key, 0) + 1
         if ptr is None or ptr == t.data_ptr():
             t._rs_amax = (self.gen, s)

@@ -55,7 +55,7 @@ def _sync_works_only(sync):
     return INLINE or (sync is not None and sync.comm is not None)
 
 
-def _wait_watchdog_idle(limit=2.0, sync_only=None):
+def _wait_watchdog_idle(limit=5.0, sync_only=None):
     """Block until the RCCL process group's watchdog has RETIRED every collective issued so far (call after a device
     synchronise, before a stream goes into capture).  The watchdog polls the end events of its pending works, and HIP refuses
     an event query ("operation not permitted on an event last recorded in a capturing stream") while the stream the event
@@ -67,6 +67,7 @@ def _wait_watchdog_idle(limit=2.0, sync_only=None):
     import pickle
     dump = getattr(torch._C._distributed_c10d, '_dump_nccl_trace', None)
     t0 = time.perf_counter()
+    timed_out = False
     try:
         if dump is not None:
             full = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False))
@@ -76,6 +77,7 @@ def _wait_watchdog_idle(limit=2.0, sync_only=None):
                     if not (act and act.get('entries')):
                         return 'recorder', time.perf_counter() - t0
                     time.sleep(0.01)
+                timed_out = True  # the recorder works, the watchdog just has not retired its entries in time
     except (RuntimeError, pickle.UnpicklingError, KeyError, TypeError, AttributeError) as e:  # a diagnostic API of c10d
         cause = e
     else:
@@ -84,10 +86,15 @@ def _wait_watchdog_idle(limit=2.0, sync_only=None):
     if not (INLINE if sync_only is None else sync_only):
         # the overlapped exchange THROUGH c10d leaves asynchronous works with the watchdog: guessing when it has dropped their events is
         # not good enough (a wrong guess aborts the process from the watchdog thread in the middle of a capture)
-        raise RuntimeError('capturing the overlapped gradient exchange (RSCOTR_DIST_INLINE=0) needs c10d\'s flight recorder to '
-                           'tell when the RCCL watchdog is idle, and it is not available (TORCH_NCCL_TRACE_BUFFER_SIZE=0?'
+        if timed_out:
+            raise RuntimeError(f'capturing the overlapped gradient exchange through c10d: the RCCL watchdog still holds active works '
+                               f'{limit:.0f} s after a device synchronise (flight recorder on) — not safe to start a capture; use '
+                               'the exchange\'s own communicator (RSCOTR_DIST_DIRECT=1, the default) or the inline exchange')
+        raise RuntimeError('capturing the overlapped gradient exchange through c10d (RSCOTR_DIST_INLINE=0, RSCOTR_DIST_DIRECT=0) needs '
+                           'c10d\'s flight recorder to tell when the RCCL watchdog is idle, and it is not available '
+                           '(TORCH_NCCL_TRACE_BUFFER_SIZE=0?'
                            + (f' {type(cause).__name__}: {cause}' if cause is not None else ' no entries recorded')
-                           + '); enable it or use the inline exchange')
+                           + '); enable it, or use the exchange\'s own communicator / the inline exchange')
     time.sleep(0.35)  # (inline exchange: synchronous works only — three watchdog periods are ample)
     return 'sleep', 0.35
 
@@ -104,6 +111,7 @@ class GraphedTask:
     reads the packed loss vector back (the step's one device->host copy)."""
 
     TENSOR_KEYS = ('img', 'gt_label', 'gt_semantic_seg')
+    capture_veto = False  # injection point of the capture-fallback test: never set by product code or the environment
 
     def __init__(self, runner, task, batch):
         self.runner, self.task = runner, task
@@ -182,15 +190,17 @@ class GraphedTask:
             err = e
             _recover_from_failed_capture(getattr(self, 'graph', None), e)
         if not self.exchange_in_graph:
+            ops.DEFER.keep_captured()
             return
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.static['img'].device)
         import torch.distributed as dist
         torch.cuda.synchronize()
         from .dist import control_all_reduce
         control_all_reduce(ok, dist.ReduceOp.MIN)
-        if os.environ.get('RSCOTR_TEST_CAPTURE_VETO') == '1':  # test hook: "another rank's capture failed" (tests/test_dist_gpu.py)
+        if GraphedTask.capture_veto:  # (tests only — tests/test_dist_gpu.py sets the attribute: "another rank's capture failed")
             ok.zero_()
         if int(ok.item()) == 1:
+            ops.DEFER.keep_captured()
             return
         import warnings
         warnings.warn(f'capturing the RCCL collectives of task {self.task!r} failed on at least one rank'
@@ -200,6 +210,7 @@ class GraphedTask:
         self.graph = None
         self.runner.sync.reset_step()
         ops.DEFER.drop()
+        ops.DEFER.forget_captured()  # (tables the dropped graph's copy nodes were to fill)
         self.exchange_in_graph, self.split = False, True
         self.opt.restore(snap0)
         self._warm_and_capture()
@@ -251,6 +262,7 @@ class GraphedTask:
                 self._body()
         except Exception:
             ops.DEFER.drop()
+            ops.DEFER.forget_captured()
             self.opt.restore(snap)
             raise
         finally:

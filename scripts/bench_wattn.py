@@ -22,7 +22,7 @@ for (H, heads) in [(128, 3), (64, 6), (32, 12), (16, 24)]:
     dqb = torch.zeros_like(qb); dtb = torch.zeros_like(tb)
     nws = lib.rscotr_swin_wattn_bwd_workspace(B, H, H, C, heads); wsb = torch.empty(max(nws, 4), dtype=torch.uint8, device=dev)
     for shift in (0, 3):
-        f = t(lambda: lib.call('rscotr_swin_wattn_fwd', qkv.data_ptr(), qb.data_ptr(), tb.data_ptr(), out.data_ptr(), B, H, H, C, heads, 7, shift, s))
-        b = t(lambda: lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), qb.data_ptr(), tb.data_ptr(), go.data_ptr(), dqkv.data_ptr(), dqb.data_ptr(), dtb.data_ptr(), B, H, H, C, heads, 7, shift, out.data_ptr(), wsb.data_ptr(), nws, s))
+        f = t(lambda: lib.call('rscotr_swin_wattn_fwd', qkv.data_ptr(), qb.data_ptr(), tb.data_ptr(), out.data_ptr(), B, H, H, C, heads, 7, shift, 0, s))
+        b = t(lambda: lib.call('rscotr_swin_wattn_bwd', qkv.data_ptr(), qb.data_ptr(), tb.data_ptr(), go.data_ptr(), dqkv.data_ptr(), dqb.data_ptr(), dtb.data_ptr(), B, H, H, C, heads, 7, shift, out.data_ptr(), wsb.data_ptr(), nws, 0, s))
         print(json.dumps(dict(H=H, heads=heads, shift=shift, fwd_us=round(f, 1), bwd_us=round(b, 1),
                               phases=os.environ.get('RSCOTR_WATTN_PHASES', '4'))), flush=True)

@@ -34,6 +34,17 @@ def gemm_precision():
     lib.call('rscotr_gemm_set_precision', old)
 
 
+@pytest.fixture
+def six_term():
+    """The six-term bf16 product of rounds 2-4 for the duration of a test (what RSCOTR_GEMM_H3=0 selects): value ranges off,
+    pre-split weight planes on.  Restored on exit."""
+    from rscotr_amd import ops
+    old = (ops.RANGES.enabled, ops.WPLANES.enabled)
+    ops.RANGES.enabled, ops.WPLANES.enabled = False, os.environ.get('RSCOTR_WPLANES', '1') != '0'
+    yield
+    ops.RANGES.enabled, ops.WPLANES.enabled = old
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # The parity suite must test what ships (VERDICT r2, weak item 1: a test that left the MSDA backward strategy changed made
 # every later whole-step test run a non-default kernel).  Before EVERY test — ahead of the test's own fixtures, which may

@@ -28,7 +28,8 @@ if os.environ.get('RSCOTR_DIST_SINGLE') == '1':
     dist.init_process_group('nccl', device_id=dev)
 from rscotr_amd import Config, MODELS
 from rscotr_amd.data import build_synthetic_multidataloader
-from rscotr_amd.runner import build_runner
+from rscotr_amd.runner import GraphedTask, build_runner
+GraphedTask.capture_veto = os.environ.get('TEST_CAPTURE_VETO') == '1'  # (the test's injection point: not an RSCOTR_* switch of the product)
 cfg = Config.fromfile(os.path.join(sys.argv[1], 'configs', 'multi', 'MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py'))
 torch.manual_seed(0); np.random.seed(2022)
 model = MODELS.build(cfg.model); model.init_weights(); model.to(dev).train()
@@ -89,7 +90,7 @@ def test_capture_fallback_keeps_the_step_counts(cuda):
     ranks forced to "failed"): every task ends in the split form, and step counts, weights and losses equal the run that
     took the split form from the start."""
     want = _run({'RSCOTR_DIST_SINGLE': '1', 'RSCOTR_DIST_CAPTURE': '0'}, 29551)
-    got = _run({'RSCOTR_DIST_SINGLE': '1', 'RSCOTR_TEST_CAPTURE_VETO': '1'}, 29552)
+    got = _run({'RSCOTR_DIST_SINGLE': '1', 'TEST_CAPTURE_VETO': '1'}, 29552)
     assert got['graphed'] == want['graphed'] == ['cls', 'det', 'seg']
     assert got['split'] == want['split'] == ['cls', 'det', 'seg']
     assert got['steps'] == want['steps'], (got['steps'], want['steps'])

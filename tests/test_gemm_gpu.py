@@ -93,7 +93,7 @@ def _split_planes(lib, W, rows, red, ldw, tr, cuda):
 @pytest.mark.parametrize('M,N,K', [(10880, 256, 2048), (10880, 2048, 256), (2048, 384, 1536), (8192, 288, 192), (1600, 256, 256),
                                    (1000, 200, 112), (300, 45, 64), (13294, 256, 272), (2500, 3072, 768), (32768, 96, 384)])
 @pytest.mark.parametrize('tr', [0, 1])
-def test_gemm_with_presplit_weight_planes(cuda, M, N, K, tr):
+def test_gemm_with_presplit_weight_planes(cuda, six_term, M, N, K, tr):
     _presplit_weight_planes(cuda, M, N, K, tr)
 
 
@@ -314,7 +314,7 @@ def test_layernorm_fork(cuda, M, C):
                                          (53176, 256, 256, 0, 0), (53176, 256, 256, 0, 1), (256, 2048, 53176, 1, 1),
                                          (32768, 96, 384, 0, 0), (2000, 1024, 512, 1, 0), (8192, 200, 512, 0, 1),
                                          (1604, 2048, 256, 0, 0)])
-def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
+def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, six_term, M, N, K, ak, bk):
     """Precision mode 3 (gemm_bf16x6_kernel: three bf16 planes per fp32 operand, six MFMAs per k-step, fp32 accumulate)
     against fp64 next to the fp32 matrix pipe on the step's own shapes, all four operand layouts, both tile sizes, with
     the fused epilogue: its error must be of the fp32 FMA chain's class — at most 1e-6 of max|C| (or 1.5x the fp32 pipe's own error) up
@@ -351,7 +351,7 @@ def test_gemm_bf16x6_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk):
         assert torch.equal(guard[:M], outs[3]) and bool((guard[M:] == 7.0).all())
 
 
-def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
+def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision, six_term):
     """The dW route of mode 3: k-slices through slabs (immediate combine and accumulate into C), the bias gradient riding
     along (row sums of the k-major A operand, taken from the fp32 registers) and per-sample k scaling (stochastic depth)."""
     from rscotr_amd import ops
@@ -372,7 +372,7 @@ def test_gemm_bf16x6_weight_gradient_routes(cuda, gemm_precision):
 
 
 @pytest.mark.parametrize('x6', [0, 1])
-def test_grouped_deferred_weight_gradients(cuda, x6, monkeypatch):
+def test_grouped_deferred_weight_gradients(cuda, x6, monkeypatch, six_term):
     """(x6 = 0: every member on the fp32 pipe's 64 x 64 tiles; 1, the default: members with min(M, N) >= 48 on the split product's
     128 x 128 edge body.)  rscotr_gemm_dw_group through ops.DEFER: a batch of dW = A^T B problems of the step's small-output shapes (ragged
     M / N / K, a destination shared by two problems, bias gradients riding along, per-sample k scaling) computed by ONE

@@ -66,9 +66,12 @@ def test_pack4(cuda):
     from rscotr_amd._lib import lib
     parts = [torch.randn(k, device=cuda) for k in (1000, 7, 0, 333)]
     out = torch.empty(1340, device=cuda)
+    slot = ops.RANGES.new_slot(cuda)
     lib.call('rscotr_pack4', parts[0].data_ptr(), 1000, parts[1].data_ptr(), 7, 0, 0, parts[3].data_ptr(), 333, out.data_ptr(),
-             ops._stream())
+             slot, ops._stream())
     assert torch.equal(out, torch.cat(parts))
+    # the range word of the packed tensor rides along (include/rscotr.h: rscotr_gemm_f32_r)
+    assert float(ops.RANGES.buf[:, ops.RANGES.index(slot)].view(torch.float32).max()) == float(out.abs().max())
 
 
 @pytest.mark.parametrize('uniform', [True, False])

@@ -65,7 +65,7 @@ def test_amax_group_measures_many_tensors_in_one_launch(cuda):
                                          (53176, 256, 256, 0, 1), (256, 2048, 53176, 1, 1), (32768, 96, 384, 0, 0),
                                          (2000, 1024, 512, 1, 0), (8192, 200, 512, 0, 1), (1604, 2048, 256, 0, 0)])
 @pytest.mark.parametrize('sa,sb,tail', [(1.0, 0.05, False), (3e-7, 40.0, False), (1.0, 0.05, True)])
-def test_gemm_h3_is_fp32_accurate(cuda, gemm_precision, M, N, K, ak, bk, sa, sb, tail):
+def test_gemm_h3_is_fp32_accurate(cuda, gemm_precision, six_term, M, N, K, ak, bk, sa, sb, tail):
     """Two fp16 planes per operand, power-of-two scales from the range words, three MFMAs per k-step: against fp64 next to
     the fp32 matrix pipe on the shapes precision mode 3 routes to the split kernels (all four layouts, both tile sizes, edge
     instantiations, k-slices, fused epilogue).  Same bound as the six-term bf16 product (tests/test_gemm_gpu.py): at most
@@ -138,6 +138,35 @@ def test_h3_weight_gradient_routes(cuda):
         rs = torch.zeros(N, device=cuda)
         out = ops.gemm(dy, x, N, K, Mt, N, K, 1, 1, rowsum=rs, kscale=ks, krows_per=per)
     assert _rel(out, ref) < 2e-6 and _rel(rs, scaled.sum(0)) < 2e-6
+
+
+def test_grouped_weight_gradients_on_the_fp16_body(cuda):
+    """rscotr_gemm_dw_group variant 7 through ops.DEFER: small-output weight gradients of one backward pass in ONE launch on the
+    fp16 split product, the operands' range words measured by ONE grouped launch (rscotr_amax_group) right before it."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 256, 10880), (256, 256, 1600), (96, 48, 4096), (384, 384, 2048), (192, 576, 8192), (128, 256, 10880)]
+    outs = [torch.nn.Parameter(torch.zeros(M, N, device=cuda)) for M, N, K in shapes]   # destinations in a gradient arena
+    opt = FlatAdamW([dict(name=f'w{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(outs)])
+    try:
+        with ranges_on(ops) as R:
+            R.stats = {k: 0 for k in R.stats}
+            want, keep = [], []
+            for (M, N, K), p in zip(shapes, outs):
+                A = (torch.randn(K, M, generator=g) * 1e-3).to(cuda)
+                B = torch.randn(K, N, generator=g).to(cuda)
+                keep.append((A, B))
+                want.append(A.double().cpu().t() @ B.double().cpu())
+                ops.gemm(A, B, M, N, K, M, N, 1, 1, out=p.grad, accumulate=True)
+            assert ops.DEFER.group and all(e[11] and e[12] for e in ops.DEFER.group if min(e[5], e[6]) >= 48)
+            ops.flush_deferred()
+            assert R.stats.get('grouped', 0) == 2 * len(shapes)
+        torch.cuda.synchronize()
+        for p, w in zip(outs, want):
+            assert _rel(p.grad, w) < 2e-6, tuple(p.shape)
+    finally:
+        opt.close()
 
 
 def test_optimizer_keeps_parameter_ranges(cuda):

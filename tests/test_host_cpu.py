@@ -392,3 +392,44 @@ def test_state_dict_key_families_the_reference_defines_itself(main_model):
                     break  # (mmcls LinearClsHead.fc)
                 assert member in named, f'{k}: {member} is not an attribute the reference classes assign'
                 break
+
+
+def test_reference_import_paths_and_train_model_signature(tmp_path):
+    """VERDICT r4 missing 7: the reference's import paths (`mtl.apis`, `mtl.data`, `mtl.runner.hooks`, `mtl.utils.optimizer`,
+    `models.multi`) resolve to this package, `train_model` has the signature of mtl/apis/train.py:24-30, and a config's
+    `custom_imports` is honoured — an unknown module raises (unless the config allows failures), it is never ignored."""
+    import inspect
+    import rscotr_amd
+    from rscotr_amd import Config
+    from rscotr_amd.compat import apply_custom_imports, install_aliases
+    assert len(install_aliases()) >= 18
+    from mtl.apis import train_model
+    from mtl.data import MultiDataLoader, RoundRobinIterationStrategy
+    from mtl.engine import multi_gpu_test, single_gpu_test
+    from mtl.runner.hooks import MultiDatasetsEvalHook
+    from mtl.utils.optimizer import build_optimizer
+    import models.multi
+    assert MultiDataLoader is rscotr_amd.data.MultiDataLoader and models.multi.MTL is rscotr_amd.mtl.MTL
+    assert callable(single_gpu_test) and callable(multi_gpu_test) and callable(build_optimizer)
+    assert RoundRobinIterationStrategy is rscotr_amd.data.RoundRobinIterationStrategy
+    assert MultiDatasetsEvalHook is rscotr_amd.engine.MultiDatasetsEvalHook
+    want = ['model', 'datasets', 'cfg', 'distributed', 'validate', 'timestamp', 'meta']
+    ref = '/root/reference/mtl/apis/train.py'
+    if os.path.exists(ref):  # (build container only: the GPU box has no reference tree)
+        import ast
+        fn = [n for n in ast.parse(open(ref).read()).body if isinstance(n, ast.FunctionDef) and n.name == 'train_model'][0]
+        want = [a.arg for a in fn.args.args]
+        assert [ast.literal_eval(d) for d in fn.args.defaults] == [False, False, None, None]
+    sig = inspect.signature(train_model)
+    assert list(sig.parameters) == want
+    assert [p.default for p in sig.parameters.values()][3:] == [False, False, None, None]
+    # custom_imports: the reference's own value works; an unknown module is an error, or a warning when the config says so
+    p = tmp_path / 'c.py'
+    p.write_text("custom_imports = dict(imports='models.multi', allow_failed_imports=False)\nx = 1\n")
+    assert Config.fromfile(str(p)).x == 1
+    p.write_text("custom_imports = dict(imports=['models.multi', 'no_such_module_xyz'], allow_failed_imports=False)\n")
+    with pytest.raises(ImportError):
+        Config.fromfile(str(p))
+    p.write_text("custom_imports = dict(imports=['no_such_module_xyz'], allow_failed_imports=True)\n")
+    with pytest.warns(UserWarning):
+        assert apply_custom_imports(Config.fromfile(str(p), import_custom_modules=False)) == []

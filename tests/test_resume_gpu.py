@@ -65,9 +65,10 @@ def test_resumed_run_continues_bit_for_bit(cuda, tmp_path):
     run_b.optimizer.close()
 
 
-def test_weight_planes_are_fresh_after_graph_replays(cuda):
-    """Graphs on, precision mode 3, planes on — the default configuration at BASELINE configs[1] size, where the encoder
-    FFN products (10880 x 256 x 2048) take the pre-split-plane route in training AND in a no-grad evaluation."""
+def test_weight_planes_are_fresh_after_graph_replays(cuda, six_term):
+    """Graphs on, precision mode 3, planes on — round 4's default and today's RSCOTR_GEMM_H3=0 configuration — at BASELINE
+    configs[1] size, where the encoder FFN products (10880 x 256 x 2048) take the pre-split-plane route in training AND in a
+    no-grad evaluation."""
     from rscotr_amd import ops, synth
     from rscotr_amd._lib import lib
     assert ops.WPLANES.enabled and lib.rscotr_gemm_get_precision() == 3
