@@ -348,6 +348,10 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
     return;
   }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
+  // exactly one extra tensor read by the epilogue: its 16 values per 32 x 32 tile in one batch (epilogue_tile16; one-tile-per-
+  // wavefront configurations only: the 128-row tiles keep their registers)
+  const bool one_extra = MT == 1 && NT == 1 && !p.C2 &&
+                         ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
   float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -358,7 +362,9 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
       const float bv = p.bias ? p.bias[n] : 0.f;
       const int mb = m0 + wm * TM + i * 32 + 4 * fk;
       float* crow = p.C + (long)mb * p.ldc + n;
-      if (plain) {
+      if (one_extra) {
+        epilogue_tile16<EDGE>(p, acc[i][j], bv, mb, n, amx);
+      } else if (plain) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dm = (r & 3) + 8 * (r >> 2);
@@ -872,7 +878,9 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
   // exactly one extra tensor read by the epilogue (aux of act', residual, or old C): its 16 values per tile in one batch
-  // (64 x 64 tiles only: on the 128 x 128 one-stage kernel the 16-register batch costs the third resident workgroup)
+  // (64 x 64 tiles only: on the 128 x 128 one-stage bf16 kernel the 16-register batch costs the third resident workgroup, and on
+  // the fp16 one — measured cold, 10880 x 2048 x 256 + residual: 109.7 against 105.8 us — it buys nothing: those launches are
+  // bound by the 190 MB their epilogue moves in 512-byte row segments 8 KB apart)
   const bool one_extra = BM == 64 && !p.C2 &&
                          ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
   float amx = 0.f;
