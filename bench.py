@@ -27,10 +27,11 @@ CFG = os.path.join(ROOT, 'configs', 'multi', 'MTL_slvlcls_swin-t-p4-w7_1x1_resis
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (= fp32 vector) peak, dense
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA peak, dense (no sparsity)
-# the fp16 split product (opt-in, RSCOTR_GEMM_H3=1: gemm_h3_*_kernel) issues three fp16 MFMAs per fp32-equivalent product
+# the fp16 split product (the default large-product route, RSCOTR_GEMM_H3=0 turns it off: gemm_h3_*_kernel) issues three fp16 MFMAs per fp32-equivalent product
 # (price a split product by its MFMA issues; fp16 and bf16 MFMAs share the 2.5 PFLOP/s dense peak)
 H3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
-# gemm_bf16x6_kernel (precision mode 3, fp32-accurate): six bf16 MFMAs per fp32-equivalent product
+# gemm_bf16x6_kernel (the route with RSCOTR_GEMM_H3=0 and for operands without a range word; fp32-accurate): six bf16 MFMAs per
+# fp32-equivalent product
 BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 PROF_EVERY_GEMM = 1  # every GEMM launch of the roofline rounds carries a pair of HIP events (1 in 4 made the choice of the dominant instantiation depend on which launches were drawn)
 
@@ -421,11 +422,11 @@ def main():
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
                        kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_small_kernel<*>, '
-                              'gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> (the grouped weight-gradient launch), gemm_h3_*_kernel (opt-in)',
+                              'gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> / gemm_h3_group_kernel (the grouped weight-gradient launch), gemm_h3_kernel<*> / gemm_h3_128_kernel<*>',
                        launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
-                            '2500/3 (fp16 split product, opt-in)')
+                            '2500/3 (fp16 split product)')
         # the fused attention core (csrc/attn_core.hip) reports through the GEMM kind: its own two lines, fp32 matrix pipe
         def attn(name):
             d = ga.get(name)
@@ -486,8 +487,12 @@ def main():
             pass
         out = dict(metric=wl['metric'], value=images / dt, unit='images/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype={0: 'f32', 3: 'f32 (large products as six bf16 MFMAs on three-plane splits of the fp32 operands, fp32 accumulate: '
-                                     'fp32-FMA-class error)'}[lib.rscotr_gemm_get_precision()],
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=('f32' if lib.rscotr_gemm_get_precision() == 0 else
+                          'f32 (large products as three fp16 MFMAs on two-plane power-of-two-scaled splits of the fp32 operands, fp32 '
+                          'accumulate: fp32-FMA-class error; six bf16 MFMAs on three-plane splits where an operand has no range word)'
+                          if ops.RANGES.enabled else
+                          'f32 (large products as six bf16 MFMAs on three-plane splits of the fp32 operands, fp32 accumulate: '
+                          'fp32-FMA-class error)'),
                    data='synthetic',
                    config=dict(workload=f'{a.workload}: {wl["name"]}, {a.size}x{a.size} bs={a.batch}/task/GPU',
                                step=('one round-robin round = ' + '+'.join(wl['tasks']) + ' train iterations') if ntask > 1

@@ -523,14 +523,18 @@ int rscotr_adamw_clip_step(float* param, const float* grad, float* exp_avg, floa
                            float beta1, float beta2, float eps, void* stream);
 /* The same step keeping the VALUE RANGES of the parameters (round 5; consumed by rscotr_gemm_f32_r as amax_b of a weight
  * operand): seg_amax[segment] = bit pattern of max |w| over the segment, refreshed for every live segment by the update
- * itself (zeroed, then one atomicMax per chunk: order-independent, deterministic); other segments keep their word.
+ * itself (each chunk's wavefronts store their maxima into the scratch chunk_amax — 4 * nchunks uint32, 16-byte aligned — and
+ * a second small launch folds them per segment, found by bisection of the ascending chunk_seg: no atomics, deterministic);
+ * other segments keep their word.  chunk_amax is required when seg_amax is given.
  * rscotr_param_amax computes all nseg words from the arena (construction, checkpoint load, restore). */
 int rscotr_adamw_clip_step_r(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                              const int32_t* chunk_seg, const int64_t* chunk_off, const int32_t* chunk_len,
                              const float* seg_dyn, int nchunks, const float* sumsq, float max_norm,
-                             float beta1, float beta2, float eps, uint32_t* seg_amax, int nseg, void* stream);
+                             float beta1, float beta2, float eps, uint32_t* seg_amax, int nseg, uint32_t* chunk_amax,
+                             void* stream);
 int rscotr_param_amax(const float* param, const int32_t* chunk_seg, const int64_t* chunk_off,
-                      const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, void* stream);
+                      const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, uint32_t* chunk_amax,
+                      void* stream);
 
 /* ---- gradient exchange on RCCL, called directly ------------------------------------------------------------------------
  * Replaces the bucket all-reduces of torch DDP / c10d ProcessGroupNCCL behind the reference's MMDistributedDataParallel

@@ -57,29 +57,46 @@ __global__ __launch_bounds__(256) void grad_sumsq_final_kernel(float* __restrict
 }
 
 // Value ranges of the parameters (round 5: the fp16 split product of csrc/gemm.hip scales a weight operand by a power of two
-// taken from max |w| of its tensor): seg_amax[segment] = bit pattern of max |w|.  The update kernel below refreshes the word
-// of every segment it touches — amax_reset_kernel zeroes the live segments' words, each chunk's workgroup then folds its
-// maximum in with one atomicMax on the bit pattern (a maximum does not depend on the order: deterministic; the plain read
-// in front only skips atomics that cannot raise the word).  Segments that are not stepped keep their word.
-__global__ __launch_bounds__(256) void amax_reset_kernel(const float* __restrict__ seg_dyn, unsigned* __restrict__ seg_amax, int nseg) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nseg && (!seg_dyn || seg_dyn[i * SEG_STRIDE + 4] != 0.f)) seg_amax[i] = 0u;
+// taken from max |w| of its tensor): seg_amax[segment] = bit pattern of max |w|.  The update kernel below leaves the maximum
+// of every wavefront's share of a chunk in chunk_amax[4 * chunk + wavefront] (plain stores), seg_amax_reduce_kernel — one
+// wavefront per segment, the segment's chunks found by bisection of the sorted chunk_seg — folds them into the words of the
+// segments that were stepped; the others keep theirs.  No atomics: the first cut folded each workgroup's maximum into the
+// word with atomicMax (one per workgroup behind a look at the word: 285 -> 345 us per update of the 62 M elements of
+// configs[1]; one per wavefront against a look taken at the start: 575-1000 us — a few thousand atomics on a handful of
+// lines serialise at ~50-100 ns each and the kernel cannot retire before them).
+__global__ __launch_bounds__(256) void seg_amax_reduce_kernel(const int32_t* __restrict__ chunk_seg, const unsigned* __restrict__ chunk_amax,
+                                                              const float* __restrict__ seg_dyn, unsigned* __restrict__ seg_amax,
+                                                              int nseg, int nchunks) {
+  const int sgm = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (sgm >= nseg || (seg_dyn && seg_dyn[sgm * SEG_STRIDE + 4] == 0.f)) return;  // (wavefront-uniform)
+  // first chunk of this segment and of the next: two bisections of the ascending chunk_seg, stepped together (one memory
+  // latency per step for both)
+  int lo0 = 0, hi0 = nchunks, lo1 = 0, hi1 = nchunks;
+  while (lo0 < hi0 || lo1 < hi1) {
+    const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+    const int v0 = lo0 < hi0 ? chunk_seg[m0] : 0, v1 = lo1 < hi1 ? chunk_seg[m1] : 0;
+    if (lo0 < hi0) { if (v0 < sgm) lo0 = m0 + 1; else hi0 = m0; }
+    if (lo1 < hi1) { if (v1 < sgm + 1) lo1 = m1 + 1; else hi1 = m1; }
+  }
+  const int c0 = lo0, c1 = lo1;
+  unsigned m = 0u;  // (bit patterns of non-negative floats order like the floats)
+  for (int c = c0 + lane; c < c1; c += 64) {
+    const uint4 v = reinterpret_cast<const uint4*>(chunk_amax)[c];
+    m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if (lane == 0) seg_amax[sgm] = m;
 }
 
-__device__ __forceinline__ void chunk_amax_commit(unsigned* __restrict__ word, float amx) {
-  __shared__ float part_amax[4];
+__device__ __forceinline__ void chunk_amax_store(unsigned* __restrict__ chunk_amax, int c, float amx) {
   amx = wave_max(amx);
-  if ((threadIdx.x & 63) == 0) part_amax[threadIdx.x >> 6] = amx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned m = __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3])));
-    if (m > *reinterpret_cast<volatile unsigned*>(word)) atomicMax(word, m);
-  }
+  if ((threadIdx.x & 63) == 0) chunk_amax[4 * c + (threadIdx.x >> 6)] = __float_as_uint(amx);
 }
 
 __global__ __launch_bounds__(256) void param_amax_kernel(const float* __restrict__ param, const int32_t* __restrict__ chunk_seg,
                                                          const int64_t* __restrict__ chunk_off,
-                                                         const int32_t* __restrict__ chunk_len, unsigned* __restrict__ seg_amax) {
+                                                         const int32_t* __restrict__ chunk_len, unsigned* __restrict__ chunk_amax) {
   const int c = blockIdx.x;
   const float4* p4 = reinterpret_cast<const float4*>(param + chunk_off[c]);
   const int n4 = chunk_len[c] >> 2;
@@ -88,7 +105,7 @@ __global__ __launch_bounds__(256) void param_amax_kernel(const float* __restrict
     const float4 p = p4[i];
     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(p.x), fabsf(p.y))), fmaxf(fabsf(p.z), fabsf(p.w)));
   }
-  chunk_amax_commit(seg_amax + chunk_seg[c], amx);
+  chunk_amax_store(chunk_amax, c, amx);
 }
 
 __global__ __launch_bounds__(256) void adamw_clip_kernel(
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(
     float* __restrict__ exp_avg_sq, const int32_t* __restrict__ chunk_seg,
     const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ chunk_len,
     const float* __restrict__ seg_dyn, const float* __restrict__ sumsq, float max_norm, float beta1,
-    float beta2, float eps, unsigned* __restrict__ seg_amax) {
+    float beta2, float eps, unsigned* __restrict__ chunk_amax) {
   const int c = blockIdx.x;
   const float* d = seg_dyn + chunk_seg[c] * SEG_STRIDE;
   if (d[4] == 0.f) return;
@@ -116,8 +133,6 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(
   const float step_size = lr * inv_bc1;
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   float amx = 0.f;
-  for (int i = threadIdx.x; i < n4; i += 256) {
-    float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
 #define RSCOTR_ADAMW_1(X)                                   \
   {                                                         \
     const float gg = g.X * coef;                            \
@@ -127,14 +142,27 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(
     const float denom = sqrtf(v.X) * inv_sqrt_bc2 + eps;    \
     p.X -= step_size * (m.X / denom);                       \
   }
+  auto step4 = [&](int i, float4 p, const float4& g, float4 m, float4 v) {
     RSCOTR_ADAMW_1(x) RSCOTR_ADAMW_1(y) RSCOTR_ADAMW_1(z) RSCOTR_ADAMW_1(w)
-#undef RSCOTR_ADAMW_1
     p4[i] = p;
     m4[i] = m;
     v4[i] = v;
     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(p.x), fabsf(p.y))), fmaxf(fabsf(p.z), fabsf(p.w)));
+  };
+  // two elements of the thread's stride requested before either is stepped (the running maximum kept the compiler from
+  // unrolling the plain loop: one iteration's four loads in flight)
+  int i = threadIdx.x;
+  for (; i + 256 < n4; i += 512) {
+    const int j = i + 256;
+    const float4 p0 = p4[i], g0 = g4[i], m0 = m4[i], v0 = v4[i];
+    const float4 p1 = p4[j], g1 = g4[j], m1 = m4[j], v1 = v4[j];
+    asm volatile("" ::: "memory");  // (all eight requests before the first store: the scheduler sank three of them behind it)
+    step4(i, p0, g0, m0, v0);
+    step4(j, p1, g1, m1, v1);
   }
-  if (seg_amax) chunk_amax_commit(seg_amax + chunk_seg[c], amx);
+  if (i < n4) step4(i, p4[i], g4[i], m4[i], v4[i]);
+#undef RSCOTR_ADAMW_1
+  if (chunk_amax) chunk_amax_store(chunk_amax, c, amx);
 }
 
 }  // namespace rscotr
@@ -160,7 +188,7 @@ extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* 
                                         const int32_t* chunk_seg, const int64_t* chunk_off,
                                         const int32_t* chunk_len, const float* seg_dyn, int nchunks,
                                         const float* sumsq, float max_norm, float beta1, float beta2,
-                                        float eps, uint32_t* seg_amax, int nseg, void* stream);
+                                        float eps, uint32_t* seg_amax, int nseg, uint32_t* chunk_amax, void* stream);
 
 extern "C" int rscotr_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                                       const int32_t* chunk_seg, const int64_t* chunk_off,
@@ -168,16 +196,18 @@ extern "C" int rscotr_adamw_clip_step(float* param, const float* grad, float* ex
                                       const float* sumsq, float max_norm, float beta1, float beta2,
                                       float eps, void* stream) {
   return rscotr_adamw_clip_step_r(param, grad, exp_avg, exp_avg_sq, chunk_seg, chunk_off, chunk_len, seg_dyn, nchunks, sumsq,
-                                  max_norm, beta1, beta2, eps, nullptr, 0, stream);
+                                  max_norm, beta1, beta2, eps, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int rscotr_param_amax(const float* param, const int32_t* chunk_seg, const int64_t* chunk_off,
-                                 const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, void* stream) {
+                                 const int32_t* chunk_len, int nchunks, uint32_t* seg_amax, int nseg, uint32_t* chunk_amax,
+                                 void* stream) {
   if (nchunks < 0 || nseg < 0) return fail(RSCOTR_E_SHAPE, "rscotr_param_amax: negative count");
   if (nchunks == 0 || nseg == 0) return RSCOTR_OK;
-  if (!param || !chunk_seg || !chunk_off || !chunk_len || !seg_amax) return fail(RSCOTR_E_ARG, "rscotr_param_amax: null pointer");
-  amax_reset_kernel<<<dim3((nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(nullptr, seg_amax, nseg);
-  param_amax_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(param, chunk_seg, chunk_off, chunk_len, seg_amax);
+  if (!param || !chunk_seg || !chunk_off || !chunk_len || !seg_amax || !chunk_amax) return fail(RSCOTR_E_ARG, "rscotr_param_amax: null pointer");
+  if (!aligned16(chunk_amax)) return fail(RSCOTR_E_ALIGN, "rscotr_param_amax: chunk_amax must be 16-byte aligned");
+  param_amax_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(param, chunk_seg, chunk_off, chunk_len, chunk_amax);
+  seg_amax_reduce_kernel<<<dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(chunk_seg, chunk_amax, nullptr, seg_amax, nseg, nchunks);
   return check_launch("rscotr_param_amax");
 }
 
@@ -185,7 +215,7 @@ extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* 
                                         const int32_t* chunk_seg, const int64_t* chunk_off,
                                         const int32_t* chunk_len, const float* seg_dyn, int nchunks,
                                         const float* sumsq, float max_norm, float beta1, float beta2,
-                                        float eps, uint32_t* seg_amax, int nseg, void* stream) {
+                                        float eps, uint32_t* seg_amax, int nseg, uint32_t* chunk_amax, void* stream) {
   if (nchunks < 0) return fail(RSCOTR_E_SHAPE, "rscotr_adamw_clip_step: negative chunk count");
   if (nchunks == 0) return RSCOTR_OK;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !chunk_seg || !chunk_off || !chunk_len || !seg_dyn)
@@ -193,12 +223,15 @@ extern "C" int rscotr_adamw_clip_step_r(float* param, const float* grad, float* 
   if (max_norm > 0.f && !sumsq) return fail(RSCOTR_E_ARG, "rscotr_adamw_clip_step: sumsq required when clipping");
   if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
     return fail(RSCOTR_E_ALIGN, "rscotr_adamw_clip_step: arenas must be 16-byte aligned");
-  if (seg_amax && nseg > 0)
-    amax_reset_kernel<<<dim3((nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(seg_dyn, seg_amax, nseg);
+  const bool ranges = seg_amax && nseg > 0;
+  if (ranges && !chunk_amax) return fail(RSCOTR_E_ARG, "rscotr_adamw_clip_step_r: chunk_amax (4 * nchunks words) required with seg_amax");
+  if (ranges && !aligned16(chunk_amax)) return fail(RSCOTR_E_ALIGN, "rscotr_adamw_clip_step_r: chunk_amax must be 16-byte aligned");
   // (work 0: which segments are live is device data — the caller prices the launch: 28 bytes per stepped element)
   ProfScope prof(PROF_HBM, 0.0, (hipStream_t)stream, "rscotr::adamw_clip_kernel");
   adamw_clip_kernel<<<dim3(nchunks), dim3(256), 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, chunk_seg, chunk_off, chunk_len, seg_dyn, sumsq, max_norm, beta1,
-      beta2, eps, seg_amax);
+      beta2, eps, ranges ? chunk_amax : nullptr);
+  if (ranges)
+    seg_amax_reduce_kernel<<<dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(chunk_seg, chunk_amax, seg_dyn, seg_amax, nseg, nchunks);
   return check_launch("rscotr_adamw_clip_step");
 }

@@ -112,12 +112,10 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) float uce_smem[];
   float* sN = uce_smem;                                  // [UCE_NB * UCE_NB][128]   neighbourhood logits of the 128 classes of a pass
   float* sAcc = sN + UCE_NB * UCE_NB * 128;              // [4 groups][UCE_TB * UCE_TB][128]
-  float* sLse = sAcc + 4 * UCE_TB * UCE_TB * 128;        // [UCE_FP * UCE_FP]
-  int* sLab = reinterpret_cast<int*>(sLse + UCE_FP * UCE_FP);
-  float* sYl = reinterpret_cast<float*>(sLab + UCE_FP * UCE_FP);   // [UCE_FP][2]  l0, l1 of a footprint row
-  float* sXl = sYl + 2 * UCE_FP;
-  int* sYi = reinterpret_cast<int*>(sXl + 2 * UCE_FP);   // [UCE_FP][2]  i0, i1 relative to the block's first cell - 1
-  int* sXi = sYi + 2 * UCE_FP;
+  int2* sLL = reinterpret_cast<int2*>(sAcc + 4 * UCE_TB * UCE_TB * 128);  // [UCE_FP * UCE_FP] {label, bits of lse * log2 e} of a footprint pixel
+  float* sYl = reinterpret_cast<float*>(sLL + UCE_FP * UCE_FP);    // [UCE_FP][2]  l0, l1 of a footprint row
+  int* sYi = reinterpret_cast<int*>(sYl + 2 * UCE_FP);   // [UCE_FP][2]  i0, i1 relative to the block's first cell - 1
+  int4* sXT = reinterpret_cast<int4*>(sYi + 2 * UCE_FP);  // [UCE_FP] {i0, i1 (same origin), bits of l0, l1} of a footprint column
   const int bw = (w + UCE_TB - 1) / UCE_TB, bh = (h + UCE_TB - 1) / UCE_TB;
   const int blk = blockIdx.x;
   const int cx0 = (blk % bw) * UCE_TB, cy0 = ((blk / bw) % bh) * UCE_TB, b = blk / (bw * bh);
@@ -135,8 +133,7 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
   if (staged) {
     for (int i = tid; i < ny * nx; i += 512) {
       const long p = ((long)b * H + y_lo + i / nx) * W + x_lo + i % nx;
-      sLab[i] = (int)label[p];
-      sLse[i] = lse[p];
+      sLL[i] = make_int2((int)label[p], __float_as_int(lse[p] * 1.4426950408889634f));  // (the staged path works in the log2 domain: one v_exp_f32 per pixel and class)
     }
   }
   for (int i = tid; i < min(ny, UCE_FP); i += 512) {
@@ -146,8 +143,7 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
   }
   for (int i = tid; i < min(nx, UCE_FP); i += 512) {
     const Interp ix = src_index(x_lo + i, sx, w);
-    sXl[2 * i] = ix.l0; sXl[2 * i + 1] = ix.l1;
-    sXi[2 * i] = ix.i0 - cx0 + 1; sXi[2 * i + 1] = ix.i1 - cx0 + 1;
+    sXT[i] = make_int4(ix.i0 - cx0 + 1, ix.i1 - cx0 + 1, __float_as_int(ix.l0), __float_as_int(ix.l1));
   }
   for (int c0 = 0; c0 < C; c0 += 128) {
     const int c = c0 + lane;
@@ -160,7 +156,76 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < UCE_TB * UCE_TB; ++k) sAcc[(grp * UCE_TB * UCE_TB + k) * 128 + lane] = 0.f;
     __syncthreads();
-    if (c < C) {
+    if (c < C && staged) {
+      // Staged footprints (the step's shapes).  Everything that depends on the pixel alone — tap indices and weights, label,
+      // log-sum-exp — is the same for the 64 lanes of a wavefront (a row group is two whole wavefronts): read to scalar
+      // registers.  The footprint columns are walked one COLUMN PAIR (first tap on block column k - 1, k = 0 .. TB) at a time,
+      // the pair loop unrolled: the vector work per pixel and class is the interpolation (2 FMAs on the row-combined cell
+      // logits A0 / A1 of the pair), one exp2, the one-hot and two FMAs into the pair's sums s0 / s1, which land in the row's
+      // column sums cs[] by static register index; the row weights multiply cs once per row and only then touch the thread's
+      // LDS cells (8 read-add-writes per footprint row; the first cut folded 4 per column pair: 151 -> 118 us at
+      // 2 x 100 x 64 x 64 -> 512^2, this form: see profiles/README.md)
+      float* acc = sAcc + grp * UCE_TB * UCE_TB * 128 + lane;
+      auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+      auto scf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      int xs[UCE_TB + 2];  // xs[k] = first footprint column whose first tap is block column >= k - 1 (columns ascend with xx)
+#pragma unroll
+      for (int k = 0; k < UCE_TB + 2; ++k) xs[k] = 0;
+      for (int xx = 0; xx < nx; ++xx) {
+        const int kx0 = sc(sXT[xx].x);
+#pragma unroll
+        for (int k = 0; k < UCE_TB + 2; ++k) xs[k] += kx0 < k ? 1 : 0;
+      }
+      for (int r = grp; r < ny; r += 4) {
+        const int ky0 = sc(sYi[2 * r]), ky1 = sc(sYi[2 * r + 1]);
+        const float yl0 = scf(sYl[2 * r]), yl1 = scf(sYl[2 * r + 1]);
+        const bool in0 = ky0 >= 1 && ky0 <= UCE_TB && cy0 + ky0 - 1 < h, in1 = ky1 >= 1 && ky1 <= UCE_TB && cy0 + ky1 - 1 < h;
+        if (!in0 && !in1) continue;
+        const int b0 = min(max(ky0, 0), UCE_NB - 1), b1 = min(max(ky1, 0), UCE_NB - 1);
+        const int2* llr = sLL + r * nx;
+        float cs[UCE_TB + 2];  // column sums of this row by block column + 1 (0 and TB + 1: the halo, dropped)
+#pragma unroll
+        for (int k = 0; k < UCE_TB + 2; ++k) cs[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k <= UCE_TB; ++k) {  // pairs (k, k + 1); at the far edge of the map (k, k)
+          const int x0 = xs[k], x1 = xs[k + 1];
+          if (x0 == x1) continue;  // (uniform)
+          const int kx1 = sc(sXT[x0].y);
+          const int a1 = min(max(kx1, 0), UCE_NB - 1);
+          const float n00 = sN[(b0 * UCE_NB + k) * 128 + lane], n01 = sN[(b0 * UCE_NB + a1) * 128 + lane];
+          const float n10 = sN[(b1 * UCE_NB + k) * 128 + lane], n11 = sN[(b1 * UCE_NB + a1) * 128 + lane];
+          const float A0 = (yl0 * n00 + yl1 * n10) * 1.4426950408889634f;
+          const float A1 = (yl0 * n01 + yl1 * n11) * 1.4426950408889634f;
+          float s0 = 0.f, s1 = 0.f;
+          // one 16-byte column record + one 8-byte pixel record per step, the next step's pair requested before this one is used
+          int4 xt_n = sXT[x0];
+          int2 ll_n = llr[x0];
+          for (int xx = x0; xx < x1; ++xx) {
+            const int4 xt = xt_n;
+            const int2 ll = ll_n;
+            const int xn = min(xx + 1, nx - 1);
+            xt_n = sXT[xn];
+            ll_n = llr[xn];
+            const int lab = sc(ll.x);
+            if (lab == ignore) continue;
+            const float xl0 = __int_as_float(sc(xt.z)), xl1 = __int_as_float(sc(xt.w));
+            const float ls = __int_as_float(sc(ll.y));
+            const float gq = __builtin_amdgcn_exp2f(fmaf(xl1, A1, fmaf(xl0, A0, -ls))) - (c == lab ? 1.f : 0.f);
+            s0 = fmaf(xl0, gq, s0);
+            s1 = fmaf(xl1, gq, s1);
+          }
+          cs[k] += s0;
+          if (kx1 == k) cs[k] += s1; else cs[k + 1] += s1;  // (uniform)
+        }
+#pragma unroll
+        for (int k = 1; k <= UCE_TB; ++k) {
+          if (cx0 + k - 1 < w) {
+            if (in0) acc[((ky0 - 1) * UCE_TB + k - 1) * 128] += yl0 * cs[k];
+            if (in1) acc[((ky1 - 1) * UCE_TB + k - 1) * 128] += yl1 * cs[k];
+          }
+        }
+      }
+    } else if (c < C) {
       float* acc = sAcc + grp * UCE_TB * UCE_TB * 128 + lane;
       for (int r = grp; r < ny; r += 4) {
         int ky0, ky1;
@@ -185,7 +250,7 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
         for (int xx = 0; xx < nx; ++xx) {
           int kx0, kx1;
           float xl0, xl1;
-          if (xx < UCE_FP) { kx0 = sXi[2 * xx]; kx1 = sXi[2 * xx + 1]; xl0 = sXl[2 * xx]; xl1 = sXl[2 * xx + 1]; }
+          if (xx < UCE_FP) { const int4 xt = sXT[xx]; kx0 = xt.x; kx1 = xt.y; xl0 = __int_as_float(xt.z); xl1 = __int_as_float(xt.w); }
           else { const Interp ix = src_index(x_lo + xx, sx, w); kx0 = ix.i0 - cx0 + 1; kx1 = ix.i1 - cx0 + 1; xl0 = ix.l0; xl1 = ix.l1; }
           if (kx0 != cur0 || kx1 != cur1) {  // a new column pair: fold the finished one, fetch this one's four cell logits
             flush();
@@ -197,8 +262,7 @@ __global__ __launch_bounds__(512) void upsample_ce_bwd_kernel(const float* __res
           }
           int lab;
           float ls;
-          if (staged) { lab = sLab[r * nx + xx]; ls = sLse[r * nx + xx]; }
-          else { const long p = ((long)b * H + y_lo + r) * W + x_lo + xx; lab = (int)label[p]; ls = lse[p]; }
+          { const long p = ((long)b * H + y_lo + r) * W + x_lo + xx; lab = (int)label[p]; ls = lse[p]; }  // (footprints past the staged size)
           if (lab == ignore) continue;
           const float v = yl0 * (xl0 * n00 + xl1 * n01) + yl1 * (xl0 * n10 + xl1 * n11);
           const float gq = __expf(v - ls) - (c == lab ? 1.f : 0.f);

@@ -143,6 +143,7 @@ class FlatAdamW:
         # refreshed by the update kernel for every tensor it steps, recomputed from the arena after any other change
         # (words of the operator layer's range buffer, ops.RANGES: one per parameter tensor, at the top of the buffer)
         self.seg_amax_ptr = ops.RANGES.param_region(max(n, 1), device) if device.type == 'cuda' else 0
+        self.chunk_amax = torch.zeros(4 * max(self.nchunks, 1), dtype=torch.int32, device=device)  # (scratch: per-wavefront maxima of a chunk)
         self._seg_order = np.argsort(np.asarray(self.offsets, dtype=np.int64), kind='stable')
         self._seg_starts = np.asarray(self.offsets, dtype=np.int64)[self._seg_order]
         self.amax_dirty = True
@@ -180,7 +181,8 @@ class FlatAdamW:
     def refresh_amax(self):
         if self.device.type == 'cuda':
             lib.call('rscotr_param_amax', self.flat_p.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
-                     self.chunk_len.data_ptr(), self.nchunks, self.seg_amax_ptr, len(self.groups), ops._stream())
+                     self.chunk_len.data_ptr(), self.nchunks, self.seg_amax_ptr, len(self.groups), self.chunk_amax.data_ptr(),
+                     ops._stream())
         self.amax_dirty = False
 
     def amax_slot(self, ptr):
@@ -280,7 +282,7 @@ class FlatAdamW:
         lib.call('rscotr_adamw_clip_step_r', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                  self.flat_v.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(), self.chunk_len.data_ptr(),
                  self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), self.max_norm, float(b1), float(b2),
-                 float(self.eps), self.seg_amax_ptr, len(self.groups), s)
+                 float(self.eps), self.seg_amax_ptr, len(self.groups), self.chunk_amax.data_ptr(), s)
 
     def step(self):
         self.prepare_step()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic counters of the bench command, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do
 # not fit one pass; no trace domains besides --kernel-trace next to --pmc).  Counter collection serialises every
-# instrumented dispatch (~11 ms each here), so it is restricted to the tiled GEMM family (fp32 pipe, bf16x6, the grouped weight-gradient launch) and the MSDA kernels: the whole
+# instrumented dispatch (~11 ms each here), so it is restricted to the tiled GEMM family (fp32 pipe, the fp16 / bf16 split products, the grouped weight-gradient launch) and the MSDA kernels: the whole
 # step (80k dispatches) does not finish in 15 minutes per counter.  scripts/pmc_summary.py folds the two CSVs into
 # profiles/pmc_gemm_traffic.json, which bench.py reads for roofline.traffic.
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -9,7 +9,7 @@ TAG=${1:-r1}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_bf16x3|gemm_bf16x6|gemm_wplanes|gemm_f32_group|msda_|attn_' --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-rounds 1 > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_h3|gemm_bf16x6|gemm_f32_group|msda_|attn_' --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-rounds 1 > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   python - "$f" "$R/gpurun_out/${TAG}_pmc_$c.csv" <<'PY'
 import csv, sys, collections

@@ -11,8 +11,11 @@ def key(name):
     m = re.match(r'(rscotr::gemm_f32_kernel<\d+, \d+, \d+, \d+, \w+, \w+), .*>', name)
     if m:
         return m.group(1) + ', *>'
-    m = re.match(r'(rscotr::gemm_bf16x6_kernel<\d+, \d+, \w+, \w+), .*>', name)
-    return m.group(1) + ', *>' if m else name
+    m = re.match(r'(rscotr::gemm_(?:bf16x6|h3)_kernel<\d+, \d+, \w+, \w+), .*>', name)
+    if m:
+        return m.group(1) + ', *>'
+    m = re.match(r'rscotr::gemm_h3_128_kernel<(\w+, \w+), .*>', name)  # (bench.py names the 128 x 128 instantiation by its tile)
+    return 'rscotr::gemm_h3_kernel<128, 128, ' + m.group(1) + ', *>' if m else name
 
 
 def load(path):
@@ -32,7 +35,7 @@ for k in fetch:
         kernels[k] = dict(dispatches=fetch[k][0], fetch_kib_per_launch=fetch[k][1] / fetch[k][0],
                           write_kib_per_launch=write[k][1] / write[k][0])
 json.dump({
-    'command': "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_bf16x3|gemm_bf16x6|gemm_wplanes|gemm_f32_group|msda_' -- python "
+    'command': "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_h3|gemm_bf16x6|gemm_f32_group|msda_|attn_' -- python "
                'bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-rounds 1 (scripts/gpu_pmc.sh, scripts/pmc_summary.py)',
     'units': 'KiB per dispatch as reported; FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md, HBM): '
              'bench.py doubles it',
