@@ -364,6 +364,7 @@ def main():
         # dominant kernel of the step = the fp32 MFMA GEMM family; report the instantiation that takes the
         # most time, the whole family next to it
         gg = group('gemm')
+        pmc_applies = a.workload == 'mtl512' and a.size == WORKLOADS['mtl512']['size'] and a.batch == WORKLOADS['mtl512']['batch']
         # (the fused attention core reports through the GEMM kind with DENSE-equivalent flops — fully masked tiles are skipped by
         # the kernel — and has its own two lines below: it stays out of the GEMM family's sums)
         ga = {k: v for k, v in gg.items() if 'attn_' in k}
@@ -402,9 +403,9 @@ def main():
                                   '2 M N K over the problems of the launch, stated by the host that built the table); ') + r_gemm['note']
             # HBM traffic of that kernel: rocprofv3 PMC passes over this same command (scripts/gpu_pmc.sh), summary
             # committed under profiles/; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-            try:
+            try:  # (the committed PMC passes ran the default workload: no traffic figure for the others)
                 with open(os.path.join(ROOT, 'profiles', 'pmc_gemm_traffic.json')) as fh:
-                    pm = json.load(fh)['kernels'].get(name)
+                    pm = json.load(fh)['kernels'].get(name) if pmc_applies else None
                 if pm:
                     r_gemm['traffic'] = (2.0 * pm['fetch_kib_per_launch'] + pm['write_kib_per_launch']) * 1024.0
                     r_gemm['traffic_note'] = ('bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB) averaged over the '
@@ -474,7 +475,7 @@ def main():
         r_b = hbm('msda_bwd', 'rscotr_msda_bwd (sample + tile + combine kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
             with open(os.path.join(ROOT, 'profiles', 'pmc_gemm_traffic.json')) as fh:
-                pk = json.load(fh)['kernels']
+                pk = json.load(fh)['kernels'] if pmc_applies else {}
             tb = lambda v: (2.0 * v['fetch_kib_per_launch'] + v['write_kib_per_launch']) * 1024.0
             fw = [v for k, v in pk.items() if 'msda_fwd_kernel' in k]
             if r_f and fw:

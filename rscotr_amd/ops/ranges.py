@@ -152,7 +152,11 @@ class _Ranges:
         return s
 
     def _verify(self, t, rows, cols, ld, p, slot, what):
-        """RSCOTR_RANGES_CHECK=1 (debugging aid, synchronises): the slot a tensor carries must bound what it holds NOW."""
+        """RSCOTR_RANGES_CHECK=1 (debugging aid, synchronises): the slot a tensor carries must bound what it holds NOW.
+        (Not while a hipGraph is being captured — a synchronisation there invalidates the capture; the eager warm-up
+        iterations in front of every capture run the same code with the check on.)"""
+        if torch.cuda.is_current_stream_capturing():
+            return
         probe = torch.zeros((self.PLANES, self.STRIDE), dtype=torch.int32, device=t.device)
         lib.call('rscotr_amax_f32', p, rows, cols, ld, probe.data_ptr(), _stream())
         torch.cuda.current_stream().synchronize()
