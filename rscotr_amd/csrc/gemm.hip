@@ -881,6 +881,9 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   // (64 x 64 tiles only: on the 128 x 128 one-stage bf16 kernel the 16-register batch costs the third resident workgroup, and on
   // the fp16 one — measured cold, 10880 x 2048 x 256 + residual: 109.7 against 105.8 us — it buys nothing: those launches are
   // bound by the 190 MB their epilogue moves in 512-byte row segments 8 KB apart)
+  // (Requesting the 16 values in the PROLOGUE instead, so that they wait in registers through the k loop, measured SLOWER in the
+  // step: 34.27 against 34.11 ms per round on one box, two runs each — the in-order load counter makes the second k-step wait
+  // for them, and 130 + 32 registers leave the scheduler no slack under the three-workgroup cap.)
   const bool one_extra = BM == 64 && !p.C2 &&
                          ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
   float amx = 0.f;
