@@ -462,6 +462,13 @@ __device__ __forceinline__ void split_rows4(const float4& e, const float4& o, ui
 // h h into one accumulator and l h + h l into a second one that enters with 2^-11 at the end (fp32 accumulate; the dropped
 // l l term is <= 2^-24 |a||b|): THREE v_mfma_f32_32x32x16_f16 per 16 k instead of six bf16 ones, two planes instead of three
 // through the conversion and LDS.  7 VALU instructions per value pair (pk_mul, cvt_pk, 2 cvt, pk_mul, pk_fma, cvt_pk).
+// (Measured and not kept, profiles/r5_h3_one_acc.txt: l UNSCALED and all three MFMAs into ONE accumulator set — 16 / 64 accumulator
+// registers and one VALU instruction per value pair less, the 64 x 64 kernel at four workgroups per CU: 34.55 -> 33.86 ms per
+// round with every product on it, 34.0 -> 33.7 with the forward-layout products only.  Its error is that of an fp32 FMA chain
+// (4.3e-7 of max|C| against 2.5e-7 here), and elements more than 2^16 below the tensor's amax keep 11 bits only (fp16's 5-bit
+// exponent; 2^27 with the scaled l).  The det step at 256^2, seed 4, then takes a ReLU gate of a decoder FFN on the other side
+// — a coin toss for any fp32-class product, but outside the band tests/parity.py flips (3e-6 of the mean |pre-activation|)
+// — and leaves the 1e-3 tier by 4e-3 on decoder layer 5.  Parity first: the two accumulator sets stay.)
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct H3Scale {

@@ -1,2 +1,2 @@
-bash scripts/lab/pmc_cmd.sh pmc_h3_64 'gemm_h3_kernel<64, 64, false, true, 2, false>' python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-wc -l gpurun_out/pmc_h3_64/counters.txt
+mkdir -p gpurun_out/t9
+RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_one64.so python scripts/lab/h3_det_flip.py > gpurun_out/t9/flip.txt 2>&1
