@@ -388,6 +388,8 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
   amax_commit(p.amax_out, amx);
 }
 
+// (holding the k-group instantiations — 512 / 1024 threads, 68-72 registers — to 64 registers so that two 1024-thread workgroups
+// fit a CU measured nothing: 33.80 against 33.79 ms per round)
 template <int BM, int BN, int WM, int WN, bool AK, bool BK_, bool EDGE, int KG>
 __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
   gemm_f32_body<BM, BN, WM, WN, AK, BK_, EDGE, KG, false>(p, blockIdx.x, gridDim.x, blockIdx.y);
@@ -934,8 +936,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
   gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false>
-__global__ __launch_bounds__(256) void gemm_h3_kernel(GemmParams p) {
+// OCC: wavefronts per SIMD the register allocation is held to (1: the compiler's own choice).  The interior pipelined 64 x 64
+// kernels with a row-major A take 134 / 146 registers on their own and 126 / 128 without a spill when asked: four workgroups
+// per CU instead of three
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm_h3_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, true>()];
   gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, true>(p, blockIdx.x, gridDim.x, lds);
 }
@@ -1336,7 +1341,11 @@ static void launch_h3(const GemmParams& p, int a_kmajor, int b_kmajor, unsigned 
     else if (!b_kmajor) gemm_h3_128_kernel<true, false, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else gemm_h3_128_kernel<true, true, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
   } else {
-    if (!a_kmajor && !b_kmajor) gemm_h3_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
+    // (the interior pipelined 64 x 64 kernels with a row-major A: the 128-register instantiations, four workgroups per CU —
+    // 33.84 against 34.00 ms per round, bit-identical results)
+    if (BM == 64 && PIPE == 2 && !EDGE && !a_kmajor && !b_kmajor) gemm_h3_kernel<64, 64, false, false, 2, false, 4><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (BM == 64 && PIPE == 2 && !EDGE && !a_kmajor && b_kmajor) gemm_h3_kernel<64, 64, false, true, 2, false, 4><<<dim3(nwg), 256, 0, s>>>(p);
+    else if (!a_kmajor && !b_kmajor) gemm_h3_kernel<BM, BM, false, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else if (!a_kmajor) gemm_h3_kernel<BM, BM, false, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else if (!b_kmajor) gemm_h3_kernel<BM, BM, true, false, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
     else gemm_h3_kernel<BM, BM, true, true, PIPE, EDGE><<<dim3(nwg), 256, 0, s>>>(p);
