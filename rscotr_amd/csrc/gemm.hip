@@ -623,7 +623,7 @@ struct SplitOperand {
 // operand row is one whole 128-byte line per step; half as many barriers), PIPE 3 stages 16 (128 x 128 tiles: LDS).
 __device__ const float bf16x6_one = 1.f;
 #ifndef RSCOTR_X6_BK0
-#define RSCOTR_X6_BK0 16  // k per barrier pair of the one-stage loop (PIPE 0: the 128 x 128 kernels, the grouped launch's bodies)
+#define RSCOTR_X6_BK0 32  // k per barrier pair of the one-stage loop (PIPE 0: the 128 x 128 kernels, the grouped launch's bodies).  Round 4 measured 32 at +0.2 ms per round on the six-term bf16 product (MFMA + conversion issue bound); on the fp16 product, which waits on memory for half of its wave life (profiles/r5_h3_64_pmc.txt), 32 is -0.6 ms: 33.73 against 34.32
 #endif
 template <int PIPE> constexpr int bf16x6_bk() { return PIPE == 2 ? 32 : PIPE == 0 ? RSCOTR_X6_BK0 : 16; }
 #ifndef RSCOTR_X6_D2

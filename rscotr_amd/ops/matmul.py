@@ -167,7 +167,7 @@ class _DeferredCombine:
                 if x6 != variant:
                     continue
                 sp = max(1, -(-K // max(256, klen_t // (4 if x6 in (6, 7) else 1))))
-                kq = 16
+                kq = 32 if x6 in (6, 7) else 16  # (k-slices of whole steps of the body: the one-stage split loop takes 32 k per barrier pair, the fp32 body 16)
                 klen = -(-(-(-K // sp)) // kq) * kq
                 sp = -(-K // klen)
                 if sp == 1:
