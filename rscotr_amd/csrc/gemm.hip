@@ -837,8 +837,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
     for (int t = 0; t < nk; ++t) {
       __syncthreads();  // the previous tile has been consumed
       stage(sA[0], sB[0]);
+      if (t + 1 < nk) fetch(t + 1);  // next tile's global loads: requested before the barrier, in flight under it and the MFMAs
       __syncthreads();
-      if (t + 1 < nk) fetch(t + 1);  // next tile's global loads fly under the MFMAs
       mma(sA[0], sB[0]);
     }
   }

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/t15
 python -m pytest tests/test_gemm_gpu.py tests/test_h3_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | cut -c1-300
-BENCH_ARGS=--no-roofline bash scripts/gpu_ab_bench.sh t15 "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_bk16.so" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_bk64.so" "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_bk16.so" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_bk64.so" > /dev/null 2>&1
+BENCH_ARGS=--no-roofline bash scripts/gpu_ab_bench.sh t18 "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_latefetch.so" "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_latefetch.so" > /dev/null 2>&1
