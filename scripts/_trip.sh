@@ -1,2 +1,11 @@
-python -m pytest tests/test_gemm_gpu.py tests/test_h3_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | cut -c1-300
-BENCH_ARGS=--no-roofline bash scripts/gpu_ab_bench.sh t18 "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_latefetch.so" "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_latefetch.so" > /dev/null 2>&1
+mkdir -p gpurun_out/r5
+bash scripts/gpu_prof_graph.sh r5/r5
+bash scripts/gpu_prof_bench.sh r5/r5
+bash scripts/gpu_pmc.sh r5/r5
+python scripts/pmc_summary.py gpurun_out/r5/r5_pmc_FETCH_SIZE.csv gpurun_out/r5/r5_pmc_WRITE_SIZE.csv gpurun_out/r5/pmc_gemm_traffic.json
+cp gpurun_out/r5/pmc_gemm_traffic.json profiles/pmc_gemm_traffic.json
+python bench.py > gpurun_out/r5/r5_bench.json 2> gpurun_out/r5/r5_bench.err; cut -c1-300 gpurun_out/r5/r5_bench.json
+python bench.py --workload det800 --no-cpu-baseline > gpurun_out/r5/r5_bench_det800.json 2>/dev/null; cut -c1-300 gpurun_out/r5/r5_bench_det800.json
+python bench.py --workload swinb1024 --no-cpu-baseline > gpurun_out/r5/r5_bench_swinb1024.json 2>/dev/null; cut -c1-300 gpurun_out/r5/r5_bench_swinb1024.json
+RSCOTR_DIST_SINGLE=1 python bench.py --no-cpu-baseline > gpurun_out/r5/r5_bench_dist_single.json 2>/dev/null; cut -c1-300 gpurun_out/r5/r5_bench_dist_single.json
+RSCOTR_DIST_SINGLE=1 python bench.py --no-cpu-baseline --exchange overlap > gpurun_out/r5/r5_bench_dist_single_overlap.json 2>/dev/null; cut -c1-300 gpurun_out/r5/r5_bench_dist_single_overlap.json
