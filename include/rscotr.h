@@ -176,8 +176,26 @@ int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, in
                       float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
                       const uint32_t* amax_b, uint32_t* amax_out, void* stream);
 int rscotr_gemm_set_h3(int on);
-/* 1 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
- * product once both value ranges are supplied: callers ask before they go looking for ranges. */
+/* The B operand of the fp16 split product from PRE-SPLIT PLANES (round 5).  In y = x W^T and dx = dy W the B tile of a
+ * workgroup is a weight — it changes once per optimizer step, yet every row tile of every launch converts it again, and the
+ * k loop of the 64 x 64 kernel is bound by that conversion (profiles/r5_h3_64_pmc.txt).  rscotr_gemm_split_weights_h3 writes the
+ * two fp16 planes of a weight once per step, scaled by the power of two of its range word: layout [reduction / 32][rpad][h | l][32]
+ * fp16, rpad = plane rows rounded up to 64 (zero rows behind the end).  table: device (n, 9) int64 rows {W, planes, rows of W,
+ * cols of W, ldw, rpad, first block, transposed, address of the parameter's range word}; transposed = 0: the planes of W (for a
+ * row-major B: y = x W^T), 1: of W^T (for a k-major B: dx = dy W); reduction % 32 == 0; an entry takes
+ * ceil(rpad * (reduction / 32) / 256) blocks, total_blocks = their sum.  rscotr_gemm_f32_rb = rscotr_gemm_f32_r with the plane
+ * set of B given as well: where rscotr_gemm_f32_split_route answers 2 the kernel stages B from the planes (bit-identical to
+ * the in-kernel split: same planes), everywhere else B itself is used.  The range word must not have changed since the split. */
+int rscotr_gemm_split_weights_h3(const int64_t* table, int n, int total_blocks, void* stream);
+int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                       int ldc, int a_kmajor, int b_kmajor, const float* bias, int act, const float* aux,
+                       float* pre, const float* resid, int accumulate, float* rowsum, int rowsum_accumulate,
+                       const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
+                       float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
+                       const uint32_t* amax_b, uint32_t* amax_out, const void* b_planes, int b_rpad, void* stream);
+/* > 0 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
+ * product once both value ranges are supplied: callers ask before they go looking for ranges.  2: the interior pipelined
+ * 64 x 64 kernel, which can take a weight operand B from pre-split planes (rscotr_gemm_f32_rb). */
 int rscotr_gemm_f32_split_route(int M, int N, int K, int lda, int ldb, int a_kmajor, int b_kmajor, int act, int has_pre,
                                 int has_rowscale, int has_kscale, int64_t workspace_bytes);
 int rscotr_amax_f32(const float* X, int64_t rows, int cols, int ld, uint32_t* slot, void* stream);

@@ -615,6 +615,35 @@ struct SplitOperand {
   }
 };
 
+// B operand of the fp16 split product from PRE-SPLIT planes (round 5, rscotr_gemm_split_weights_h3): in y = x W^T and dx = dy W the
+// B tile of a workgroup is a weight, which changes once per optimizer step, yet every one of the M / 64 row tiles of every launch
+// converts it again — and the k loop of the 64 x 64 kernel is bound by exactly that conversion issue (78 VALU instructions per 6
+// MFMAs and k-step, half of them B's: profiles/r5_h3_64_pmc.txt).  Plane layout [K / 32][rows padded to 64][h | l][32 k] fp16 (the
+// planes of W for y = x W^T, of W^T for dx = dy W, so the kernel never sees a k-major B): the 64-row stage of a workgroup is ONE
+// contiguous 8 KB run, 32 bytes per thread, written to the LDS rows of SplitOperand<R, false, 2, 32, true> as they are — no VALU
+// work.  The planes carry the scale of the weight's range word at the time of the split; the consumer takes its 2^-s from the
+// same word (the word only changes in the optimizer step, after which the planes are re-split).
+template <int R, int SBK>
+struct PlaneOperandH {
+  using Lay = SplitOperand<R, false, 2, SBK, true>;
+  static_assert(R == 64 && SBK == 32, "one 32-byte piece per thread");
+  static constexpr int WORDS = Lay::WORDS, KP = Lay::KP;
+  float4 v[2];
+  // P: the plane set (as const float* for the shared body), ld: its padded row count
+  template <bool EDGE = false>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid, int = 0, int = 0) {
+    const float4* src = reinterpret_cast<const float4*>(P) + ((long)(k0 / SBK) * ld + row0) * 8 + tid * 2;
+    v[0] = src[0];
+    v[1] = src[1];
+  }
+  __device__ __forceinline__ void store(unsigned* S, int tid, const H3Scale& = H3Scale{1.f, 2048.f}) const {
+    float4* dst = reinterpret_cast<float4*>(S + (tid >> 2) * (Lay::LDR / 2) + (tid & 3) * 8);
+    dst[0] = v[0];
+    dst[1] = v[1];
+  }
+  static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) { Lay::frag(S, row, g, ks, f); }
+};
+
 // PIPE: 0 = one LDS stage, two barriers per k-tile of 16; 1 = two LDS stages, one barrier, next tile's loads one step ahead;
 // 2 / 3 = the software-pipelined loop (two LDS stages, one barrier): the loads of tile t + D are issued at the top of step t
 // into the register set step t - 1 freed (D = 2 / 3 sets), and the split / pack / LDS writes of tile t + 1 are interleaved
@@ -647,12 +676,13 @@ constexpr int bf16x6_lds_words() {
 // lds: bf16x6_lds_words() dwords, 16-byte aligned.
 // H16: the fp16 split product (split_pair_h above): operands scaled by powers of two from p.amax_a / p.amax_b (both
 // required), three MFMAs per 16 k into two accumulator sets.
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool H16 = false>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool SLAB, bool EDGE = false, bool H16 = false, bool BPL = false>
 __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, const int gx, unsigned* lds) {
   constexpr int NPL = H16 ? 2 : 3, SBK = bf16x6_bk<PIPE>(), D = bf16x6_depth<PIPE>();
   constexpr int MT = BM / 64, NT = BN / 64;
   using OA = SplitOperand<BM, AKM, NPL, SBK, H16>;
-  using OB = SplitOperand<BN, BKM, NPL, SBK, H16>;
+  static_assert(!BPL || (H16 && !BKM && !EDGE && PIPE == 2), "B from planes: the interior pipelined fp16 kernel");
+  using OB = typename std::conditional<BPL, PlaneOperandH<BN, SBK>, SplitOperand<BN, BKM, NPL, SBK, H16>>::type;
   H3Scale ha{1.f, 2048.f}, hb{1.f, 2048.f};
   float inva = 1.f, invb = 1.f;
   // The range words are REQUESTED here and reduced (h3_scales) only after the first operand tiles have been requested too:
@@ -939,10 +969,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(GemmParams p) {
 // OCC: wavefronts per SIMD the register allocation is held to (1: the compiler's own choice).  The interior pipelined 64 x 64
 // kernels with a row-major A take 134 / 146 registers on their own and 126 / 128 without a spill when asked: four workgroups
 // per CU instead of three
-template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, int OCC = 1>
+template <int BM, int BN, bool AKM, bool BKM, int PIPE, bool EDGE = false, int OCC = 1, bool BPL = false>
 __global__ __launch_bounds__(256, OCC) void gemm_h3_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned lds[bf16x6_lds_words<BM, BN, AKM, BKM, PIPE, true>()];
-  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, true>(p, blockIdx.x, gridDim.x, lds);
+  gemm_bf16x6_body<BM, BN, AKM, BKM, PIPE, false, EDGE, true, BPL>(p, blockIdx.x, gridDim.x, lds);
 }
 // 128 x 128 tiles: two accumulator sets are 128 registers; held to two wavefronts per SIMD (256 registers in all) so that
 // two workgroups per CU cover each other's staging phases in the one-stage loop
@@ -1167,6 +1197,54 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const int64_t* __res
   for (int pl = 0; pl < 3; ++pl) {
     dst[pl * 2] = make_uint4(out[pl][0], out[pl][1], out[pl][2], out[pl][3]);
     dst[pl * 2 + 1] = make_uint4(out[pl][4], out[pl][5], out[pl][6], out[pl][7]);
+  }
+}
+
+// Planes of weights for PlaneOperandH (rscotr_gemm_split_weights_h3): table rows {W, planes, rows of W, cols of W, ldw, rpad,
+// first block, transposed, range word of the parameter} (int64 x 9).  transposed = 0: planes of W (plane rows = rows of W,
+// reduction over its columns: y = x W^T); 1: planes of W^T (plane rows = columns of W, reduction over its rows: dx = dy W).
+// The reduction length is a multiple of 32; rpad = plane rows rounded up to 64, the rows past the end are zeros.  One thread per
+// (k-step, plane row): 32 values in, one 128-byte record {h[32], l[32]} out; an entry takes ceil(rpad * (reduction / 32) / 256)
+// blocks.  Consecutive threads take consecutive plane rows of one k-step (the records of a k-step are contiguous; transposed
+// reads run along the rows of W).
+__global__ __launch_bounds__(256) void split_weights_h3_kernel(const int64_t* __restrict__ table, int n_entries) {
+  int e = 0;
+  while (e + 1 < n_entries && (long)table[(long)(e + 1) * 9 + 6] <= (long)blockIdx.x) ++e;
+  const int64_t* t = table + (long)e * 9;
+  const float* W = reinterpret_cast<const float*>(t[0]);
+  uint4* planes = reinterpret_cast<uint4*>(t[1]);
+  const int wrows = (int)t[2], wcols = (int)t[3], ldw = (int)t[4], rpad = (int)t[5], tr = (int)t[7];
+  const int rows = tr ? wcols : wrows, red = tr ? wrows : wcols;
+  const int se = h3_scale_exp(amax_read(reinterpret_cast<const unsigned*>(t[8])));
+  const H3Scale hs{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(se + 11) << 23)};
+  const long idx = ((long)blockIdx.x - t[6]) * 256 + threadIdx.x;
+  const int nkt = red / 32;
+  const int kt = (int)(idx / rpad), row = (int)(idx % rpad);
+  if (kt >= nkt) return;
+  float v[32];
+  if (row >= rows) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+  } else if (!tr) {
+    const float4* src = reinterpret_cast<const float4*>(W + (long)row * ldw + kt * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = W[(long)(kt * 32 + i) * ldw + row];
+  }
+  unsigned h[16], l[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    unsigned o[3];
+    split_pair_h(v[2 * q], v[2 * q + 1], hs, o);
+    h[q] = o[0]; l[q] = o[1];
+  }
+  uint4* dst = planes + ((long)kt * rpad + row) * 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dst[q] = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    dst[4 + q] = make_uint4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
   }
 }
 
@@ -2006,7 +2084,7 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
                          float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
                          const float* kscale, int krows_per_scale, float* out2, float* workspace,
                          int64_t workspace_bytes, void* stream, const uint32_t* amax_a, const uint32_t* amax_b,
-                         uint32_t* amax_out);
+                         uint32_t* amax_out, const void* b_planes = nullptr, int b_rpad = 0);
 
 extern "C" int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda,
                                int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
@@ -2031,13 +2109,30 @@ extern "C" int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M
                        stream, amax_a, amax_b, amax_out);
 }
 
+// rscotr_gemm_f32_r with the B operand ALSO given as pre-split fp16 planes (rscotr_gemm_split_weights_h3: the planes of B for a
+// row-major B, of its transpose for a k-major one; b_rpad = their padded row count).  Taken where rscotr_gemm_f32_split_route
+// answers 2 (the interior pipelined 64 x 64 fp16 kernel); everywhere else the call is rscotr_gemm_f32_r on B itself.
+extern "C" int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, int K, int lda,
+                                  int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
+                                  const float* aux, float* pre, const float* resid, int accumulate,
+                                  float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
+                                  const float* kscale, int krows_per_scale, float* out2, float* workspace,
+                                  int64_t workspace_bytes, const uint32_t* amax_a, const uint32_t* amax_b, uint32_t* amax_out,
+                                  const void* b_planes, int b_rpad, void* stream) {
+  if (b_planes && (b_rpad < N || b_rpad % 64 || ((uintptr_t)b_planes & 15)))
+    return fail(RSCOTR_E_ARG, "rscotr_gemm_f32_rb: the plane set has %d rows for N = %d (a multiple of 64 >= N, 16-byte aligned)", b_rpad, N);
+  return gemm_f32_impl(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, act, aux, pre, resid, accumulate, rowsum,
+                       rowsum_accumulate, rowscale, rows_per_scale, kscale, krows_per_scale, out2, workspace, workspace_bytes,
+                       stream, amax_a, amax_b, amax_out, b_planes, b_rpad);
+}
+
 static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda,
                          int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
                          const float* aux, float* pre, const float* resid, int accumulate,
                          float* rowsum, int rowsum_accumulate, const float* rowscale, int rows_per_scale,
                          const float* kscale, int krows_per_scale, float* out2, float* workspace,
                          int64_t workspace_bytes, void* stream, const uint32_t* amax_a, const uint32_t* amax_b,
-                         uint32_t* amax_out) {
+                         uint32_t* amax_out, const void* b_planes, int b_rpad) {
   if (M < 0 || N < 0 || K < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: negative dimension");
   if ((rowscale && rows_per_scale <= 0) || (kscale && (krows_per_scale <= 0 || !a_kmajor)))
     return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: rowscale needs rows_per_scale > 0; kscale needs a k-major A and krows_per_scale > 0");
@@ -2106,12 +2201,15 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
       static const bool prof_shapes_6 = getenv("RSCOTR_PROF_SHAPES") != nullptr;
       const bool h3 = amax_a && amax_b && g_h3_on.load(std::memory_order_relaxed);
       p.amax_a = amax_a; p.amax_b = amax_b;
+      static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;  // bit 0: 64 x 64 (measured -0.45 ms / round), bit 1: 128 x 128 (measured slower on every layout of the step: +0.65 ms)
+      // B from its pre-split planes (rscotr_gemm_f32_rb; row-major by construction): the interior pipelined 64 x 64 fp16 kernel only
+      const bool use_planes = h3 && b_planes && !a_kmajor && !ragged && sc.bm == 64 && (pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0;
+      if (use_planes) b_kmajor = 0;  // (what the kernel and its profile name see)
       char xname[112];
       if (prof_shapes_6) snprintf(xname, sizeof(xname), "M=%d N=%d K=%d %d%d %s-%d splits=%d", M, N, K, a_kmajor, b_kmajor, h3 ? "h3" : "bf16x6", sc.bm, sc.splits);
       else snprintf(xname, sizeof(xname), "rscotr::gemm_%s_kernel<%d, %d, %s, %s, *>", h3 ? "h3" : "bf16x6", sc.bm, sc.bm, a_kmajor ? "true" : "false", b_kmajor ? "true" : "false");
       ProfScope prof(PROF_GEMM, 2.0 * M * N * K, s, "%s", xname);
       const unsigned nwg = sc.splits > 1 ? (unsigned)(8 * ((p.tiles >> 3) + ((p.tiles & 7) ? 1 : 0)) * sc.splits) : (unsigned)p.tiles;
-      static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;  // bit 0: 64 x 64 (measured -0.45 ms / round), bit 1: 128 x 128 (measured slower on every layout of the step: +0.65 ms)
       if (h3) {  // the fp16 split product: same tiles, same loops
         if (ragged) {
           if (sc.bm == 128) launch_h3<128, 0, true>(p, a_kmajor, b_kmajor, nwg, s);
@@ -2120,8 +2218,17 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
         } else if (sc.bm == 128) {
           launch_h3<128, 0>(p, a_kmajor, b_kmajor, nwg, s);
         } else {
-          if ((pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0) launch_h3<64, 2>(p, a_kmajor, b_kmajor, nwg, s);
-          else launch_h3<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+          if ((pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0) {
+            if (use_planes) {  // no conversion of B in the loop
+              p.B = reinterpret_cast<const float*>(b_planes);
+              p.ldb = b_rpad;
+              gemm_h3_kernel<64, 64, false, false, 2, false, 4, true><<<dim3(nwg), 256, 0, s>>>(p);
+            } else {
+              launch_h3<64, 2>(p, a_kmajor, b_kmajor, nwg, s);
+            }
+          } else {
+            launch_h3<64, 1>(p, a_kmajor, b_kmajor, nwg, s);
+          }
         }
       } else if (ragged) {  // (EDGE instantiations: the 128 x 128 one-stage loop and the pipelined 64 x 64 loop)
         if (sc.bm == 128) launch_split6<128, 0, true>(p, a_kmajor, b_kmajor, nwg, s);
@@ -2235,7 +2342,12 @@ extern "C" int rscotr_gemm_f32_split_route(int M, int N, int K, int lda, int ldb
     const DwCfg d = choose_dw_direct(M, N, K);
     if (d.splits >= 2 && workspace_bytes >= d.splits * ((int64_t)M * N + M) * 4) return 0;
   }
-  return choose_split6(p, a_kmajor, b_kmajor, workspace_bytes).bm ? 1 : 0;
+  const Split6Cfg sc = choose_split6(p, a_kmajor, b_kmajor, workspace_bytes);
+  if (!sc.bm) return 0;
+  // 2: the interior pipelined 64 x 64 kernel, which can take its B operand from pre-split planes (rscotr_gemm_f32_rb)
+  static const int pipelined = getenv("RSCOTR_BF16X6_PIPE") ? atoi(getenv("RSCOTR_BF16X6_PIPE")) : 1;
+  const bool ragged = M % sc.bm || N % sc.bm || K % 16;
+  return (sc.bm == 64 && !ragged && !a_kmajor && (pipelined & 1) && K % 32 == 0 && sc.klen % 32 == 0) ? 2 : 1;
 }
 
 // Planes of weights for rscotr_gemm_f32_wplanes (layout: gemm_wplanes_kernel).  table: device (n, 8) int64 rows {W, planes, N,
@@ -2247,6 +2359,14 @@ extern "C" int rscotr_gemm_split_weights(const int64_t* table, int n, int total_
   if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_split_weights: null table");
   split_weights_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(table, n);
   return check_launch("rscotr_gemm_split_weights");
+}
+
+extern "C" int rscotr_gemm_split_weights_h3(const int64_t* table, int n, int total_blocks, void* stream) {
+  if (n < 0 || total_blocks < 0) return fail(RSCOTR_E_SHAPE, "rscotr_gemm_split_weights_h3: negative count");
+  if (n == 0 || total_blocks == 0) return RSCOTR_OK;
+  if (!table) return fail(RSCOTR_E_ARG, "rscotr_gemm_split_weights_h3: null table");
+  split_weights_h3_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(table, n);
+  return check_launch("rscotr_gemm_split_weights_h3");
 }
 
 // Tile width and k-slices of the pre-split product: one 128 x 256 workgroup is resident per CU (86 KB of LDS), two 128 x 128

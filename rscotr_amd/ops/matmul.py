@@ -31,14 +31,17 @@ class _WeightPlanes:
 
     def begin(self, group):
         self.current = group
+        HPLANES.current = group
 
     def reset(self):
         """Forget every plane set (a new optimizer arena: addresses may be reused by other parameters)."""
         self.entries, self.groups, self.tables = {}, {}, {}
         self.version += 1
+        HPLANES.reset()
 
     def bump(self):
         self.version += 1
+        HPLANES.version += 1
 
     def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, gelu=False):
         if not self.enabled or a_kmajor or STATE.grad_sink is None or K % 16 or N < 64:
@@ -87,7 +90,74 @@ class _WeightPlanes:
             self.entries[k]['version'] = self.version
 
 
+class _WeightPlanesH:
+    """fp16 planes of the weights that serve as B operand of the interior pipelined 64 x 64 fp16 split kernel (round 5,
+    rscotr_gemm_split_weights_h3 / rscotr_gemm_f32_rb): y = x W^T takes the planes of W, dx = dy W those of W^T.  A plane set
+    carries the scale of the parameter's range word at the time of the split, and that word only changes in the optimizer
+    step: the sets follow WPLANES' version (bump / reset / begin are forwarded from there) and the first product of an
+    iteration that finds its task's sets stale re-splits ALL of them in one launch (inside the task's hipGraph when the
+    iteration is replayed)."""
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_HPLANES', '1') != '0'
+        self.version = 1
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.current = None
+
+    def reset(self):
+        self.entries, self.groups, self.tables = {}, {}, {}
+        self.version += 1
+
+    def eligible(self, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, act, pre, rowscale, kscale, nws):
+        sink = STATE.grad_sink
+        if not self.enabled or not RANGES.enabled or a_kmajor or sink is None or K % 32 or ldb % 4 or B.data_ptr() % 16:
+            return False
+        if not sink.is_param_ptr(B.data_ptr()):
+            return False
+        key = (M, N, K, lda, ldb, int(a_kmajor), int(b_kmajor), int(act), pre is not None, rowscale is not None, kscale is not None,
+               nws, lib.rscotr_gemm_get_precision())
+        r = RANGES.route2.get(key)
+        if r is None:
+            r = RANGES.route2[key] = lib.rscotr_gemm_f32_split_route(M, N, K, lda, ldb, int(a_kmajor), int(b_kmajor), int(act),
+                                                                     int(pre is not None), int(rowscale is not None),
+                                                                     int(kscale is not None), nws) == 2
+        return r
+
+    def get(self, B, N, K, ldb, b_kmajor, word):
+        """-> (planes pointer, rpad) of the weight behind operand B (N plane rows, reduction K), fresh."""
+        key = (B.data_ptr(), N, K, ldb, int(b_kmajor))
+        e = self.entries.get(key)
+        if e is None:
+            rpad = (N + 63) // 64 * 64
+            e = self.entries[key] = dict(planes=torch.empty(rpad * K * 2, dtype=torch.int16, device=B.device), rpad=rpad,
+                                         version=0, blocks=(rpad * (K // 32) + 255) // 256, word=int(word))
+        keys = self.groups.setdefault(self.current, [])
+        if key not in keys:
+            keys.append(key)
+        if e['version'] != self.version:
+            self._refresh(keys, B.device)
+        return e['planes'].data_ptr(), e['rpad']
+
+    def _refresh(self, keys, dev):
+        stale = tuple(k for k in keys if self.entries[k]['version'] != self.version)
+        hit = self.tables.get(stale)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for (ptr, N, K, ldb, tr) in stale:
+                e = self.entries[(ptr, N, K, ldb, tr)]
+                # {W, planes, rows of W, cols of W, ldw, rpad, first block, transposed, range word}: a row-major operand B (N, K) is
+                # W itself; a k-major one is the (K, N) matrix W whose TRANSPOSE is multiplied
+                rows.append((ptr, e['planes'].data_ptr(), K if tr else N, N if tr else K, ldb, e['rpad'], first, tr, e['word']))
+                first += e['blocks']
+            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+        lib.call('rscotr_gemm_split_weights_h3', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        for k in stale:
+            self.entries[k]['version'] = self.version
+
+
 WPLANES = _WeightPlanes()
+HPLANES = _WeightPlanesH()
 
 
 class _DeferredCombine:
@@ -517,12 +587,19 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
             _ptr(bias), int(act), _ptr(aux), _ptr(pre), _ptr(resid), int(accumulate), _ptr(rowsum),
             int(rowsum_accumulate), _ptr(rowscale), int(rows_per), _ptr(kscale), int(krows_per), _ptr(out2), ws, nws,
             int(amax_a), int(amax_b), int(amax_out), _stream())
+    entry = 'rscotr_gemm_f32_r'
+    if (amax_a and amax_b and rowsum is None
+            and HPLANES.eligible(B, M, N, K, lda, ldb, a_kmajor, b_kmajor, act, pre, rowscale, kscale, nws)):
+        # B is a parameter and the interior pipelined 64 x 64 kernel takes the product: its pre-split fp16 planes ride along
+        planes, rpad = HPLANES.get(B, N, K, ldb, b_kmajor, amax_b)
+        args = args[:-1] + (planes, rpad, args[-1])
+        entry = 'rscotr_gemm_f32_rb'
     if STATE.profile is None:
-        lib.call('rscotr_gemm_f32_r', *args)
+        lib.call(entry, *args)
     else:
         with _Prof('gemm', 2 * M * N * K, gemm_kernel_name(M, N, K, a_kmajor, b_kmajor),
                    shape=(M, N, K, int(a_kmajor), int(b_kmajor))):
-            lib.call('rscotr_gemm_f32_r', *args)
+            lib.call(entry, *args)
     return out
 
 

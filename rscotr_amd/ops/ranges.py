@@ -40,6 +40,7 @@ class _Ranges:
         self.n = 0
         self.gen = 1
         self.route = {}
+        self.route2 = {}  # (... and on the kernel that takes a weight operand from pre-split planes: ops.matmul.HPLANES)
         self.check = os.environ.get('RSCOTR_RANGES_CHECK') == '1'
         self.log = os.environ.get('RSCOTR_RANGES_STATS') == '1'
         self.sites = {}

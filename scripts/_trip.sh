@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/t24
-RSCOTR_BF16X6_KMIN=32 python scripts/lab/h3_ksweep.py > gpurun_out/t24/ksweep.txt 2>&1
+mkdir -p gpurun_out/t25
+bash scripts/gpu_prof_graph.sh t25/t25 > /dev/null 2>&1
