@@ -99,7 +99,7 @@ class _WeightPlanesH:
     iteration is replayed)."""
 
     def __init__(self):
-        self.enabled = os.environ.get('RSCOTR_HPLANES', '1') != '0'
+        self.enabled = os.environ.get('RSCOTR_HPLANES', '0') != '0'
         self.version = 1
         self.entries, self.groups, self.tables = {}, {}, {}
         self.current = None
