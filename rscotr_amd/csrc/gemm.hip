@@ -628,18 +628,19 @@ struct PlaneOperandH {
   using Lay = SplitOperand<R, false, 2, SBK, true>;
   static_assert(R == 64 && SBK == 32, "one 32-byte piece per thread");
   static constexpr int WORDS = Lay::WORDS, KP = Lay::KP;
-  float4 v[2];
+  typedef float vec4 __attribute__((ext_vector_type(4)));  // (a native vector: whole-struct copies of HIP's float4 / uint4 between
+  vec4 v0, v1;                                             //  address spaces stay memcpys, and the register sets stayed in scratch)
   // P: the plane set (as const float* for the shared body), ld: its padded row count
   template <bool EDGE = false>
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int k0, int tid, int = 0, int = 0) {
-    const float4* src = reinterpret_cast<const float4*>(P) + ((long)(k0 / SBK) * ld + row0) * 8 + tid * 2;
-    v[0] = src[0];
-    v[1] = src[1];
+    const vec4* src = reinterpret_cast<const vec4*>(P) + ((long)(k0 / SBK) * ld + row0) * 8 + tid * 2;
+    v0 = src[0];
+    v1 = src[1];
   }
   __device__ __forceinline__ void store(unsigned* S, int tid, const H3Scale& = H3Scale{1.f, 2048.f}) const {
-    float4* dst = reinterpret_cast<float4*>(S + (tid >> 2) * (Lay::LDR / 2) + (tid & 3) * 8);
-    dst[0] = v[0];
-    dst[1] = v[1];
+    vec4* dst = reinterpret_cast<vec4*>(S + (tid >> 2) * (Lay::LDR / 2) + (tid & 3) * 8);
+    dst[0] = v0;
+    dst[1] = v1;
   }
   static __device__ __forceinline__ void frag(const unsigned* S, int row, int g, int ks, bf16x8 (&f)[3]) { Lay::frag(S, row, g, ks, f); }
 };

@@ -99,7 +99,7 @@ class _WeightPlanesH:
     iteration is replayed)."""
 
     def __init__(self):
-        self.enabled = os.environ.get('RSCOTR_HPLANES', '0') != '0'
+        self.enabled = os.environ.get('RSCOTR_HPLANES', '1') != '0'
         self.version = 1
         self.entries, self.groups, self.tables = {}, {}, {}
         self.current = None
@@ -151,6 +151,9 @@ class _WeightPlanesH:
                 rows.append((ptr, e['planes'].data_ptr(), K if tr else N, N if tr else K, ldb, e['rpad'], first, tr, e['word']))
                 first += e['blocks']
             hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+        if os.environ.get('RSCOTR_HPLANES_DEBUG'):
+            import sys
+            print(f'[hplanes] group {self.current}: re-split {hit[1]} of {len(keys)} sets, {hit[2]} blocks (version {self.version})', file=sys.stderr, flush=True)
         lib.call('rscotr_gemm_split_weights_h3', hit[0].data_ptr(), hit[1], hit[2], _stream())
         for k in stale:
             self.entries[k]['version'] = self.version
