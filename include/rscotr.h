@@ -98,7 +98,7 @@ int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const fl
  *   C[m,n] = epilogue( sum_k Aop[m,k] * Bop[n,k] ),  Aop[m,k] = a_kmajor ? A[k*lda+m] : A[m*lda+k],
  *   Bop[n,k] = b_kmajor ? B[k*ldb+n] : B[n*ldb+k]
  *   epilogue(v): v += bias[n] (bias may be NULL); if (pre) pre[m*ldc+n] = v;
- *                act 0 none | 1 relu | 2 gelu(erf) | 3 v *= (aux>0) | 4 v *= gelu'(aux)   [aux: (M,N), ldc];
+ *                act 0 none | 1 relu | 2 gelu(erf) | 3 v *= (aux>0) | 4 v *= gelu'(aux)   [aux: (M,N), ldc] | 5 / 6: rscotr_gemm_relu_bits_ok;
  *                v += resid[m*ldc+n] (resid may be NULL); if (accumulate) v += C[m*ldc+n].
  * F.linear(x,W,b) = (A=x,B=W,0,0); dx = (A=dy,B=W,0,1); dW = (A=dy,B=x,1,1).
  * rowsum (may be NULL; needs a_kmajor): rowsum[m] (+)= sum_k Aop[m,k] — with A = dy this is the bias
@@ -176,6 +176,17 @@ int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, in
                       float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
                       const uint32_t* amax_b, uint32_t* amax_out, void* stream);
 int rscotr_gemm_set_h3(int on);
+/* The ReLU gate of an FFN as ONE BIT per element (round 5).  mmcv FFN.forward is Linear -> ReLU -> Linear (cfg ...potsdam.py:86-93,
+ * reached from models/multi/bbox_head/transformer.py:78-131 and seg_head/pixel_decoder.py:134-146); autograd's ReLU backward reads the
+ * M x N activation again to gate dH = (dY W2) * [h > 0] — at 10880 x 2048 that is 89 MB fetched in 512-byte row segments at the end
+ * of every workgroup of the dX product, which is what bounds that launch.  act 5 (forward: relu, and the words [y > 0] leave through
+ * `pre`, M * N / 8 bytes, 8-byte aligned) and act 6 (backward: v *= bit, the words arrive through `aux`) replace act 1 / act 3 on
+ * products that run on the interior 128 x 128 split-product tiles with one k-slice — rscotr_gemm_relu_bits_ok answers 1 for those
+ * (precision mode 3, M % 128 == N % 128 == 0, K % 32 == 0, row-major A) and rscotr_gemm_f32* refuses the codes anywhere else.  The
+ * word layout (uint64 [128 x 128 tile, row-major][thread]) is private to the two kernels; the activation itself is still written
+ * (the weight gradient multiplies with it).  With acts 5 / 6: bias only — no pre-activation output, residual, accumulate, row
+ * scale, second output. */
+int rscotr_gemm_relu_bits_ok(int M, int N, int K, int lda, int ldb, int a_kmajor, int b_kmajor);
 /* The B operand of the fp16 split product from PRE-SPLIT PLANES (round 5).  In y = x W^T and dx = dy W the B tile of a
  * workgroup is a weight — it changes once per optimizer step, yet every row tile of every launch converts it again, and the
  * k loop of the 64 x 64 kernel is bound by that conversion (profiles/r5_h3_64_pmc.txt).  rscotr_gemm_split_weights_h3 writes the

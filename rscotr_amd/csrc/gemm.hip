@@ -918,6 +918,42 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       }
     return;
   }
+  if constexpr (BM == 128 && BN == 128 && !EDGE) {
+    // the ReLU gate as one bit per element (ACT_RELU_BITS / ACT_RELU_GRAD_BITS, gemm_common.h): the forward product of an FFN leaves
+    // 8 bytes per thread and tile next to its activation, and dH = (g W) * [h > 0] reads them back instead of the M x N activation
+    // (10880 x 2048: 89 MB in 512-byte row segments at the end of every workgroup — what bounds that launch).  Host-checked: no pre /
+    // residual / accumulate / row scale / second output with these codes.
+    if (p.act == ACT_RELU_BITS || p.act == ACT_RELU_GRAD_BITS) {
+      const bool fwd = p.act == ACT_RELU_BITS;
+      const long widx = ((long)(m0 / 128) * (p.N / 128) + n0 / 128) * 256 + tid;
+      unsigned long long bits = fwd ? 0ull : reinterpret_cast<const unsigned long long*>(p.aux)[widx];
+      float amx = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+          const float bv = p.bias ? p.bias[n] : 0.f;
+          float* crow = p.C + (long)(m0 + wm * (BM / 2) + i * 32 + 4 * g) * p.ldc + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int b = (i * NT + j) * 16 + r;
+            float v = acc[i][j][r] + bv;
+            if (fwd) {
+              v = fmaxf(v, 0.f);
+              bits |= (unsigned long long)(v > 0.f) << b;
+            } else {
+              v = ((bits >> b) & 1ull) ? v : 0.f;
+            }
+            crow[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = v;
+            amx = fmaxf(amx, fabsf(v));
+          }
+        }
+      if (fwd) reinterpret_cast<unsigned long long*>(p.pre)[widx] = bits;
+      amax_commit(p.amax_out, amx);
+      return;
+    }
+  }
   const bool plain = !p.pre && p.act == ACT_NONE && !p.resid && !p.accumulate && !p.rowscale && !p.C2;
   // exactly one extra tensor read by the epilogue (aux of act', residual, or old C): its 16 values per tile in one batch
   // (64 x 64 tiles only: on the 128 x 128 one-stage bf16 kernel the 16-register batch costs the third resident workgroup, and on
@@ -2129,6 +2165,20 @@ extern "C" int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int 
                        stream, amax_a, amax_b, amax_out, b_planes, b_rpad);
 }
 
+// 1 if rscotr_gemm_f32 with these arguments (16-byte aligned operands, precision mode 3) runs on the interior 128 x 128
+// split-product tiles with one k-slice: the products that may carry the ReLU gate as bits (ACT_RELU_BITS / ACT_RELU_GRAD_BITS)
+extern "C" int rscotr_gemm_relu_bits_ok(int M, int N, int K, int lda, int ldb, int a_kmajor, int b_kmajor) {
+  if (M <= 0 || N <= 0 || K <= 0 || a_kmajor || g_gemm_prec.load(std::memory_order_relaxed) != 3) return 0;
+  if (M % 128 || N % 128 || K % RSCOTR_X6_BK0) return 0;
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N;
+  p.act = ACT_RELU;
+  p.vecA = lda % 4 == 0; p.vecB = ldb % 4 == 0;
+  if (small_gemm_ok(p, a_kmajor, b_kmajor, 1)) return 0;
+  const Split6Cfg sc = choose_split6(p, a_kmajor, b_kmajor, 0);
+  return sc.bm == 128 && sc.splits == 1;
+}
+
 static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda,
                          int ldb, int ldc, int a_kmajor, int b_kmajor, const float* bias, int act,
                          const float* aux, float* pre, const float* resid, int accumulate,
@@ -2141,9 +2191,21 @@ static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N,
     return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: rowscale needs rows_per_scale > 0; kscale needs a k-major A and krows_per_scale > 0");
   if (M == 0 || N == 0) return RSCOTR_OK;
   if (!A || !B || !C) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: null pointer");
-  if (act < ACT_NONE || act > ACT_GELU_GRAD) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: unknown act %d", act);
-  if ((act == ACT_RELU_GRAD || act == ACT_GELU_GRAD) && !aux)
+  if (act < ACT_NONE || act > ACT_RELU_GRAD_BITS) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: unknown act %d", act);
+  if ((act == ACT_RELU_GRAD || act == ACT_GELU_GRAD || act == ACT_RELU_GRAD_BITS) && !aux)
     return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: act %d needs aux", act);
+  const bool relu_bits = act == ACT_RELU_BITS || act == ACT_RELU_GRAD_BITS;
+  if (relu_bits) {
+    // the one-bit ReLU gate lives in the interior 128 x 128 split-product tiles only (callers ask rscotr_gemm_relu_bits_ok first)
+    if (act == ACT_RELU_BITS ? (!pre || ((uintptr_t)pre & 7)) : ((uintptr_t)aux & 7))
+      return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: act %d moves the gate bits through %s (8-byte aligned, M * N / 8 bytes)", act,
+                  act == ACT_RELU_BITS ? "pre" : "aux");
+    if ((act == ACT_RELU_GRAD_BITS && pre) || resid || accumulate || rowscale || out2 || rowsum || kscale)
+      return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: act %d takes bias only (no pre / resid / accumulate / rowscale / out2 / rowsum)", act);
+    if (!rscotr_gemm_relu_bits_ok(M, N, K, lda, ldb, a_kmajor, b_kmajor))
+      return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: act %d on a product that does not take the interior 128 x 128 split-product tiles "
+                  "(M = %d N = %d K = %d): rscotr_gemm_relu_bits_ok", act, M, N, K);
+  }
   if (lda < (a_kmajor ? M : K) || ldb < (b_kmajor ? N : K) || ldc < N)
     return fail(RSCOTR_E_SHAPE, "rscotr_gemm_f32: leading dimension too small");
   if (rowsum && !a_kmajor) return fail(RSCOTR_E_ARG, "rscotr_gemm_f32: rowsum needs a k-major A");

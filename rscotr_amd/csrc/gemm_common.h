@@ -7,7 +7,13 @@ namespace rscotr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_GRAD = 3, ACT_GELU_GRAD = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_GRAD = 3, ACT_GELU_GRAD = 4,
+       // the ReLU pair of the wide FFN products with the gate as ONE BIT per element (interior 128 x 128 split-product tiles only;
+       // rscotr_gemm_relu_bits_ok): ACT_RELU_BITS = ACT_RELU that also leaves [y > 0] through `pre`, ACT_RELU_GRAD_BITS =
+       // ACT_RELU_GRAD that reads those words through `aux` instead of the M x N activation.  Word layout: uint64
+       // [tile (row-major over the 128 x 128 tiles)][thread of the workgroup], bit (i * 2 + j) * 16 + r = accumulator element r of the
+       // thread's 32 x 32 tile (i, j) — opaque to callers, the same in both kernels.
+       ACT_RELU_BITS = 5, ACT_RELU_GRAD_BITS = 6 };
 
 constexpr int GEMM_BK = 16;
 

@@ -155,6 +155,7 @@ def _sink(t):
 
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_GRAD, ACT_GELU_GRAD = 0, 1, 2, 3, 4
+ACT_RELU_BITS, ACT_RELU_GRAD_BITS = 5, 6  # the ReLU gate as one bit per element (include/rscotr.h: rscotr_gemm_relu_bits_ok)
 _ACT = {None: ACT_NONE, 'relu': ACT_RELU, 'gelu': ACT_GELU}
 
 

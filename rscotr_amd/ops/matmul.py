@@ -6,7 +6,8 @@ import os
 import torch
 from torch.autograd import Function
 
-from .core import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_RELU_GRAD, _ACT, _WS, _Prof, _chk, _f32c, _gemm_ws_bytes,
+from .core import (ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_RELU_BITS, ACT_RELU_GRAD, ACT_RELU_GRAD_BITS, _ACT, _WS, _Prof,
+                   _chk, _f32c, _gemm_ws_bytes,
                    _off_path, _ptr, _sink, _stream, lib)
 from .ranges import RANGES
 from .state import STATE
@@ -629,6 +630,29 @@ def colsum(X, M, N, out=None, accumulate=False):
     return out
 
 
+class _ReluBits:
+    """The ReLU gate of a wide FFN as one bit per element (include/rscotr.h, rscotr_gemm_relu_bits_ok): where BOTH the forward
+    product h = relu(x W1^T + b) and the gated backward product dH = (g W2) * [h > 0] run on the interior 128 x 128
+    split-product tiles, the forward leaves M * N / 8 bytes of gate words and the backward reads those instead of h."""
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_RELU_BITS', '1') != '0'
+        self.cache = {}
+
+    def ok(self, M, N, K, N_next):
+        if not self.enabled or not RANGES.enabled:
+            return False
+        key = (M, N, K, N_next, lib.rscotr_gemm_get_precision())
+        r = self.cache.get(key)
+        if r is None:
+            r = self.cache[key] = bool(lib.rscotr_gemm_relu_bits_ok(M, N, K, K, K, 0, 0)
+                                       and lib.rscotr_gemm_relu_bits_ok(M, N, N_next, N_next, N, 0, 1))
+        return r
+
+
+RELU_BITS = _ReluBits()
+
+
 class _MLP(Function):
     """y = L_n(act(L_{n-1}(... act(L_1(x))))) [+ identity], L_i(h) = h W_i^T + b_i: every Linear is
     one MFMA GEMM with bias/activation/residual fused in its epilogue; backward folds act' into the
@@ -665,19 +689,22 @@ class _MLP(Function):
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
             N, K = W.shape
             last = i == n - 1
-            pre = None
+            pre, a_i = None, act
             if not last and act == ACT_GELU:
                 pre = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+            elif not last and act == ACT_RELU and RELU_BITS.ok(M, N, K, ws[i + 1].shape[0]):
+                # the gate leaves the forward epilogue as bits: the gated dH product of backward reads 1 / 32 of the bytes
+                pre, a_i = torch.empty(M * N // 64, dtype=torch.int64, device=x2.device), ACT_RELU_BITS
             sc = out_scale if last else None
             if last and s2 is not None:  # out2 = y + sum_with, y itself stored without it (epilogue's second output)
                 y2 = torch.empty((M, N), dtype=torch.float32, device=x2.device)
                 h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE, resid=s2, out2=y2)
             else:
-                h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else act, pre=pre,
+                h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else a_i, pre=pre,
                          resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0)
             if not last:
                 hs.append(h)
-                auxs.append(pre if act == ACT_GELU else h)
+                auxs.append(pre if pre is not None else h)  # (GELU: the pre-activation; ReLU: the gate bits, or h itself)
         ctx.save_for_backward(*hs, *auxs, *ws)
         ctx.h_slots = [RANGES.slot_of(t) for t in hs]  # (value ranges of the saved activations: the weight gradients want them)
         ctx.out_scale, ctx.rows_per = out_scale, rows_per
@@ -748,7 +775,8 @@ class _MLP(Function):
             if skb is not None:
                 STATE.grad_sink.grad_written(skb[0])
             if i > 0:
-                g = gemm(g, W, M, K, N, N, K, 0, 1, act=gact, aux=auxs[i - 1], **scr)  # dH = (g W) * act'
+                ga = ACT_RELU_GRAD_BITS if (act == ACT_RELU and auxs[i - 1].dtype == torch.int64) else gact
+                g = gemm(g, W, M, K, N, N, K, 0, 1, act=ga, aux=auxs[i - 1], **scr)  # dH = (g W) * act'
             elif ctx.needs_input_grad[0]:
                 # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
                 dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr)

@@ -12,9 +12,9 @@ for envs in "$@"; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    fam = d.get('roofline_gemm_family', {})
+    fam = d.get('roofline_gemm_family') or {}
     print(f"[{sys.argv[2] or 'defaults'}] {d['ms_per_step']:.2f} ms/step  per-task {d.get('per_task_ms')}  "
-          f"split share {fam.get('split_product_flop_share')}  dominant {d.get('roofline', {}).get('kernel')} frac {d.get('roofline', {}).get('frac')}")
+          f"split share {fam.get('split_product_flop_share')}  dominant {(d.get('roofline') or {}).get('kernel')} frac {(d.get('roofline') or {}).get('frac')}")
 except Exception as e:
     print(f"[{sys.argv[2]}] FAILED {e}"); print(open(sys.argv[1].replace('.json', '.err')).read()[-1500:])
 PY
