@@ -352,6 +352,13 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
   // wavefront configurations only: the 128-row tiles keep their registers)
   const bool one_extra = MT == 1 && NT == 1 && !p.C2 &&
                          ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
+  // an activation (and / or the stored pre-activation) but no tensor to read: epilogue_noload16
+#ifdef RSCOTR_NO_NOLOAD  // (A/B builds: scripts/build_variant.sh)
+  const bool noload = false;
+#else
+  const bool noload = !plain && (p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_GELU) && !p.resid && !p.accumulate &&
+                      !p.rowscale && !p.C2;
+#endif
   float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -364,6 +371,8 @@ __device__ __forceinline__ void gemm_f32_body(GemmParams& p, const int bx, const
       float* crow = p.C + (long)mb * p.ldc + n;
       if (one_extra) {
         epilogue_tile16<EDGE>(p, acc[i][j], bv, mb, n, amx);
+      } else if (noload) {
+        epilogue_noload16<EDGE>(p, acc[i][j], bv, mb, n, amx);
       } else if (plain) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -964,6 +973,13 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
   // for them, and 130 + 32 registers leave the scheduler no slack under the three-workgroup cap.)
   const bool one_extra = BM == 64 && !p.C2 &&
                          ((p.act == ACT_RELU_GRAD || p.act == ACT_GELU_GRAD) ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) == 1;
+  // an activation (and / or the stored pre-activation) but no tensor to read: epilogue_noload16
+#ifdef RSCOTR_NO_NOLOAD  // (A/B builds: scripts/build_variant.sh)
+  const bool noload = false;
+#else
+  const bool noload = !plain && (p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_GELU) && !p.resid && !p.accumulate &&
+                      !p.rowscale && !p.C2;
+#endif
   float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -977,6 +993,8 @@ __device__ __forceinline__ void gemm_bf16x6_body(GemmParams& p, const int bx, co
       if (one_extra) {
         epilogue_tile16<EDGE>(p, acc[i][j], bv, mb, n, amx);
         __builtin_amdgcn_sched_barrier(0);
+      } else if (noload) {
+        epilogue_noload16<EDGE>(p, acc[i][j], bv, mb, n, amx);
       } else if (plain) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -1948,9 +1966,12 @@ static bool small_gemm_ok(const GemmParams& p, int a_kmajor, int b_kmajor, long 
   static const int on = getenv("RSCOTR_GEMM_SMALL") ? atoi(getenv("RSCOTR_GEMM_SMALL")) : 1;
   static const long max_tiles = getenv("RSCOTR_GEMM_SMALL_TILES") ? atol(getenv("RSCOTR_GEMM_SMALL_TILES")) : 512;
   static const int max_k = getenv("RSCOTR_GEMM_SMALL_K") ? atoi(getenv("RSCOTR_GEMM_SMALL_K")) : 512;
-  if (!on || p.K % 8 || p.K < 32 || p.K > max_k || p.rowscale || p.kscale) return false;
+  if (!on || p.K % 8 || p.K < 32 || p.rowscale || p.kscale) return false;
   if ((!a_kmajor && !p.vecA) || (!b_kmajor && !p.vecB)) return false;
   const long tiles = (long)((p.M + 31) / 32) * ((p.N + 31) / 32);
+  // a handful of output tiles with a longer reduction (the classifier's fc: 2 x 45 x 768) ran as ONE workgroup of the tiled
+  // kernel walking 48 dependent k-tiles (26 us); here 16 wavefronts split K
+  if (p.K > max_k) return p.K <= 4096 && tiles * nbatch <= 8;
   return tiles * nbatch <= max_tiles;
 }
 

@@ -285,6 +285,27 @@ __device__ __forceinline__ void epilogue_tile16(const GemmParams& p, const f32x1
   }
 }
 
+// One 32 x 32 accumulator tile of a lane whose epilogue reads NO tensor (bias + ReLU / GELU, optionally the pre-activation
+// stored as well: the first Linear of an FFN / MLP): nothing to batch, so none of epilogue_rows4's staging and scheduling
+// barriers — the encoder's 10880 x 2048 x 256 FFN product ran 82-92 us through epilogue_rows4 and 70-74 us through a loop like
+// this one (profiles/r5_relu_bits_ab.txt).
+template <bool EDGE>
+__device__ __forceinline__ void epilogue_noload16(const GemmParams& p, const f32x16& acc, float bv, int m0, int n, float& amx) {
+  const long base = (long)m0 * p.ldc + n;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int dm = (r & 3) + 8 * (r >> 2);
+    if (EDGE && m0 + dm >= p.M) continue;
+    const long o = base + (long)dm * p.ldc;
+    float v = acc[r] + bv;
+    if (p.pre) p.pre[o] = v;
+    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == ACT_GELU) v = gelu_f(v);
+    p.C[o] = v;
+    amx = fmaxf(amx, fabsf(v));
+  }
+}
+
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, used for speed
 // only); give each XCD a contiguous run of tiles in row-major (tile_m, tile_n) order so that the
 // A row-panel a run shares is fetched into ONE private L2 (bijective for any tile count).
