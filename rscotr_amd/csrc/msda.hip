@@ -79,7 +79,32 @@ __device__ __forceinline__ float4 ld4(const float* p, bool ok) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int D, int P>
+// One sample of a (query, head) as the gather loop wants it: the bilinear set-up is done ONCE per sample by the thread that
+// stages it — the G = D / 4 lanes that share a (query, head) used to repeat it, ~50 of the ~85 instructions a lane issued per
+// sample, and the launch was bound by instruction issue (22 us of issue on the whole chip for the 1.39 M samples of an
+// encoder call), not by the L2.  Same arithmetic on the same inputs: results are bit-identical.
+struct alignas(16) MsdaSample {
+  float aw, w1, w2, w3;  // attention weight; bilinear weights of the four taps
+  float w4;
+  int e1;                // element offset of the top-left tap's channel row from the (image, head) base (level start included)
+  int ok;                // bit t: tap t lies inside the map
+  int pad;
+};
+
+// the backward sample kernel's record: the fractional weights themselves (its derivative terms want them)
+struct alignas(16) MsdaSampleB {
+  float aw, hh, hw, lh;
+  float lw;
+  int e1;   // element offset of the top-left tap's channel row from the LEVEL's first token
+  int ok;   // bits 0-3: tap inside the map; bit 4: the sample counts (inside (-1, size) on both axes)
+  int pad;
+};
+
+#ifndef RSCOTR_MSDA_FWD_DEDUP
+#define RSCOTR_MSDA_FWD_DEDUP 1  // (0: the per-lane set-up of rounds 1-4, for A/B builds)
+#endif
+
+template <int D, int P, bool DEDUP = true>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
@@ -90,8 +115,6 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   constexpr int QB = 4 * QW;      // queries per workgroup
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
-  float* s_loc = smem;                // [QB][LP*2]
-  float* s_attn = smem + QB * LP * 2;  // [QB][LP]
 
   const int bid = blockIdx.x;
   const int h = bid % H;
@@ -100,6 +123,72 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   const int b = t / ntiles;
   const int q0 = tile * QB;
   const int tid = threadIdx.x;
+  const int tok_stride = H * D;
+  if constexpr (DEDUP) {
+  MsdaSample* recs = reinterpret_cast<MsdaSample*>(smem);  // [QB][LP]
+  // stage the tile's samples: locations + weights read in coalesced 128-byte rows, set up once, left as records
+  for (int i = tid; i < QB * LP; i += 256) {
+    const int r = i / LP, s_ = i - r * LP;
+    const int q = q0 + r;
+    MsdaSample m;
+    m.aw = m.w1 = m.w2 = m.w3 = m.w4 = 0.f;
+    m.e1 = m.ok = m.pad = 0;
+    if (q < Nq) {
+      const long e = (((long)b * Nq + q) * H + h) * LP + s_;
+      const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
+      const int l = s_ / P;
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      const Bilinear g = bilinear_setup(xy.x, xy.y, Hl, Wl);
+      m.aw = attn[e];
+      m.w1 = g.hh * g.hw; m.w2 = g.hh * g.lw; m.w3 = g.lh * g.hw; m.w4 = g.lh * g.lw;
+      m.e1 = ((int)lsi[l] + g.i1) * tok_stride;
+      m.ok = (g.ok1 ? 1 : 0) | (g.ok2 ? 2 : 0) | (g.ok3 ? 4 : 0) | (g.ok4 ? 8 : 0);
+    }
+    recs[i] = m;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int r = w * QW + lane / G;
+  const int sub = lane % G;
+  const int q = q0 + r;
+  if (q >= Nq) return;
+
+  const float* vb = value + ((long)b * Nk * H + h) * D + sub * 4;  // + element offset of a token's channel row
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const MsdaSample* mine = recs + r * LP;
+  for (int l = 0; l < L; ++l) {
+    const int rowstep = (int)shapes[2 * l + 1] * tok_stride;
+    float4 ra[P], rb[P];
+    float4 v1[P], v2[P], v3[P], v4[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float4* rp = reinterpret_cast<const float4*>(mine + l * P + p);
+      ra[p] = rp[0];
+      rb[p] = rp[1];
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int ok = __float_as_int(rb[p].z);
+      const float* t1 = vb + __float_as_int(rb[p].y);
+      v1[p] = ld4(t1, ok & 1);
+      v2[p] = ld4(t1 + tok_stride, ok & 2);
+      v3[p] = ld4(t1 + rowstep, ok & 4);
+      v4[p] = ld4(t1 + rowstep + tok_stride, ok & 8);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float aw = ra[p].x, w1 = ra[p].y, w2 = ra[p].z, w3 = ra[p].w, w4 = rb[p].x;
+      acc.x += aw * (w1 * v1[p].x + w2 * v2[p].x + w3 * v3[p].x + w4 * v4[p].x);
+      acc.y += aw * (w1 * v1[p].y + w2 * v2[p].y + w3 * v3[p].y + w4 * v4[p].y);
+      acc.z += aw * (w1 * v1[p].z + w2 * v2[p].z + w3 * v3[p].z + w4 * v4[p].z);
+      acc.w += aw * (w1 * v1[p].w + w2 * v2[p].w + w3 * v3[p].w + w4 * v4[p].w);
+    }
+  }
+  *reinterpret_cast<float4*>(out + (((long)b * Nq + q) * H + h) * D + sub * 4) = acc;
+  } else {  // the per-lane set-up (records of a tile past 48 KB of LDS, or element offsets past 2^31)
+  float* s_loc = smem;                // [QB][LP*2]
+  float* s_attn = smem + QB * LP * 2;  // [QB][LP]
 
   // stage sampling locations + attention weights of the tile (coalesced 128-byte rows)
   for (int i = tid; i < QB * LP * 2; i += 256) {
@@ -121,7 +210,6 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   if (q >= Nq) return;
 
   const float* vb = value + ((long)b * Nk * H + h) * D + sub * 4;  // + token*H*D
-  const int tok_stride = H * D;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* my_loc = s_loc + r * LP * 2;
   const float* my_attn = s_attn + r * LP;
@@ -156,6 +244,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
     }
   }
   *reinterpret_cast<float4*>(out + (((long)b * Nq + q) * H + h) * D + sub * 4) = acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -231,14 +320,14 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
     for (int l = 0; l < L; ++l) NE += ((int)shapes[2 * l] + 1) * ((int)shapes[2 * l + 1] + 1);
     scatter = NE > bins_cap;
   }
-  float* s_loc = smem;                      // [QB][LP*2]  in: locations, out: grad_loc
-  float* s_attn = smem + QB * LP * 2;        // [QB][LP]    in: weights
-  float* s_gattn = smem + QB * LP * 3;       // [QB][LP]    out: grad_attn
-  float* s_gloc = smem + QB * LP * 4;        // [QB][LP*2]  out: grad_loc
-  // TILE (tile-accumulation backward): one 4-byte bin word per sample (bin of the top-left tap on the extended grid | -1),
-  // laid out (b h, level, q, p), staged [L][QB][P] for a coalesced store (the launch then brings QB * LP * 4 more bytes of LDS)
-  int* s_bin = reinterpret_cast<int*>(smem + QB * LP * 6);
-  unsigned* s_mask = reinterpret_cast<unsigned*>(smem + QB * LP * 7);  // [L][2] (TILE only)
+  // one record per sample (the set-up is done ONCE, by the thread that stages the sample — as in the forward kernel: the G lanes
+  // of a (query, head) used to repeat it inside the gather loop), the gradients gathered for a coalesced store, and (TILE) one
+  // 4-byte bin word per sample (bin of the top-left tap on the extended grid | -1), staged [L][QB][P]
+  MsdaSampleB* recs = reinterpret_cast<MsdaSampleB*>(smem);  // [QB][LP]
+  float* s_gattn = smem + QB * LP * 8;       // [QB][LP]    out: grad_attn
+  float* s_gloc = smem + QB * LP * 9;        // [QB][LP*2]  out: grad_loc
+  int* s_bin = reinterpret_cast<int*>(smem + QB * LP * 11);
+  unsigned* s_mask = reinterpret_cast<unsigned*>(smem + QB * LP * 12);  // [L][2] (TILE only)
   if (TILE && threadIdx.x < 2 * L) s_mask[threadIdx.x] = 0u;  // (ordered before the atomics by the barrier below)
 
   const int bid = blockIdx.x;
@@ -248,34 +337,37 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
   const int b = t / ntiles;
   const int q0 = tile * QB;
   const int tid = threadIdx.x;
+  const int tok_stride = H * D;
+  if (TILE) __syncthreads();
 
-  for (int i = tid; i < QB * LP * 2; i += 256) {
-    const int r = i / (LP * 2), c = i - r * (LP * 2);
-    const int q = q0 + r;
-    s_loc[i] = (q < Nq) ? loc[(((long)b * Nq + q) * H + h) * (LP * 2) + c] : 0.f;
-  }
   for (int i = tid; i < QB * LP; i += 256) {
-    const int r = i / LP, c = i - r * LP;
-    const int q = q0 + r;
-    s_attn[i] = (q < Nq) ? attn[(((long)b * Nq + q) * H + h) * LP + c] : 0.f;
-  }
-  __syncthreads();
-
-  if (TILE) {
-    // bin word of every sample and the tile it falls in, in a pass of its own over the staged locations (two samples per
-    // thread): inside the gather loop below the same code (round 2: plus a 16-byte record per sample) pushed the kernel over
-    // the 128-register cap it runs under — 32 bytes of scratch per lane, +17 us per launch
-    for (int i = tid; i < QB * LP; i += 256) {
-      const int rr = i / LP, c = i - rr * LP, l = c / P, pp = c - l * P;
-      const Bilinear gg = bilinear_setup(s_loc[2 * i], s_loc[2 * i + 1], (int)shapes[2 * l], (int)shapes[2 * l + 1]);
-      const bool in = gg.in && q0 + rr < Nq;
-      s_bin[(l * QB + rr) * P + pp] = in ? ((gg.h_low + 1) << 16) | (gg.w_low + 1) : -1;
+    const int rr = i / LP, c = i - rr * LP, l = c / P, pp = c - l * P;
+    const int q = q0 + rr;
+    MsdaSampleB m;
+    m.aw = m.hh = m.hw = m.lh = m.lw = 0.f;
+    m.e1 = m.ok = m.pad = 0;
+    bool in = false;
+    int h_low = 0, w_low = 0;
+    if (q < Nq) {
+      const long e = (((long)b * Nq + q) * H + h) * LP + c;
+      const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
+      const Bilinear gg = bilinear_setup(xy.x, xy.y, (int)shapes[2 * l], (int)shapes[2 * l + 1]);
+      m.aw = attn[e];
+      m.hh = gg.hh; m.hw = gg.hw; m.lh = gg.lh; m.lw = gg.lw;
+      m.e1 = gg.i1 * tok_stride;  // (from the level's first token: grad_value is addressed with the same offset)
+      m.ok = (gg.ok1 ? 1 : 0) | (gg.ok2 ? 2 : 0) | (gg.ok3 ? 4 : 0) | (gg.ok4 ? 8 : 0) | (gg.in ? 16 : 0);
+      in = gg.in; h_low = gg.h_low; w_low = gg.w_low;
+    }
+    recs[i] = m;
+    if (TILE) {
+      s_bin[(l * QB + rr) * P + pp] = in ? ((h_low + 1) << 16) | (w_low + 1) : -1;
       if (in) {  // (+ 0.5: the quotient is at least 1 / 32 away from an integer, far above the rounding of the product)
-        const int t = (int)(((float)(gg.h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(gg.w_low + 1) + 0.5f) * MG.itx[l]);
-        atomicOr(&s_mask[2 * l + ((t >> 5) & 1)], 1u << (t & 31));
+        const int tt = (int)(((float)(h_low + 1) + 0.5f) * MG.ity[l]) * MG.ntx[l] + (int)(((float)(w_low + 1) + 0.5f) * MG.itx[l]);
+        atomicOr(&s_mask[2 * l + ((tt >> 5) & 1)], 1u << (tt & 31));
       }
     }
   }
+  __syncthreads();
 
   const int lane = tid & 63, w = tid >> 6;
   const int r = w * QW + lane / G;
@@ -286,34 +378,35 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
   const long voff = ((long)b * Nk * H + h) * D + sub * 4;
   const float* vb = value + voff;
   float* gvb = grad_value + voff;
-  const int tok_stride = H * D;
   const float4 go = qok ? *reinterpret_cast<const float4*>(
                               grad_out + (((long)b * Nq + q) * H + h) * D + sub * 4)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* my_loc = s_loc + r * LP * 2;
-  const float* my_attn = s_attn + r * LP;
+  const MsdaSampleB* mine = recs + r * LP;  // (rows past Nq hold zero records: nothing is loaded, nothing counts)
 
   for (int l = 0; l < L; ++l) {
     const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
     const long lofs = (long)lsi[l] * tok_stride;
     const float* vl = vb + lofs;
     float* gvl = gvb + lofs;
-    Bilinear g[P];
+    const int rowstep = Wl * tok_stride;
+    MsdaSampleB g[P];
     float aw[P];
     float4 v1[P], v2[P], v3[P], v4[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float2 xy = *reinterpret_cast<const float2*>(my_loc + (l * P + p) * 2);
-      aw[p] = my_attn[l * P + p];
-      g[p] = bilinear_setup(xy.x, xy.y, Hl, Wl);
-      if (!qok) g[p].in = g[p].ok1 = g[p].ok2 = g[p].ok3 = g[p].ok4 = false;
+      const float4* rp = reinterpret_cast<const float4*>(mine + l * P + p);
+      const float4 ra = rp[0], rb = rp[1];
+      g[p].aw = ra.x; g[p].hh = ra.y; g[p].hw = ra.z; g[p].lh = ra.w;
+      g[p].lw = rb.x; g[p].e1 = __float_as_int(rb.y); g[p].ok = __float_as_int(rb.z);
+      aw[p] = ra.x;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      v1[p] = ld4(vl + (long)g[p].i1 * tok_stride, g[p].ok1);
-      v2[p] = ld4(vl + (long)g[p].i2 * tok_stride, g[p].ok2);
-      v3[p] = ld4(vl + (long)g[p].i3 * tok_stride, g[p].ok3);
-      v4[p] = ld4(vl + (long)g[p].i4 * tok_stride, g[p].ok4);
+      const float* t1 = vl + g[p].e1;
+      v1[p] = ld4(t1, g[p].ok & 1);
+      v2[p] = ld4(t1 + tok_stride, g[p].ok & 2);
+      v3[p] = ld4(t1 + rowstep, g[p].ok & 4);
+      v4[p] = ld4(t1 + rowstep + tok_stride, g[p].ok & 8);
     }
     float part[3 * P];
     unsigned inmask = 0u;
@@ -323,10 +416,11 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
       const float4 top = scale4(go, aw[p]);  // grad_out * attention weight
       if (scatter) {
-        atomic_add4(gvl + (long)g[p].i1 * tok_stride, scale4(top, w1), g[p].ok1);
-        atomic_add4(gvl + (long)g[p].i2 * tok_stride, scale4(top, w2), g[p].ok2);
-        atomic_add4(gvl + (long)g[p].i3 * tok_stride, scale4(top, w3), g[p].ok3);
-        atomic_add4(gvl + (long)g[p].i4 * tok_stride, scale4(top, w4), g[p].ok4);
+        float* t1 = gvl + g[p].e1;
+        atomic_add4(t1, scale4(top, w1), g[p].ok & 1);
+        atomic_add4(t1 + tok_stride, scale4(top, w2), g[p].ok & 2);
+        atomic_add4(t1 + rowstep, scale4(top, w3), g[p].ok & 4);
+        atomic_add4(t1 + rowstep + tok_stride, scale4(top, w4), g[p].ok & 8);
       }
       // d(sample)/d(h_im), d(sample)/d(w_im), and the sample itself, dotted with the grads
       const float d1 = dot4(top, v1[p]), d2 = dot4(top, v2[p]);
@@ -335,7 +429,7 @@ __global__ __launch_bounds__(256, P <= 4 && SCATTER == 0 ? 4 : 2) void msda_bwd_
       part[3 * p + 0] = -hh * d1 + hh * d2 - lh * d3 + lh * d4;
       part[3 * p + 1] = -hw * d1 - lw * d2 + hw * d3 + lw * d4;
       part[3 * p + 2] = w1 * dot4(go, v1[p]) + w2 * dot4(go, v2[p]) + w3 * dot4(go, v3[p]) + w4 * dot4(go, v4[p]);
-      if (g[p].in) inmask |= 1u << p;
+      if (g[p].ok & 16) inmask |= 1u << p;
     }
     // the 3 P sums of the level over the G lanes of the group as a REDUCE-SCATTER: at every butterfly step a lane keeps one
     // half of the values and sends the other (12 values on 8 lanes: 6 + 3 + 2 = 11 exchanges against 36 for one all-reduce
@@ -1282,13 +1376,17 @@ __global__ __launch_bounds__(256) void msda_tile_combine_kernel(const float* __r
   amax_commit(amax_out, amx);  // (every lane of the wavefront, also those past the last token)
 }
 
+// dynamic LDS of msda_bwd_kernel: per sample a 32-byte record, grad_attn, grad_loc (2), one bin word; + the level masks
+static size_t msda_bwd_lds(int QB, int L, int P) { return (size_t)QB * L * P * 12 * sizeof(float) + 64; }
+
 template <int D, int P>
 static void launch_bwd_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                              const float* go, float* gv, float* gl, float* ga, int B, int Nk, int Nq, int H, int L,
                              const MsdaTiles& T, char* ws, hipStream_t s, unsigned* amax_gv) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 7 * sizeof(float) + 64;  // + bin words staged for a coalesced store, + masks
+  const size_t shm = msda_bwd_lds(QB, L, P);  // records + gathered gradients + bin words staged for a coalesced store + masks
+  if (shm > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_kernel<D, P, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   const int BH = B * H;
   const MsdaTileWs W = msda_tile_ws(T, BH, Nq, P, D);
   int* binw = reinterpret_cast<int*>(ws + W.binw);
@@ -1334,8 +1432,14 @@ static void launch_fwd(const float* value, const int64_t* shapes, const int64_t*
                        int H, int L, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
+  const size_t shm_rec = (size_t)QB * L * P * sizeof(MsdaSample);
+  if (RSCOTR_MSDA_FWD_DEDUP && shm_rec <= 48 * 1024 && (long)(Nk + 1) * H * D < (1l << 31)) {
+    msda_fwd_kernel<D, P, true><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm_rec, s>>>(
+        value, shapes, lsi, loc, attn, out, Nk, Nq, H, L, ntiles);
+    return;
+  }
   const size_t shm = (size_t)QB * L * P * 3 * sizeof(float);
-  msda_fwd_kernel<D, P><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
+  msda_fwd_kernel<D, P, false><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
       value, shapes, lsi, loc, attn, out, Nk, Nq, H, L, ntiles);
 }
 
@@ -1345,7 +1449,7 @@ static void launch_bwd(const float* value, const int64_t* shapes, const int64_t*
                        float* ga, int B, int Nk, int Nq, int H, int L, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
+  const size_t shm = msda_bwd_lds(QB, L, P);
   msda_bwd_kernel<D, P, 1><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm, s>>>(
       value, shapes, lsi, loc, attn, go, gv, gl, ga, nullptr, nullptr, MsdaMaskGeom(), Nk, Nq, H, L, ntiles, 0);
 }
@@ -1357,7 +1461,7 @@ static void launch_bwd_sorted(const float* value, const int64_t* shapes, const i
                               float* ga, int B, int Nk, int Nq, int H, int L, int* ws, hipStream_t s) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
-  const size_t shm = (size_t)QB * L * P * 6 * sizeof(float);
+  const size_t shm = msda_bwd_lds(QB, L, P);
   const int BH = B * H;
   const MsdaWs W = msda_ws_layout(BH, Nk, Nq, L, P);
   const long S = (long)Nq * L * P;
