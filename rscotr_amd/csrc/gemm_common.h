@@ -264,6 +264,23 @@ __device__ __forceinline__ void epilogue_tile16(const GemmParams& p, const f32x1
     const int dm = (r & 3) + 8 * (r >> 2);
     e[r] = (!EDGE || m0 + dm < p.M) ? ep[base + (long)dm * p.ldc] : 0.f;
   }
+#ifndef RSCOTR_NO_UNSWITCH  // (A/B builds: scripts/build_variant.sh)
+  // the two forms the step's large products carry, without the per-element tests of the general loop below (the compiler keeps
+  // them inside the unrolled body: ~15 scalar instructions per element): a residual / old C on a plain product, and ReLU'
+  if (!p.pre && !p.rowscale && (p.act == ACT_NONE || p.act == ACT_RELU_GRAD)) {
+    const bool gate = p.act == ACT_RELU_GRAD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (EDGE && m0 + dm >= p.M) continue;
+      float v = acc[r] + bv;
+      v = gate ? (e[r] > 0.f ? v : 0.f) : v + e[r];
+      p.C[base + (long)dm * p.ldc] = v;
+      amx = fmaxf(amx, fabsf(v));
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int dm = (r & 3) + 8 * (r >> 2);
