@@ -1430,7 +1430,8 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
     const int bm = 128;
     const long tiles = t128;
     if (tiles > 2048) return c;
-    long sp = std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, p.K / 256));
+    static const long dw_wgs = getenv("RSCOTR_BF16X6_DW_WGS") ? atol(getenv("RSCOTR_BF16X6_DW_WGS")) : 512;  // workgroups a k-sliced weight gradient aims at
+    long sp = std::max<long>(1, std::min<long>((dw_wgs + tiles - 1) / tiles, p.K / 256));
     const int64_t per = ((int64_t)p.M * p.N + p.M) * 4;
     if (sp > 1) sp = std::min<long>(sp, ws_bytes / per);
     if (sp < 1) sp = 1;
