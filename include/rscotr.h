@@ -86,6 +86,16 @@ int rscotr_msda_prep_fwd(const float* off, const float* logit, const float* ref,
 int rscotr_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn, const float* ref,
                          const float* norm, float* grad_off, float* grad_logit, int B, int Nq, int H, int L, int P,
                          int refdim, int ld_off, int ld_logit, int ref_levels, uint32_t* amax_out, void* stream);
+/* The prologue INSIDE the sampling kernel (round 5).  rscotr_msda_fwd_prep = rscotr_msda_prep_fwd + rscotr_msda_fwd in one launch: the
+ * threads that stage a tile's samples compute the softmax over the 16 logits of a (query, head) and the sampling locations
+ * themselves (the prologue kernel's arithmetic: same loc / attn, bit for bit) and still leave loc / attn in global memory for
+ * the backward — one launch less and no second pass over the 12 bytes per sample.  Geometries rscotr_msda_fused_ok answers 1 for
+ * (L * P == 16 — the configs' 4 levels x 4 points —, D in {16, 32, 64}); elsewhere the entry fails and callers use the pair. */
+int rscotr_msda_fused_ok(int Nk, int H, int D, int L, int P);
+int rscotr_msda_fwd_prep(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const float* off, const float* logit, int ld_off, int ld_logit, const float* ref,
+                         const float* norm, int refdim, int ref_levels, float* loc, float* attn, float* out, int B,
+                         int Nk, int Nq, int H, int D, int L, int P, void* stream);
 
 /* ---- fp32 GEMM on the matrix cores, fused epilogue ----------------------------------------------
  * Replaces torch F.linear / nn.Linear and 1x1 / patchify nn.Conv2d (and the two backward

@@ -168,15 +168,7 @@ __global__ __launch_bounds__(256) void msda_prep_fwd_kernel(const float* __restr
     const int l = s / P;
     const float* r = ref + (bq * ref_levels + (ref_levels > 1 ? l : 0)) * refdim;
     const float2 o = *reinterpret_cast<const float2*>(off + bq * ld_off + (h * LP + s) * 2);
-    float2 out;
-    if (refdim == 2) {
-      out.x = r[0] + o.x / norm[2 * l];
-      out.y = r[1] + o.y / norm[2 * l + 1];
-    } else {
-      out.x = r[0] + o.x / (float)P * r[2] * 0.5f;
-      out.y = r[1] + o.y / (float)P * r[3] * 0.5f;
-    }
-    reinterpret_cast<float2*>(loc)[e] = out;
+    reinterpret_cast<float2*>(loc)[e] = msda_location(r, o, norm, l, P, refdim);
   }
   const float m = group_max<G>(lg);
   const float ex = in ? expf(lg - m) : 0.f;

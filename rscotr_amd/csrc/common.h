@@ -111,6 +111,22 @@ __device__ __forceinline__ void amax_commit(unsigned* slot, float amx) {
   }
 }
 
+// Sampling location of mmcv MultiScaleDeformableAttention.forward from a reference point and a raw offset (ONE definition for the
+// stand-alone prologue kernel, csrc/attn.hip, and the forward kernel that does the prologue itself, csrc/msda.hip):
+//   2-d reference points: ref_xy + off / (W_l, H_l);   4-d: ref_xy + off / P * ref_wh * 0.5
+__device__ __forceinline__ float2 msda_location(const float* __restrict__ r, float2 o, const float* __restrict__ norm, int l, int P,
+                                                int refdim) {
+  float2 out;
+  if (refdim == 2) {
+    out.x = r[0] + o.x / norm[2 * l];
+    out.y = r[1] + o.y / norm[2 * l + 1];
+  } else {
+    out.x = r[0] + o.x / (float)P * r[2] * 0.5f;
+    out.y = r[1] + o.y / (float)P * r[3] * 0.5f;
+  }
+  return out;
+}
+
 __device__ __forceinline__ float amax4(float a, const float4& v) {
   return fmaxf(fmaxf(a, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }

@@ -104,12 +104,26 @@ struct alignas(16) MsdaSampleB {
 #define RSCOTR_MSDA_FWD_DEDUP 1  // (0: the per-lane set-up of rounds 1-4, for A/B builds)
 #endif
 
-template <int D, int P, bool DEDUP = true>
+// PREP (rscotr_msda_fwd_prep; L * P == 16): the kernel does the element-wise prologue of the attention module itself — the softmax
+// over the 16 logits of a (query, head) and the location arithmetic, by the 16 consecutive threads that stage its samples — and
+// leaves loc / attn in global memory for the backward, instead of reading what msda_prep_fwd_kernel wrote a launch earlier.
+struct MsdaPrepIn {
+  const float* off;    // raw sampling offsets, row (b, q) at (b Nq + q) ld_off, head h at + h L P 2
+  const float* logit;  // raw attention logits, row (b, q) at (b Nq + q) ld_logit, head h at + h L P
+  const float* ref;    // reference points (B, Nq, ref_levels, refdim)
+  const float* norm;   // (L, 2) = (W_l, H_l) for 2-d reference points
+  float* loc;          // out (B, Nq, H, L, P, 2)
+  float* attn;         // out (B, Nq, H, L, P)
+  int ld_off, ld_logit, refdim, ref_levels;
+};
+
+template <int D, int P, bool DEDUP = true, bool PREP = false>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attn, float* __restrict__ out, int Nk, int Nq, int H, int L,
-    int ntiles) {
+    int ntiles, MsdaPrepIn pi = MsdaPrepIn{}) {
+  static_assert(!PREP || DEDUP, "the prologue rides the record staging");
   constexpr int G = D / 4;        // lanes per (query, head)
   constexpr int QW = kWave / G;   // queries per wavefront
   constexpr int QB = 4 * QW;      // queries per workgroup
@@ -133,13 +147,32 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
     MsdaSample m;
     m.aw = m.w1 = m.w2 = m.w3 = m.w4 = 0.f;
     m.e1 = m.ok = m.pad = 0;
+    float2 xy = make_float2(0.f, 0.f);
+    float aw_ = 0.f;
+    const long e = (((long)b * Nq + q) * H + h) * LP + s_;
+    const int l = s_ / P;
+    if constexpr (PREP) {  // (msda_prep_fwd_kernel<16>'s arithmetic: whole 16-lane groups stay together for the shuffles)
+      const bool in = q < Nq;
+      const long bq = (long)b * Nq + (in ? q : 0);
+      const float lg = in ? pi.logit[bq * pi.ld_logit + h * LP + s_] : -3.0e38f;
+      if (in) {
+        const float* rp = pi.ref + (bq * pi.ref_levels + (pi.ref_levels > 1 ? l : 0)) * pi.refdim;
+        const float2 o = *reinterpret_cast<const float2*>(pi.off + bq * pi.ld_off + (h * LP + s_) * 2);
+        xy = msda_location(rp, o, pi.norm, l, P, pi.refdim);
+        reinterpret_cast<float2*>(pi.loc)[e] = xy;
+      }
+      const float mx = group_max<16>(lg);
+      const float ex = in ? expf(lg - mx) : 0.f;
+      const float sum = group_sum<16>(ex);
+      if (in) { aw_ = ex / sum; pi.attn[e] = aw_; }
+    } else if (q < Nq) {
+      xy = *reinterpret_cast<const float2*>(loc + e * 2);
+      aw_ = attn[e];
+    }
     if (q < Nq) {
-      const long e = (((long)b * Nq + q) * H + h) * LP + s_;
-      const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
-      const int l = s_ / P;
       const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
       const Bilinear g = bilinear_setup(xy.x, xy.y, Hl, Wl);
-      m.aw = attn[e];
+      m.aw = aw_;
       m.w1 = g.hh * g.hw; m.w2 = g.hh * g.lw; m.w3 = g.lh * g.hw; m.w4 = g.lh * g.lw;
       m.e1 = ((int)lsi[l] + g.i1) * tok_stride;
       m.ok = (g.ok1 ? 1 : 0) | (g.ok2 ? 2 : 0) | (g.ok3 ? 4 : 0) | (g.ok4 ? 8 : 0);
@@ -1429,10 +1462,15 @@ static int check_shape(const char* fn, int B, int Nk, int Nq, int H, int D, int 
 template <int D, int P>
 static void launch_fwd(const float* value, const int64_t* shapes, const int64_t* lsi,
                        const float* loc, const float* attn, float* out, int B, int Nk, int Nq,
-                       int H, int L, hipStream_t s) {
+                       int H, int L, hipStream_t s, const MsdaPrepIn* prep = nullptr) {
   constexpr int QB = 4 * (kWave / (D / 4));
   const int ntiles = (Nq + QB - 1) / QB;
   const size_t shm_rec = (size_t)QB * L * P * sizeof(MsdaSample);
+  if (prep) {  // (rscotr_msda_fwd_prep checked rscotr_msda_fused_ok)
+    msda_fwd_kernel<D, P, true, true><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm_rec, s>>>(
+        value, shapes, lsi, nullptr, nullptr, out, Nk, Nq, H, L, ntiles, *prep);
+    return;
+  }
   if (RSCOTR_MSDA_FWD_DEDUP && shm_rec <= 48 * 1024 && (long)(Nk + 1) * H * D < (1l << 31)) {
     msda_fwd_kernel<D, P, true><<<dim3((unsigned)((long)B * ntiles * H)), dim3(256), shm_rec, s>>>(
         value, shapes, lsi, loc, attn, out, Nk, Nq, H, L, ntiles);
@@ -1538,6 +1576,40 @@ extern "C" int rscotr_msda_fwd(const float* value, const int64_t* spatial_shapes
   RSCOTR_DISPATCH_DP(D, P, CALL)
 #undef CALL
   return check_launch("rscotr_msda_fwd");
+}
+
+// 1 if the fused entries (rscotr_msda_fwd_prep / rscotr_msda_bwd_prep) take this geometry: 16 samples per (query, head) — the
+// prologue's softmax is a 16-lane reduction of the threads that stage them —, a tile's sample records within 48 KB of LDS and
+// element offsets within 2^31
+extern "C" int rscotr_msda_fused_ok(int Nk, int H, int D, int L, int P) {
+  if (!(D == 16 || D == 32 || D == 64) || !(P == 1 || P == 2 || P == 4 || P == 8) || L < 1 || L > MSDA_MAXL || L * P != 16) return 0;
+  const int QB = 4 * (kWave / (D / 4));
+  return RSCOTR_MSDA_FWD_DEDUP && (size_t)QB * L * P * sizeof(MsdaSample) <= 48 * 1024 && (long)(Nk + 1) * H * D < (1l << 31);
+}
+
+extern "C" int rscotr_msda_fwd_prep(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* off, const float* logit, int ld_off, int ld_logit, const float* ref,
+                                    const float* norm, int refdim, int ref_levels, float* loc, float* attn, float* out, int B,
+                                    int Nk, int Nq, int H, int D, int L, int P, void* stream) {
+  if (int e = check_shape("rscotr_msda_fwd_prep", B, Nk, Nq, H, D, L, P)) return e;
+  if (B == 0 || Nq == 0) return RSCOTR_OK;
+  if (!rscotr_msda_fused_ok(Nk, H, D, L, P))
+    return fail(RSCOTR_E_SHAPE, "rscotr_msda_fwd_prep: geometry outside rscotr_msda_fused_ok (L * P = %d, D = %d)", L * P, D);
+  if ((refdim != 2 && refdim != 4) || (ref_levels != 1 && ref_levels != L) || ld_off < H * L * P * 2 || (ld_off & 1) || ld_logit < H * L * P)
+    return fail(RSCOTR_E_SHAPE, "rscotr_msda_fwd_prep: refdim 2 | 4, ref_levels 1 | L, ld_off >= 2 H L P (even), ld_logit >= H L P");
+  if (!value || !spatial_shapes || !level_start_index || !off || !logit || !ref || !loc || !attn || !out || (refdim == 2 && !norm))
+    return fail(RSCOTR_E_ARG, "rscotr_msda_fwd_prep: null pointer");
+  if (!aligned16(value) || !aligned16(out) || ((uintptr_t)off & 7) || ((uintptr_t)loc & 7))
+    return fail(RSCOTR_E_ALIGN, "rscotr_msda_fwd_prep: value / out 16-byte, off / loc 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  MsdaPrepIn pi{off, logit, ref, norm, loc, attn, ld_off, ld_logit, refdim, ref_levels};
+  // algorithmic bytes: rscotr_msda_fwd's, with the raw offsets / logits read and loc / attn written instead of read
+  ProfScope prof(PROF_MSDA_FWD, 4.0 * B * ((double)Nk * H * D + (double)Nq * H * L * P * 6 + (double)Nq * H * D), s,
+                 "rscotr::msda_fwd_kernel<%d, %d>", D, P);
+#define CALL(DD, PP) launch_fwd<DD, PP>(value, spatial_shapes, level_start_index, nullptr, nullptr, out, B, Nk, Nq, H, L, s, &pi)
+  RSCOTR_DISPATCH_DP(D, P, CALL)
+#undef CALL
+  return check_launch("rscotr_msda_fwd_prep");
 }
 
 extern "C" int64_t rscotr_msda_bwd_workspace(int B, int Nk, int Nq, int H, int L, int P) {

@@ -114,6 +114,26 @@ def msda(value, spatial_shapes, level_start_index, loc, attn):
     return _MSDA.apply(value, spatial_shapes, level_start_index, loc, attn)
 
 
+def _msda_fused_ok(Nk, H, D, L, P):
+    """the prologue rides the sampling kernel's staging (rscotr_msda_fwd_prep): 16 samples per (query, head)"""
+    return STATE.msda_fused and bool(lib.rscotr_msda_fused_ok(Nk, H, D, L, P))
+
+
+def _msda_fwd_prep_raw(value, spatial_shapes, level_start_index, off, logit, ref, norm, L, P, ld_off, ld_logit):
+    """-> (loc, attn, out): _msda_prep_fwd_raw + _msda_fwd_raw in one launch"""
+    B, Nk, H, D = value.shape
+    Nq = ref.shape[1]
+    loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
+    attn = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=value.device)
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
+    nbytes = 4 * B * (Nk * H * D + Nq * H * L * P * 6 + Nq * H * D)
+    with _Prof('msda_fwd', nbytes):
+        lib.call('rscotr_msda_fwd_prep', value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                 off.data_ptr(), logit.data_ptr(), ld_off, ld_logit, ref.data_ptr(), _ptr(norm), ref.shape[-1], ref.shape[-2],
+                 loc.data_ptr(), attn.data_ptr(), out.data_ptr(), B, Nk, Nq, H, D, L, P, _stream())
+    return loc, attn, out
+
+
 def _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P, ld_off=None, ld_logit=None):
     """off / logit: dense (B*Nq, H*L*P*2) / (B*Nq, H*L*P), or column blocks of one wider row (ld_* = its row stride);
     ref (B,Nq,L|1,2|4)."""
@@ -214,13 +234,17 @@ class _MSDAAttn(Function):
                      b_aw.data_ptr(), n_aw, wb.data_ptr(), wslot, _stream())
             w_cat = RANGES.tag(wb[:n3 * C].view(n3, C), wslot)
             both = gemm(q2, w_cat, M, n3, C, C, C, 0, 0, bias=wb[n3 * C:])
-            loc, attn = _msda_prep_fwd_raw(both, both.view(-1)[n_off:], ref, norm, B, Nq, H, L, P, ld_off=n3, ld_logit=n3)
+            off, logit, ldo, ldl = both, both.view(-1)[n_off:], n3, n3
         else:
             w_cat = None
             off = gemm(q2, ws[0], M, n_off, C, C, C, 0, 0, bias=b_off)
             logit = gemm(q2, ws[1], M, n_aw, C, C, C, 0, 0, bias=b_aw)
-            loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P)
-        out = _msda_fwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn)
+            ldo, ldl = n_off, n_aw
+        if _msda_fused_ok(Nk, H, D, L, P):  # softmax + location arithmetic by the threads that stage the samples
+            loc, attn, out = _msda_fwd_prep_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, off, logit, ref, norm, L, P, ldo, ldl)
+        else:
+            loc, attn = _msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P, ld_off=ldo, ld_logit=ldl)
+            out = _msda_fwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn)
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(M, C))
         # (every output element is a convex combination of value entries — softmax weights x bilinear weights, zeros outside
         # the maps: max |out| <= max |v|, so the value's range word serves the output projection's operand too)

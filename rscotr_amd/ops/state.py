@@ -15,6 +15,7 @@ class OpsState:
         msda_packed=('RSCOTR_MSDA_PACKED', lambda s: s != '0', '1'),  # offsets | weights projections as one product
         pos_sum=('RSCOTR_POS_SUM', lambda s: s != '0', '1'),  # `query + query_pos` leaves the preceding LayerNorm's launch
         merge_norm=('RSCOTR_MERGE_NORM', lambda s: s != '0', '1'),  # PatchMerging's unfold done by its LayerNorm's loads / stores
+        msda_fused=('RSCOTR_MSDA_FUSED', lambda s: s != '0', '1'),  # softmax / location prologue (and its backward) inside the MSDA sample-order kernels
         attn_core=('RSCOTR_ATTN_CORE', lambda s: s != '0', '1'),  # dense attention (head dim 32) as one fused pass per direction, no stored scores
     )
 

@@ -251,3 +251,34 @@ def test_msda_attention_block_matches_composition(cuda, kind):
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, (kind, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize('refdim,packed', [(2, True), (2, False), (4, True)])
+@pytest.mark.parametrize('Nq', [5440, 1100, 37])
+def test_fused_prologue_equals_the_kernel_pair(cuda, refdim, packed, Nq):
+    """rscotr_msda_fwd_prep (the softmax / location prologue by the threads that stage the samples) against
+    rscotr_msda_prep_fwd + rscotr_msda_fwd: loc, attn and the output bit for bit (mmcv MultiScaleDeformableAttention.forward,
+    bbox_head/transformer.py:211-221,258-269)."""
+    from rscotr_amd import ops
+    from rscotr_amd.ops import deform
+    shapes = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    B, H, D, L, P = 2, 8, 32, 4, 4
+    Nk = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(Nq + refdim)
+    ss = torch.tensor(shapes, dtype=torch.long, device=cuda)
+    lsi = torch.tensor([0, 4096, 5120, 5376], dtype=torch.long, device=cuda)
+    value = torch.randn((B, Nk, H, D), generator=g).to(cuda)
+    n = H * L * P
+    both = (torch.randn((B * Nq, 3 * n), generator=g) * 2.0).to(cuda)
+    if packed:
+        off, logit, ldo, ldl = both, both.view(-1)[2 * n:], 3 * n, 3 * n
+    else:
+        off, logit, ldo, ldl = both[:, :2 * n].contiguous(), both[:, 2 * n:].contiguous(), 2 * n, n
+    ref = torch.rand((B, Nq, L if refdim == 2 else 1, refdim), generator=g).to(cuda)
+    norm = torch.tensor([(w, h) for h, w in shapes], dtype=torch.float32, device=cuda) if refdim == 2 else None
+    assert deform._msda_fused_ok(Nk, H, D, L, P)
+    loc0, attn0 = deform._msda_prep_fwd_raw(off, logit, ref, norm, B, Nq, H, L, P, ld_off=ldo, ld_logit=ldl)
+    out0 = deform._msda_fwd_raw(value, ss, lsi, loc0, attn0)
+    loc1, attn1, out1 = deform._msda_fwd_prep_raw(value, ss, lsi, off, logit, ref, norm, L, P, ldo, ldl)
+    assert torch.equal(loc0, loc1) and torch.equal(attn0, attn1) and torch.equal(out0, out1)
+    assert float(out1.abs().max()) > 0
