@@ -1,2 +1,3 @@
-python -m pytest tests/test_hplanes_gpu.py tests/test_gemm_gpu.py tests/test_h3_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | cut -c1-300
-BENCH_ARGS=--no-roofline bash scripts/gpu_ab_bench.sh t27 "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_no128.so" "" "RSCOTR_LIB=$PWD/rscotr_amd/_ab/lib_no128.so" > /dev/null 2>&1
+#!/bin/bash
+# one GPU trip: the full -m gpu suite + the default bench (scripts/gpu_suite.sh)
+bash "$(dirname "$0")/gpu_suite.sh" "${1:-trip}"
