@@ -313,9 +313,16 @@ __global__ __launch_bounds__(256) void layernorm_flush_kernel(const int64_t* __r
   }
 }
 
-static int ln_blocks(int M, int rows_per_block) {
+#ifndef RSCOTR_LN_FWD_CAP
+#define RSCOTR_LN_FWD_CAP 1024
+#endif
+#ifndef RSCOTR_LN_BWD_CAP
+#define RSCOTR_LN_BWD_CAP 1024  // workgroups (= partial dgamma / dbeta rows) of a backward launch.  512 (rounds 1-5) left the 32768- / 10880- / 8192-row
+#endif                          // launches at two wavefronts per SIMD with 5-8 dependent trips each; 1024: -0.05 to -0.2 ms per round by box, 768 /
+                                // 1536 / 2048 within noise of it, a forward cap of 2048-4096 no gain (profiles/README.md)
+static int ln_blocks(int M, int rows_per_block, long cap = RSCOTR_LN_FWD_CAP) {
   long b = ((long)M + rows_per_block - 1) / rows_per_block;
-  return (int)std::max<long>(1, std::min<long>(b, 1024));
+  return (int)std::max<long>(1, std::min<long>(b, cap));
 }
 
 }  // namespace rscotr
@@ -378,7 +385,7 @@ extern "C" int rscotr_layernorm_fwd_sum(const float* x, const float* weight, con
 static int ln_bwd_blocks(int M, int C) {
   const int c4 = C >> 2;
   const int G = c4 <= 8 ? 8 : c4 <= 16 ? 16 : c4 <= 32 ? 32 : 64;
-  return std::min(ln_blocks(M, 4 * (64 / G)), 512);
+  return ln_blocks(M, 4 * (64 / G), RSCOTR_LN_BWD_CAP);
 }
 
 extern "C" int64_t rscotr_layernorm_bwd_workspace(int M, int C) {
