@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from .core import _WS, _Prof, _chk, _f32c, _off_path, _ptr, _sink, _stream, lib
-from .matmul import DEFER, _linear_param_grad, colsum, gemm, gemm_batched, linear
+from .matmul import DEFER, RANGE_OUT, _linear_param_grad, colsum, gemm, gemm_batched, linear
 from .ranges import RANGES
 from .state import STATE
 
@@ -70,7 +70,7 @@ def swin_window_attention(x, hw, qkv_w, qkv_b, bias_table, rel_index, proj_w, pr
     reverse by index arithmetic), proj GEMM.  `rel_index` is unused: the kernel uses the closed form
     (dy+6)*13 + (dx+6) of the buffer."""
     H, W = hw
-    qkv = linear(x, qkv_w, qkv_b)
+    qkv = linear(x, qkv_w, qkv_b, range_out=False)  # (read by the window-attention kernel, which writes the word of ITS output)
     o = _SwinWindowAttn.apply(qkv, qkv_b, bias_table, H, W, heads, ws, shift)
     return linear(o, proj_w, proj_b, resid=identity, out_scale=out_scale)  # x + s_b * proj(...): one epilogue
 
@@ -120,18 +120,19 @@ class _MHA(Function):
         id_is_x = identity is x
         in_w, in_b = in_w.contiguous(), in_b.contiguous()
         ldq = 2 * C if fused else C
+        core = STATE.attn_core and hd == 32
+        nr = RANGE_OUT.want(not core)  # (q, k, v are read by the attention core, not by a product; the chain of batched products measures)
         if fused:
-            q = k = gemm(q2, in_w[:2 * C], B * Lq, 2 * C, C, C, C, 0, 0, bias=in_b[:2 * C])
+            q = k = gemm(q2, in_w[:2 * C], B * Lq, 2 * C, C, C, C, 0, 0, bias=in_b[:2 * C], range_out=nr)
         else:
-            q = gemm(q2, in_w[:C], B * Lq, C, C, C, C, 0, 0, bias=in_b[:C])
-            k = gemm(k2, in_w[C:2 * C], B * Lk, C, C, C, C, 0, 0, bias=in_b[C:2 * C])
-        v = gemm(v2, in_w[2 * C:], B * Lk, C, C, C, C, 0, 0, bias=in_b[2 * C:])
+            q = gemm(q2, in_w[:C], B * Lq, C, C, C, C, 0, 0, bias=in_b[:C], range_out=nr)
+            k = gemm(k2, in_w[C:2 * C], B * Lk, C, C, C, C, 0, 0, bias=in_b[C:2 * C], range_out=nr)
+        v = gemm(v2, in_w[2 * C:], B * Lk, C, C, C, C, 0, 0, bias=in_b[2 * C:], range_out=nr)
         if mask is not None:
             mask = mask.contiguous()
             assert mask.dtype == torch.bool and mask.is_cuda
         mode = int(mask_mode) if mask is not None else 0
         o = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
-        core = STATE.attn_core and hd == 32
         if core:
             # one pass over the keys, scores in MFMA accumulators; P below = the log-sum-exp of every score row (what backward
             # recomputes the probabilities from) instead of the (B, heads, Lq, Lk) probabilities
@@ -149,7 +150,7 @@ class _MHA(Function):
             gemm_batched(P, v, o, Lq, hd, Lk, Lk, C, C, 0, 1, B, heads, sp, sk, sq, ksplit=True)
         ctx.core, ctx.mask_t, ctx.mask_mode = core, mask, mode
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(B * Lq, C))
-        y = gemm(o, out_w, B * Lq, C, C, C, C, 0, 0, bias=out_b, resid=id2)
+        y = gemm(o, out_w, B * Lq, C, C, C, C, 0, 0, bias=out_b, resid=id2, range_out=RANGE_OUT.want(id2 is None))
         ctx.save_for_backward(q2, k2, v2, q, k, v, P, o, in_w, out_w)
         ctx.params = (in_w, in_b, out_w, out_b)  # handles for the gradient sink
         ctx.geom = (B, Lq, Lk, C, heads, hd)
@@ -172,7 +173,7 @@ class _MHA(Function):
 
         # out projection
         gw_o, gb_o, skw_o, skb_o = _linear_param_grad(g, o, C, C, B * Lq, p_out_w, p_out_b, 0, need[7], need[8])
-        do = gemm(g, out_w, B * Lq, C, C, C, C, 0, 1)
+        do = gemm(g, out_w, B * Lq, C, C, C, C, 0, 1, range_out=RANGE_OUT.want(not ctx.core))
         # attention core
         dv = torch.empty((B * Lk, C), dtype=torch.float32, device=dev)
         ldq = 2 * C if fused else C
@@ -222,6 +223,8 @@ class _MHA(Function):
             if sk_ is not None:
                 STATE.grad_sink.grad_written(sk_[0])
 
+        # (the input gradients go to a norm's backward or a merge, not straight into a product: no range words — RANGE_OUT)
+        gin = lambda *a_, **k_: gemm(*a_, range_out=RANGE_OUT.want(False), **k_)
         # ---- input gradients: what meets at x (and at the key content) is merged in the epilogues -----------------
         Mq, Mk = B * Lq, B * Lk
         w_q, w_k, w_v, w_qk = in_w[:C], in_w[C:2 * C], in_w[2 * C:], in_w[:2 * C]
@@ -235,14 +238,14 @@ class _MHA(Function):
                 # d(q side) + d(k side) in one product over K = 2C (both reach x and the shared positional embedding)
                 if want_qpos and want_x and (merge_id or v_to_x):
                     d_x = torch.empty((Mq, C), dtype=torch.float32, device=dev)
-                    d_qpos = gemm(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, out2=d_x, resid=g if merge_id else None)
+                    d_qpos = gin(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, out2=d_x, resid=g if merge_id else None)
                 elif want_x or want_qpos:
-                    pure = gemm(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, resid=g if (merge_id and not want_qpos) else None)
+                    pure = gin(dq, w_qk, Mq, C, 2 * C, 2 * C, C, 0, 1, resid=g if (merge_id and not want_qpos) else None)
                     d_x = pure if want_x else None
                     d_qpos = pure if want_qpos else None
             else:
-                dq_in = gemm(dq, w_q, Mq, C, C, C, C, 0, 1) if (want_x or want_qpos) else None
-                dk_in = gemm(dk, w_k, Mk, C, C, C, C, 0, 1) if (want_x or want_kpos) else None
+                dq_in = gin(dq, w_q, Mq, C, C, C, C, 0, 1) if (want_x or want_qpos) else None
+                dk_in = gin(dk, w_k, Mk, C, C, C, C, 0, 1) if (want_x or want_kpos) else None
                 d_qpos = dq_in if want_qpos else None
                 d_kpos = dk_in if want_kpos else None
                 if want_x:  # (rare on this path: distinct positional embeddings for the two sides)
@@ -251,33 +254,33 @@ class _MHA(Function):
                         d_x = d_x + g
             if v_to_x:
                 if d_x is None:
-                    d_x = gemm(dv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
+                    d_x = gin(dv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
                 elif d_x is d_qpos or d_x is d_kpos:  # shared with a positional gradient: must not be modified
-                    d_x = gemm(dv, w_v, Mk, C, C, C, C, 0, 1, resid=d_x)
+                    d_x = gin(dv, w_v, Mk, C, C, C, C, 0, 1, resid=d_x)
                 else:
-                    gemm(dv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
+                    gin(dv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
             elif not v_is_kx and need[4]:
-                d_vx = gemm(dv, w_v, Mk, C, C, C, C, 0, 1)
+                d_vx = gin(dv, w_v, Mk, C, C, C, C, 0, 1)
         else:
             want_kx, want_kpos = need[2], has_kpos and need[3]
             if want_x or want_qpos:
                 if want_qpos and merge_id:
                     d_x = torch.empty((Mq, C), dtype=torch.float32, device=dev)
-                    d_qpos = gemm(dq, w_q, Mq, C, C, C, C, 0, 1, out2=d_x, resid=g)
+                    d_qpos = gin(dq, w_q, Mq, C, C, C, C, 0, 1, out2=d_x, resid=g)
                 else:
-                    pure = gemm(dq, w_q, Mq, C, C, C, C, 0, 1, resid=g if merge_id else None)
+                    pure = gin(dq, w_q, Mq, C, C, C, C, 0, 1, resid=g if merge_id else None)
                     d_x = pure if want_x else None
                     d_qpos = pure if want_qpos else None
             v_to_kx = v_is_kx and want_kx
-            dv_in = gemm(dv, w_v, Mk, C, C, C, C, 0, 1) if (v_to_kx or (not v_is_kx and need[4])) else None
+            dv_in = gin(dv, w_v, Mk, C, C, C, C, 0, 1) if (v_to_kx or (not v_is_kx and need[4])) else None
             if want_kx or want_kpos:
                 if want_kpos and v_to_kx:
                     d_kx = torch.empty((Mk, C), dtype=torch.float32, device=dev)
-                    d_kpos = gemm(dk, w_k, Mk, C, C, C, C, 0, 1, out2=d_kx, resid=dv_in)
+                    d_kpos = gin(dk, w_k, Mk, C, C, C, C, 0, 1, out2=d_kx, resid=dv_in)
                 elif v_to_kx:
-                    d_kx = gemm(dk, w_k, Mk, C, C, C, C, 0, 1, out=dv_in, accumulate=True)
+                    d_kx = gin(dk, w_k, Mk, C, C, C, C, 0, 1, out=dv_in, accumulate=True)
                 else:
-                    pure = gemm(dk, w_k, Mk, C, C, C, C, 0, 1)
+                    pure = gin(dk, w_k, Mk, C, C, C, C, 0, 1)
                     d_kx = pure if want_kx else None
                     d_kpos = pure if want_kpos else None
             elif v_to_kx:

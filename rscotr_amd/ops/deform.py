@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from .core import _WS, _Prof, _chk, _f32c, _ptr, _stream, lib
-from .matmul import _linear_param_grad, gemm
+from .matmul import RANGE_OUT, _linear_param_grad, gemm
 from .ranges import RANGES
 from .state import STATE
 
@@ -233,7 +233,7 @@ class _MSDAAttn(Function):
             lib.call('rscotr_pack4', ws[0].data_ptr(), n_off * C, ws[1].data_ptr(), n_aw * C, b_off.data_ptr(), n_off,
                      b_aw.data_ptr(), n_aw, wb.data_ptr(), wslot, _stream())
             w_cat = RANGES.tag(wb[:n3 * C].view(n3, C), wslot)
-            both = gemm(q2, w_cat, M, n3, C, C, C, 0, 0, bias=wb[n3 * C:])
+            both = gemm(q2, w_cat, M, n3, C, C, C, 0, 0, bias=wb[n3 * C:], range_out=RANGE_OUT.want(False))  # (read by the prologue)
             off, logit, ldo, ldl = both, both.view(-1)[n_off:], n3, n3
         else:
             w_cat = None
@@ -248,7 +248,7 @@ class _MSDAAttn(Function):
         id2 = x2 if id_is_x else (None if identity is None else _f32c(identity).reshape(M, C))
         # (every output element is a convex combination of value entries — softmax weights x bilinear weights, zeros outside
         # the maps: max |out| <= max |v|, so the value's range word serves the output projection's operand too)
-        y = gemm(RANGES.carry(v, out.view(M, C)), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2)
+        y = gemm(RANGES.carry(v, out.view(M, C)), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2, range_out=RANGE_OUT.want(id2 is None))
         ctx.save_for_backward(q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, *ws)
         ctx.slots = (RANGES.slot_of(q2), RANGES.slot_of(val2))
         ctx.kpm = kpm
@@ -276,7 +276,7 @@ class _MSDAAttn(Function):
         # output projection
         gw_o, gb_o, s1, s2 = _linear_param_grad(g, out.view(M, C), C, C, M, p_o, pb_o, 0, need[18], pb_o is not None and need[19])
         sinks += [s1, s2]
-        d_out = gemm(g, w_o, M, C, C, C, C, 0, 1)
+        d_out = gemm(g, w_o, M, C, C, C, C, 0, 1, range_out=RANGE_OUT.want(False))  # (read by the sampling kernel's backward)
         # sampling kernel and the location / softmax arithmetic
         gv, gloc, gattn = _msda_bwd_raw(v.view(B, Nk, H, D), spatial_shapes, lsi, loc, attn, d_out.view(B, Nq, C))
         w_cat = ctx.w_cat
@@ -302,7 +302,8 @@ class _MSDAAttn(Function):
         for sk_ in sinks:
             if sk_ is not None:
                 STATE.grad_sink.grad_written(sk_[0])
-        # input gradients, merged in the epilogues
+        # input gradients, merged in the epilogues (they go to a norm's backward or a merge: no range words — RANGE_OUT)
+        gin = lambda *a_, **k_: gemm(*a_, range_out=RANGE_OUT.want(False), **k_)
         want_pos = has_pos and need[1]
         want_x = need[0]
         want_val = (not v_is_x) and need[2]
@@ -314,21 +315,21 @@ class _MSDAAttn(Function):
             if two:
                 d_x = torch.empty((M, C), dtype=torch.float32, device=g.device)  # pure = d(query_pos); d_x = pure (+ dy) (+ d(value) below)
             if packed:
-                pure = gemm(both, w_cat, M, C, n3, n3, C, 0, 1, out2=d_x if two else None, resid=res)
+                pure = gin(both, w_cat, M, C, n3, n3, C, 0, 1, out2=d_x if two else None, resid=res)
             else:
-                pure = gemm(goff, w_off, M, C, n_off, n_off, C, 0, 1)
-                gemm(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True, out2=d_x if two else None, resid=res)
+                pure = gin(goff, w_off, M, C, n_off, n_off, C, 0, 1)
+                gin(glogit, w_aw, M, C, n_aw, n_aw, C, 0, 1, out=pure, accumulate=True, out2=d_x if two else None, resid=res)
             if two:
                 d_pos = pure
             else:
                 d_x = pure if want_x else None
                 d_pos = pure if want_pos else None
             if v_is_x and want_x:
-                gemm(gv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
+                gin(gv, w_v, Mk, C, C, C, C, 0, 1, out=d_x, accumulate=True)
         elif v_is_x and want_x:
-            d_x = gemm(gv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
+            d_x = gin(gv, w_v, Mk, C, C, C, C, 0, 1, resid=g if merge_id else None)
         if want_val:
-            d_val = gemm(gv, w_v, Mk, C, C, C, C, 0, 1).view(ctx.shapes[2])
+            d_val = gin(gv, w_v, Mk, C, C, C, C, 0, 1).view(ctx.shapes[2])
         d_id = g.view(ctx.shapes[3]) if (has_id and not merge_id and need[3]) else None
         if id_is_x and not merge_id:
             d_id = None

@@ -546,7 +546,7 @@ def _in_arena(t):
 
 def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=ACT_NONE, aux=None, pre=None,
          resid=None, accumulate=False, rowsum=None, rowsum_accumulate=False, rowscale=None, rows_per=0, kscale=None,
-         krows_per=0, out2=None, amax_a=0, amax_b=0, amax_out=0):
+         krows_per=0, out2=None, amax_a=0, amax_b=0, amax_out=0, range_out=True):
     """C[m,n] = epilogue(sum_k Aop[m,k] Bop[n,k]) on the fp32 matrix cores (include/rscotr.h,
     rscotr_gemm_f32).  A, B, out are contiguous fp32 device tensors; out (M,N) is allocated here
     unless given.  `rowsum` (M,) (+)= sum_k Aop[m,k] (k-major A only: the bias gradient riding the dW
@@ -581,7 +581,7 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
             # the split kernels take this product: with the value ranges of both operands it runs as the fp16 split product
             amax_a = amax_a or (RANGES.of(A, K, M, lda) if a_kmajor else RANGES.of(A, M, K, lda))
             amax_b = amax_b or (RANGES.of(B, K, N, ldb) if b_kmajor else RANGES.of(B, N, K, ldb))
-        if not amax_out and not _in_arena(out):
+        if not amax_out and range_out and RANGE_OUT.enabled_for(out):
             # the range of what this product stores rides out of its epilogue: whoever multiplies with it next finds it
             amax_out = RANGES.new_slot(A.device)
             RANGES.tag(out, amax_out)
@@ -628,6 +628,28 @@ def colsum(X, M, N, out=None, accumulate=False):
     lib.call('rscotr_colsum_f32', X.data_ptr(), out.data_ptr(), M, N, N, int(accumulate), ws.data_ptr(), nws,
              _stream())
     return out
+
+
+class _RangeOut:
+    """Which products leave the range word of their output (amax_out of rscotr_gemm_f32_r).  The commit is one atomic round trip at
+    the end of every workgroup's life (~1 us per launch: profiles/r5_range_word_cost.txt), and only an output that a LATER product
+    multiplies with needs the word: callers that know their consumer is a norm, an attention core, the sampling kernel or an
+    element-wise merge pass `range_out=False` (ops.linear / ops.gemm).  A tensor that does reach a product without a word is
+    measured there (rscotr_amax_f32: correct, one launch; RSCOTR_RANGES_STATS=1 lists them).  RSCOTR_RANGE_OUT_ALL=1: every
+    product writes its word, as before."""
+
+    def __init__(self):
+        self.all = os.environ.get('RSCOTR_RANGE_OUT_ALL', '0') == '1'
+        self.skip_next = False  # set by ops.linear(range_out=False) for the forward of the node it creates
+
+    def enabled_for(self, out):
+        return not _in_arena(out)
+
+    def want(self, flag):
+        return True if self.all else bool(flag)
+
+
+RANGE_OUT = _RangeOut()
 
 
 class _ReluBits:
@@ -685,6 +707,10 @@ class _MLP(Function):
             s2 = _f32c(sum_with).reshape(M, -1)
         hs, auxs = [x2], []
         h = x2
+        # the last layer's range word: not for an output that takes a residual (a block output: the next reader is a norm) nor
+        # where the caller said so (ops.linear(range_out=False): qkv of a window attention, ...)
+        want_last = RANGE_OUT.want(not RANGE_OUT.skip_next and id2 is None)
+        RANGE_OUT.skip_next = False
         for i in range(n):
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
             N, K = W.shape
@@ -701,7 +727,8 @@ class _MLP(Function):
                 h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE, resid=s2, out2=y2)
             else:
                 h = gemm(h, W, M, N, K, K, K, 0, 0, bias=bs[i], act=ACT_NONE if last else a_i, pre=pre,
-                         resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0)
+                         resid=id2 if last else None, rowscale=sc, rows_per=rows_per if sc is not None else 0,
+                         range_out=want_last if last else True)
             if not last:
                 hs.append(h)
                 auxs.append(pre if pre is not None else h)  # (GELU: the pre-activation; ReLU: the gate bits, or h itself)
@@ -779,7 +806,9 @@ class _MLP(Function):
                 g = gemm(g, W, M, K, N, N, K, 0, 1, act=ga, aux=auxs[i - 1], **scr)  # dH = (g W) * act'
             elif ctx.needs_input_grad[0]:
                 # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
-                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, **scr)
+                # (the node's input gradient goes to a norm's backward, an attention backward or a merge: no later product
+                #  multiplies with it directly)
+                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, range_out=RANGE_OUT.want(False), **scr)
                 dx = RANGES.carry(dx, dx.view(ctx.x_shape))
         return (dx, d_id, None, None, None, *grads_wb)
 
@@ -795,11 +824,16 @@ def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None):
     return _MLP.apply(x, identity, _ACT[act], out_scale, None if sum_with is None else sum_with.detach(), *flat)
 
 
-def linear(x, w, b=None, act=None, resid=None, out_scale=None):
-    """F.linear(x, w, b) [* out_scale per sample] (+ resid) on the matrix cores.  Activations belong to `mlp`."""
+def linear(x, w, b=None, act=None, resid=None, out_scale=None, range_out=True):
+    """F.linear(x, w, b) [* out_scale per sample] (+ resid) on the matrix cores.  Activations belong to `mlp`.
+    range_out=False: no later product multiplies with the output (RANGE_OUT)."""
     if act is not None:
         raise RuntimeError('ops.linear has no activation: use ops.mlp')
-    return _MLP.apply(x, resid, ACT_NONE, out_scale, None, w, b)
+    RANGE_OUT.skip_next = not range_out
+    try:
+        return _MLP.apply(x, resid, ACT_NONE, out_scale, None, w, b)
+    finally:
+        RANGE_OUT.skip_next = False
 
 
 def _attn_ksplits(M, N, K, nb):

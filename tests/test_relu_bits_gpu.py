@@ -89,3 +89,31 @@ def test_ffn_node_takes_the_bits_and_matches_the_plain_route(cuda, gemm_precisio
         res.append([y.detach()] + [t.grad for t in [x] + ps])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_block_outputs_commit_no_range_word_and_values_do_not_change(cuda, gemm_precision, monkeypatch):
+    """ops.RANGE_OUT: a product whose output no later product multiplies with (a Linear that takes a residual, a projection read by
+    an attention kernel: ops.linear(range_out=False)) leaves no range word — one atomic round trip per workgroup less — and the
+    numbers are the same as with every product committing (RSCOTR_RANGE_OUT_ALL=1)."""
+    from rscotr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, C, F = 2048, 256, 1024
+    x0 = torch.randn((2, M // 2, C), generator=g).to(cuda)
+    W1, b1 = (torch.randn((F, C), generator=g) * 0.05).to(cuda), torch.randn(F, generator=g).to(cuda)
+    W2, b2 = (torch.randn((C, F), generator=g) * 0.02).to(cuda), torch.randn(C, generator=g).to(cuda)
+    dy = torch.randn((2, M // 2, C), generator=g).to(cuda)
+    res = []
+    for all_ in (False, True):
+        monkeypatch.setattr(ops.RANGE_OUT, 'all', all_)
+        x = x0.clone().requires_grad_(True)
+        ps = [t.clone().requires_grad_(True) for t in (W1, b1, W2, b2)]
+        y = ops.mlp(x, [(ps[0], ps[1]), (ps[2], ps[3])], act='relu', identity=x)
+        q = ops.linear(x, ps[0], ps[1], range_out=False)
+        k = ops.linear(x, ps[0], ps[1])
+        if ops.RANGES.enabled:
+            assert bool(ops.RANGES.slot_of(y)) == all_ and bool(ops.RANGES.slot_of(q)) == all_ and bool(ops.RANGES.slot_of(k))
+        (y.sum() * 0 + (y * dy).sum() + q.sum() + k.sum()).backward()
+        res.append([y.detach(), q.detach(), k.detach()] + [t.grad for t in [x] + ps])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not ops.RANGE_OUT.skip_next
