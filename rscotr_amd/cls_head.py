@@ -70,12 +70,12 @@ class SlvlClsHead(nn.Module):
         return self.pre_logits(backbone_feature)
 
     def forward_train(self, neck_feature, backbone_feature, gt_label, shared_encoder=None, **kwargs):
-        cls_score = ops.linear(self._features(neck_feature, backbone_feature, shared_encoder), self.fc.weight, self.fc.bias)
+        cls_score = ops.linear(self._features(neck_feature, backbone_feature, shared_encoder), self.fc.weight, self.fc.bias, range_out=False)
         loss = self.compute_loss(cls_score, gt_label, avg_factor=len(cls_score))
         return dict(loss=loss)
 
     def simple_test(self, neck_feature, backbone_feature, shared_encoder=None, softmax=True, post_process=True):
-        cls_score = ops.linear(self._features(neck_feature, backbone_feature, shared_encoder), self.fc.weight, self.fc.bias)
+        cls_score = ops.linear(self._features(neck_feature, backbone_feature, shared_encoder), self.fc.weight, self.fc.bias, range_out=False)
         pred = cls_score.softmax(-1) if softmax else cls_score
         return list(pred.detach().cpu().numpy()) if post_process else pred
 
@@ -171,7 +171,7 @@ class MlvlClsHead(SlvlClsHead):
         """nn.Linear(T, 1) over the last axis of (B, C, T), squeezed: a weighted token sum per channel."""
         B, C, T = seq.shape
         assert T == self.out_proj.in_features, f'scheme {self.scheme} is built for {self.out_proj.in_features} tokens, got {T}'
-        return ops.linear(seq.reshape(B * C, T), self.out_proj.weight, self.out_proj.bias).view(B, C)
+        return ops.linear(seq.reshape(B * C, T), self.out_proj.weight, self.out_proj.bias, range_out=False).view(B, C)
 
     def _features(self, neck_feature, backbone_feature, shared_encoder):
         return self.pre_logits(self.pixel_decoder(shared_encoder, neck_feature))

@@ -73,7 +73,7 @@ def build_mlp(input_dim, hidden_dim, output_dim, num_layers):
 
 def _mlp(x, seq):
     """Sequential(Linear, ReLU, ..., Linear) as one fused MLP (ops.mlp)."""
-    return ops.mlp(x, [(m.weight, m.bias) for m in seq if isinstance(m, nn.Linear)], act='relu')
+    return ops.mlp(x, [(m.weight, m.bias) for m in seq if isinstance(m, nn.Linear)], act='relu', range_out=False)  # (read by box arithmetic / losses)
 
 
 # ------------------------------------------------------------------------------------------
@@ -636,10 +636,10 @@ class DinoTransformer(nn.Module):
         memory, mem_dec = mems[0], mems[1:]
         om = memory if unpadded else memory.masked_fill(mask_flat.unsqueeze(-1), 0.0)
         om = om.masked_fill(~valid, 0.0)
-        om = ops.layer_norm(ops.linear(om, self.enc_output.weight, self.enc_output.bias),
+        om = ops.layer_norm(ops.linear(om, self.enc_output.weight, self.enc_output.bias, range_out=False),
                             self.enc_output_norm.weight, self.enc_output_norm.bias)
         nl = self.decoder.num_layers
-        enc_cls = ops.linear(om, cls_branches[nl].weight, cls_branches[nl].bias)
+        enc_cls = ops.linear(om, cls_branches[nl].weight, cls_branches[nl].bias, range_out=False)
         topk = self.two_stage_num_proposals
         N_tok = enc_cls.shape[1]
         if topk <= min(N_tok, ops.DET_PROPOSALS_MAX_K) and N_tok <= ops.DET_PROPOSALS_MAX_N:
@@ -848,7 +848,7 @@ class DINOHead(nn.Module):
             hs = [hs[0] + self.label_embedding.weight[0, 0] * 0.0] + list(hs[1:])  # dino_head.py:124-128
         outputs_classes, outputs_coords = [], []
         for lvl in range(len(hs)):
-            outputs_classes.append(ops.linear(hs[lvl], self.cls_branches[lvl].weight, self.cls_branches[lvl].bias))
+            outputs_classes.append(ops.linear(hs[lvl], self.cls_branches[lvl].weight, self.cls_branches[lvl].bias, range_out=False))
             outputs_coords.append(ops.refine_box(_mlp(hs[lvl], self.reg_branches[lvl]), inter_references[lvl], eps=1e-3))
         return torch.stack(outputs_classes), torch.stack(outputs_coords), topk_score, topk_anchor
 

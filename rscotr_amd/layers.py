@@ -56,7 +56,7 @@ class ChannelMapper(nn.Module):
         toks = [ops.map_to_tokens(x) for x in inputs]
         outs = []
         for (t, hw), m in zip(toks, self.convs):
-            y = ops.linear(t, m.conv.weight.view(m.conv.weight.shape[0], -1), None)
+            y = ops.linear(t, m.conv.weight.view(m.conv.weight.shape[0], -1), None, range_out=False)  # (read by the GroupNorm)
             outs.append((ops.group_norm_tokens(y, self.groups, m.gn.weight, m.gn.bias), hw))
         if self.extra_convs:
             for i, m in enumerate(self.extra_convs):

@@ -813,7 +813,7 @@ class _MLP(Function):
         return (dx, d_id, None, None, None, *grads_wb)
 
 
-def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None):
+def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None, range_out=True):
     """layers: [(W, b), ...]; activation between layers, none after the last; `identity` (same shape
     as the output) is added in the last epilogue (mmcv FFN add_identity); `out_scale` (B,) multiplies the
     output per sample before that (DropPath).  With `sum_with` (shape of the output, values only): -> (y, y + sum_with), the
@@ -821,7 +821,11 @@ def mlp(x, layers, act='relu', identity=None, out_scale=None, sum_with=None):
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _MLP.apply(x, identity, _ACT[act], out_scale, None if sum_with is None else sum_with.detach(), *flat)
+    RANGE_OUT.skip_next = not range_out  # (False: no later product multiplies with the output — RANGE_OUT)
+    try:
+        return _MLP.apply(x, identity, _ACT[act], out_scale, None if sum_with is None else sum_with.detach(), *flat)
+    finally:
+        RANGE_OUT.skip_next = False
 
 
 def linear(x, w, b=None, act=None, resid=None, out_scale=None, range_out=True):

@@ -85,7 +85,7 @@ class MlvlSegPixelDecoder(nn.Module):
         multi_scale_features = outs[:self.num_outs]
         # 1x1 conv = MFMA GEMM on the tokens of the finest level
         h, w = shapes[-1]
-        mf = ops.linear(levels[-1], self.mask_feature.weight.view(self.mask_feature.weight.shape[0], -1), self.mask_feature.bias)
+        mf = ops.linear(levels[-1], self.mask_feature.weight.view(self.mask_feature.weight.shape[0], -1), self.mask_feature.bias, range_out=False)
         mask_feature = ops.tokens_to_map(mf, (h, w))
         return mask_feature, multi_scale_features
 
@@ -150,7 +150,7 @@ class Mask2FormerHead(nn.Module):
         pn = self.transformer_decoder.post_norm
         d = ops.layer_norm(decoder_out, pn.weight, pn.bias)
         m = self.mask_embed
-        e = ops.mlp(d, [(m[0].weight, m[0].bias), (m[2].weight, m[2].bias), (m[4].weight, m[4].bias)], act='relu')
+        e = ops.mlp(d, [(m[0].weight, m[0].bias), (m[2].weight, m[2].bias), (m[4].weight, m[4].bias)], act='relu', range_out=False)  # (read by the mask-logit products on the fp32 pipe)
         B_, C_, h_, w_ = mask_feature.shape
         # einsum('bqd,bdhw->bqhw') on the token view of the mask features (channels-last map: free) -> MFMA GEMM
         mask_pred = ops.mask_logits(e, mask_feature.permute(0, 2, 3, 1).reshape(B_, h_ * w_, C_)).view(B_, -1, h_, w_)

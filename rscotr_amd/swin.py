@@ -99,7 +99,7 @@ class PatchMerging(nn.Module):
         else:
             y, hw2 = ops.patch_merge_gather(x, hw)
             y = ops.layer_norm(y, self.norm.weight, self.norm.bias)
-        return ops.linear(y, self.reduction.weight, None), hw2
+        return ops.linear(y, self.reduction.weight, None, range_out=False), hw2  # (read by the next stage's norm)
 
 
 class SwinBlockSequence(nn.Module):
