@@ -27,6 +27,11 @@ extern "C" {
 #define RSCOTR_E_LAUNCH (-4)
 #define RSCOTR_E_ARG (-5)
 
+/* ABI revision: bumped whenever an exported entry changes its argument list (round 5 inserted amax_out / nbytes before
+ * `stream` in the LayerNorm, window-attention, MSDA backward, pack4, splitk_flush and grouped-dW entries = revision 6;
+ * round 6 = 7).  rscotr_version() returns the revision the shared object was BUILT with; a binding compares the two before
+ * its first call (rscotr_amd/_lib.py does) — a stale .so would take a stream handle for a pointer. */
+#define RSCOTR_ABI_VERSION 7
 int rscotr_version(void);
 const char* rscotr_last_error(void);
 int rscotr_device_count(void);

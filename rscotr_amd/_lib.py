@@ -20,6 +20,14 @@ _CTYPES = {
 }
 
 
+def header_abi_version(path=HEADER):
+    with open(path) as fh:
+        m = re.search(r"^#define\s+RSCOTR_ABI_VERSION\s+(\d+)", fh.read(), flags=re.M)
+    if m is None:
+        raise RuntimeError("include/rscotr.h does not define RSCOTR_ABI_VERSION")
+    return int(m.group(1))
+
+
 def parse_header(path=HEADER):
     """Return {name: (restype, [argtypes])} for every function declared in the header."""
     with open(path) as fh:
@@ -67,6 +75,11 @@ class _Lib:
                 "(there is no CPU or PyTorch fallback for the HIP path)")
         dll = ctypes.CDLL(LIB_PATH)
         self._sigs = parse_header()
+        dll.rscotr_version.restype = ctypes.c_int
+        built, want = dll.rscotr_version(), header_abi_version()
+        if built != want:  # (a stale build, or an A/B library picked by RSCOTR_LIB that predates an argument-list change)
+            raise RuntimeError(f"{LIB_PATH} was built for ABI revision {built}, include/rscotr.h declares {want}: "
+                               "rebuild it (`python -m rscotr_amd.build --force`)")
         for name, (ret, args) in self._sigs.items():
             fn = getattr(dll, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = ret

@@ -73,6 +73,8 @@ def load_pretrained_backbone(model, path, convert_weights=True, map_location='cp
     skip = [k for k in sd if k.endswith(('relative_position_index', 'attn_mask'))]  # buffers recomputed here
     for k in skip:
         del sd[k]
+    from . import ops
+    ops.WPLANES.bump()  # (also when `model` is a bare backbone outside an MTL: planes and parameter range words are stale)
     return model.load_state_dict(sd, strict=False)
 
 

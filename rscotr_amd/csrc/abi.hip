@@ -1,5 +1,6 @@
 // Library-level entries of the rscotr C ABI (version, error string).
 #include "common.h"
+#include "rscotr.h"
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,7 +94,7 @@ extern "C" int rscotr_prof_disable(void) {
   return RSCOTR_OK;
 }
 
-extern "C" int rscotr_version(void) { return 1; }
+extern "C" int rscotr_version(void) { return RSCOTR_ABI_VERSION; }
 
 extern "C" const char* rscotr_last_error(void) { return rscotr::err_buf(); }
 

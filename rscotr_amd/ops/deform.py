@@ -250,7 +250,7 @@ class _MSDAAttn(Function):
         # the maps: max |out| <= max |v|, so the value's range word serves the output projection's operand too)
         y = gemm(RANGES.carry(v, out.view(M, C)), ws[3], M, C, C, C, C, 0, 0, bias=b_o, resid=id2, range_out=RANGE_OUT.want(id2 is None))
         ctx.save_for_backward(q2, val2, v, loc, attn, ref, norm, out, spatial_shapes, lsi, *ws)
-        ctx.slots = (RANGES.slot_of(q2), RANGES.slot_of(val2))
+        ctx.slots = (RANGES.saved(q2), RANGES.saved(val2))
         ctx.kpm = kpm
         ctx.w_cat = w_cat  # (a temporary of this node: not an autograd-tracked tensor)
         ctx.params = (w_off, b_off, w_aw, b_aw, w_v, b_v, w_o, b_o)  # handles for the gradient sink
@@ -270,8 +270,8 @@ class _MSDAAttn(Function):
         M, Mk = B * Nq, B * Nk
         n_off, n_aw = H * L * P * 2, H * L * P
         g = RANGES.carry(dy, _f32c(dy).reshape(M, C))
-        RANGES.tag(q2, ctx.slots[0])
-        RANGES.tag(val2, ctx.slots[1])
+        RANGES.restore(q2, ctx.slots[0])  # (void after a begin() since the forward: ADVICE r5)
+        RANGES.restore(val2, ctx.slots[1])
         sinks = []
         # output projection
         gw_o, gb_o, s1, s2 = _linear_param_grad(g, out.view(M, C), C, C, M, p_o, pb_o, 0, need[18], pb_o is not None and need[19])

@@ -40,9 +40,14 @@ class _WeightPlanes:
         self.version += 1
         HPLANES.reset()
 
-    def bump(self):
+    def bump(self, by_optimizer=False):
+        """The parameters have changed.  by_optimizer: by the update kernel itself, which also rewrites their range words;
+        any other writer (checkpoint / state-dict load, init_weights, a snapshot restore, a manual copy) leaves the words the
+        optimizer keeps stale — a stale-small word overflows the fp16 planes — so they are recomputed on next use."""
         self.version += 1
         HPLANES.version += 1
+        if not by_optimizer and STATE.grad_sink is not None:
+            STATE.grad_sink.params_changed()
 
     def eligible(self, A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, gelu=False):
         if not self.enabled or a_kmajor or STATE.grad_sink is None or K % 16 or N < 64:
@@ -484,6 +489,18 @@ class _DeferredCombine:
 DEFER = _DeferredCombine()
 
 
+def _ranges_invalidated():
+    """RANGES.begin() / a wrap of the slot buffer while grouped weight gradients are still pending (gradient accumulation, an
+    evaluation forward between backward and the flush): the raw slot addresses they hold are zero words or someone else's now.
+    The problems fall back to the member kind that needs no ranges (the six-term bf16 body), the to-be-measured list is dropped."""
+    if DEFER.group:
+        DEFER.group = [tuple(p[:11]) + (0, 0) for p in DEFER.group]
+    DEFER.group_amax = {}
+
+
+RANGES.on_invalidate.append(_ranges_invalidated)
+
+
 def flush_deferred():
     """Compute the grouped weight gradients and combine the pending split-K weight gradients / LayerNorm parameter
     gradients into the arena (no-op when nothing is pending)."""
@@ -555,6 +572,11 @@ def gemm(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor, out=None, bias=None, act=A
     _chk(A, B, out, bias, aux, pre, resid, rowsum, out2)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    elif not amax_out:
+        # a caller's tensor is (re)written: whatever bound it carried no longer holds; a route below that commits a word tags it anew
+        RANGES.untag(out)
+    if not amax_out:
+        RANGES.untag(out2)
     if (rowsum is None and kscale is None and STATE.profile is None
             and WPLANES.eligible(A, B, M, N, K, lda, ldb, a_kmajor, b_kmajor,
                                  gelu=act in (ACT_GELU, ACT_GELU_GRAD) or pre is not None)):
@@ -733,7 +755,7 @@ class _MLP(Function):
                 hs.append(h)
                 auxs.append(pre if pre is not None else h)  # (GELU: the pre-activation; ReLU: the gate bits, or h itself)
         ctx.save_for_backward(*hs, *auxs, *ws)
-        ctx.h_slots = [RANGES.slot_of(t) for t in hs]  # (value ranges of the saved activations: the weight gradients want them)
+        ctx.h_slots = [RANGES.saved(t) for t in hs]  # ((generation, slot) of the saved activations: the weight gradients want their ranges)
         ctx.out_scale, ctx.rows_per = out_scale, rows_per
         ctx.n, ctx.act, ctx.has_id, ctx.id_is_x = n, act, identity is not None, id_is_x
         ctx.has_bias = [b is not None for b in bs]
@@ -758,7 +780,7 @@ class _MLP(Function):
         hs, auxs, ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
         M = hs[0].shape[0]
         for t, sl in zip(hs, ctx.h_slots):
-            RANGES.tag(t, sl)
+            RANGES.restore(t, sl)  # (only within the generation that wrote the word: a begin() since the forward voids it)
         g = RANGES.carry(dy, _f32c(dy).reshape(M, -1))
         g_out = g
         d_id = g.view(ctx.id_shape) if ctx.has_id and not ctx.id_is_x and ctx.needs_input_grad[1] else None

@@ -45,6 +45,9 @@ class _Ranges:
         self.log = os.environ.get('RSCOTR_RANGES_STATS') == '1'
         self.sites = {}
         self.stats = dict(measured=0, carried=0, params=0)
+        # called whenever the slots are zeroed / handed out again (begin(), a wrap of new_slot): whoever holds raw slot
+        # addresses outside a tensor attribute (DEFER's pending grouped problems) must forget them
+        self.on_invalidate = []
 
     # ---- slots
     def _ensure(self, device):
@@ -82,6 +85,8 @@ class _Ranges:
             self._zero()
         self.n = 0
         self.gen += 1
+        for cb in self.on_invalidate:
+            cb()
 
     def _zero(self):
         # (one launch: the used words of all planes; at least 1024 so that the shape — and the captured node — is stable)
@@ -94,6 +99,8 @@ class _Ranges:
             self._zero()
             self.n = 0
             self.gen += 1
+            for cb in self.on_invalidate:
+                cb()
         self.n += 1
         return self.base + 4 * (self.n - 1)
 
@@ -114,6 +121,25 @@ class _Ranges:
     def slot_of(self, t):
         a = getattr(t, '_rs_amax', None)
         return a[1] if a is not None and a[0] == self.gen else 0
+
+    def saved(self, t):
+        """(generation, slot) of `t` for an autograd ctx (saved tensors come back as new objects without the attribute).  A slot
+        must never be re-stamped with the generation current at backward time: a `begin()` between forward and backward (a
+        second forward, gradient accumulation, an evaluation in between) has zeroed the word or handed it to another tensor."""
+        a = getattr(t, '_rs_amax', None)
+        return a if a is not None and a[0] == self.gen else None
+
+    def restore(self, t, saved):
+        """Hand a slot saved by `saved()` back to the (unpacked) tensor — only within the generation that wrote it; else the
+        tensor stays untagged and is measured where a product needs its range."""
+        if saved is not None and saved[0] == self.gen and t is not None:
+            t._rs_amax = saved
+        return t
+
+    def untag(self, t):
+        """`t` is about to be written by something that commits no range word: a bound it carried no longer holds."""
+        if t is not None and getattr(t, '_rs_amax', None) is not None:
+            del t._rs_amax
 
     def carry(self, src, dst):
         """dst is a view / reshape / alias of src (same values): hand the slot on."""

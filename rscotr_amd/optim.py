@@ -276,7 +276,7 @@ class FlatAdamW:
         if self.max_norm > 0:
             lib.call('rscotr_grad_sumsq', self.flat_g.data_ptr(), self.chunk_seg.data_ptr(), self.chunk_off.data_ptr(),
                      self.chunk_len.data_ptr(), self.seg_dyn.data_ptr(), self.nchunks, self.sumsq.data_ptr(), s)
-        ops.WPLANES.bump()  # the parameters change: their pre-split planes are stale from here on
+        ops.WPLANES.bump(by_optimizer=True)  # the parameters change: their pre-split planes are stale from here on
         if self.amax_dirty:  # (the words of the tensors this step does not touch must be valid too)
             self.refresh_amax()
         lib.call('rscotr_adamw_clip_step_r', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),

@@ -228,7 +228,7 @@ class GraphedTask:
             # so (WPLANES.bump() in launch_step ran at capture time only).  Without this, a non-captured forward after
             # replays — the evaluation hook, an eager det iteration whose batch exceeds the captured capacities — would find
             # its weight planes "fresh" and multiply with weights at least one step old
-            ops.WPLANES.bump()
+            ops.WPLANES.bump(by_optimizer=True)  # (the replayed update kernel rewrote the parameters' range words itself)
         self._finish()
 
     def _warm_and_capture(self):

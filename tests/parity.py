@@ -23,6 +23,22 @@ def default_dtype(dt):
         torch.set_default_dtype(old)
 
 
+@contextlib.contextmanager
+def ranges_checked():
+    """Every value-range word a product takes from a tensor, the optimizer or a producer's epilogue is verified against what the
+    tensor holds at that moment (ops.RANGES.check: one measuring launch + a synchronisation per operand).  A stale word is
+    value-dependent — 8 x of headroom hides it until a seed exceeds it — so the whole-step tests at size run their eager
+    iteration under the check, not only the 256^2 one."""
+    from rscotr_amd import ops
+    old = ops.RANGES.check
+    ops.RANGES.check = ops.RANGES.enabled
+    ops.RANGES.stats['checked'] = 0
+    try:
+        yield ops.RANGES
+    finally:
+        ops.RANGES.check = old
+
+
 def cast_tree(obj, dt):
     """Floating tensors of a nested batch / rnd structure to dtype dt (everything else untouched)."""
     if torch.is_tensor(obj):

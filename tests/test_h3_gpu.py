@@ -196,8 +196,9 @@ def test_optimizer_keeps_parameter_ranges(cuda):
         opt.close()
 
 
+@pytest.mark.parametrize('seed', [4, 23])
 @pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
-def test_train_step_with_the_fp16_split_product(cuda, task):
+def test_train_step_with_the_fp16_split_product(cuda, task, seed):
     """The whole co-training step with the opt-in route on, every carried range word verified against the tensor it travels
     with (RANGES.check) — parity with the oracle as in tests/test_model_gpu.py."""
     from parity import check_step_pair, run_step_pair
@@ -207,6 +208,105 @@ def test_train_step_with_the_fp16_split_product(cuda, task):
     model = build_model(mcfg).to(cuda)
     with ranges_on(ops, check=True) as R:
         R.stats = {k: 0 for k in R.stats}
-        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 256, seed=4, device=cuda)
+        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 256, seed=seed, device=cuda)
         assert R.stats['carried'] > 0 and R.stats.get('checked', 0) > 0
     check_step_pair(model, out, oout, rec, orec, P)
+
+
+def _mlp_grads(ops, x, w1, b1, w2, b2, dy, begin_between):
+    x = x.clone().requires_grad_(True)
+    ops.RANGES.begin(x.device)
+    y = ops.mlp(x, [(w1, b1), (w2, b2)], act='relu', identity=x)
+    if begin_between:
+        ops.RANGES.begin(x.device)  # a second forward / an evaluation between forward and backward starts a new generation
+        junk = torch.full((64, 64), 1e-30, device=x.device)
+        for _ in range(8):  # ... and hands the first slots to other tensors
+            ops.RANGES.of(junk, 64, 64, 64)
+            junk = junk.clone()
+    y.backward(dy)
+    ops.flush_deferred()
+    return [x.grad] + [p.grad.clone() for p in (w1, b1, w2, b2)]
+
+
+def test_range_words_do_not_outlive_their_generation(cuda):
+    """slots carried through an autograd ctx were re-stamped with the generation current at backward time.
+    With a begin() between forward and backward the words are zero or someone else's: a zero word scales the operand by 2^116
+    and the gradients came back inf / NaN.  They must equal the undisturbed run's (a measured range may differ from a carried
+    upper bound by the power of two it rounds to: the products agree to fp32 rounding, not bit for bit)."""
+    from rscotr_amd import ops
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    g = torch.Generator().manual_seed(5)
+    M, C, H = 2176, 256, 1024
+    x = torch.randn(M, C, generator=g).to(cuda)
+    dy = torch.randn(M, C, generator=g).to(cuda)
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.05).to(cuda)) for s in ((H, C), (H,), (C, H), (C,))]
+    res = {}
+    for between in (False, True):
+        for p in ps:
+            p.grad = None
+        res[between] = _mlp_grads(ops, x, *ps, dy, between)
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a).all()
+        assert _rel(a, b.cpu()) < 2e-6
+
+
+def test_pending_grouped_gradients_survive_a_new_generation(cuda):
+    """Gradient accumulation: the grouped weight-gradient problems of a first backward are still pending (their operands' slot
+    addresses held raw by DEFER) when the second forward's begin() zeroes the words."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    g = torch.Generator().manual_seed(6)
+    M, C, H = 2176, 256, 512
+    xs = [torch.randn(M, C, generator=g).to(cuda) for _ in range(2)]
+    dys = [torch.randn(M, C, generator=g).to(cuda) for _ in range(2)]
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.05).to(cuda)) for s in ((H, C), (H,), (C, H), (C,))]
+    ref = [torch.zeros_like(p) for p in ps]
+    for x, dy in zip(xs, dys):  # the reference: fp64 on the host
+        xd = x.double().cpu()
+        h = torch.relu(xd @ ps[0].detach().double().cpu().T + ps[1].detach().double().cpu())
+        gy = dy.double().cpu()
+        gh = (gy @ ps[2].detach().double().cpu()) * (h > 0)
+        for r, v in zip(ref, (gh.T @ xd, gh.sum(0), gy.T @ h, gy.sum(0))):
+            r += v.float().to(cuda)
+    opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
+    try:
+        opt.zero_grad()
+        for x, dy in zip(xs, dys):
+            ops.RANGES.begin(cuda)  # (MTL.forward does this at the start of every iteration)
+            y = ops.mlp(x, [(ps[0], ps[1]), (ps[2], ps[3])], act='relu')
+            y.backward(dy)  # no flush in between: the second begin() finds the first pass's problems pending
+        ops.flush_deferred()
+        torch.cuda.synchronize()
+        for p, r in zip(ps, ref):
+            assert torch.isfinite(p.grad).all()
+            assert _rel(p.grad, r.cpu()) < 2e-6
+    finally:
+        ops.DEFER.drop()
+        opt.close()
+
+
+def test_parameter_words_follow_every_writer_of_the_arena(cuda):
+    """only MTL.load_state_dict and FlatAdamW.restore marked the parameters' range words stale.  A submodule
+    load (nn.Module recursion never calls a child's load_state_dict), init_weights() and load_checkpoint leave them stale too —
+    and a stale-small word overflows the fp16 planes."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW, build_param_groups
+    from util import build_model, load_model_cfg
+    cfg, mcfg = load_model_cfg(tiny=True)
+    model = build_model(mcfg).to(cuda)
+    opt = FlatAdamW(build_param_groups(model, dict(type='AdamW', lr=1e-3, weight_decay=0.0)))
+    try:
+        w = model.cls_head.fc.weight if hasattr(model.cls_head, 'fc') else next(model.cls_head.parameters())
+        assert _word(ops, opt.amax_slot(w.data_ptr())) == float(w.detach().abs().max())
+        sd = {k: v * 64.0 for k, v in model.cls_head.state_dict().items()}
+        model.cls_head.load_state_dict(sd)  # a SUBMODULE load
+        assert _word(ops, opt.amax_slot(w.data_ptr())) == float(w.detach().abs().max())
+        model.init_weights()
+        for p in model.parameters():
+            if p.requires_grad and p.numel():
+                assert _word(ops, opt.amax_slot(p.data_ptr())) == float(p.detach().abs().max())
+    finally:
+        opt.close()

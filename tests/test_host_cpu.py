@@ -347,6 +347,8 @@ def test_c_abi_library_exports_every_declared_symbol():
     dll.rscotr_last_error.restype = ctypes.c_char_p
     dll.rscotr_version.restype = ctypes.c_char_p if sigs['rscotr_version'][0] is ctypes.c_char_p else ctypes.c_int
     assert dll.rscotr_version() is not None
+    # the shared object says which revision of the argument lists it was built with; the binding refuses any other
+    assert dll.rscotr_version() == _lib.header_abi_version() >= 7
     # host-side argument checking works without a device: a negative dimension is refused with a message
     dll.rscotr_gemm_f32_workspace.restype = ctypes.c_int64
     assert dll.rscotr_gemm_f32_workspace(-1, 4, 4) == 0
@@ -433,3 +435,31 @@ def test_reference_import_paths_and_train_model_signature(tmp_path):
     p.write_text("custom_imports = dict(imports=['no_such_module_xyz'], allow_failed_imports=True)\n")
     with pytest.warns(UserWarning):
         assert apply_custom_imports(Config.fromfile(str(p), import_custom_modules=False)) == []
+
+
+def test_binding_refuses_a_library_of_another_abi_revision(monkeypatch, tmp_path):
+    """A stale .so (or an A/B build picked by RSCOTR_LIB) whose entries have older argument lists must not be called."""
+    from rscotr_amd import _lib
+    hdr = tmp_path / 'rscotr.h'
+    hdr.write_text(open(_lib.HEADER).read().replace(f'#define RSCOTR_ABI_VERSION {_lib.header_abi_version()}',
+                                                     '#define RSCOTR_ABI_VERSION 9999'))
+    monkeypatch.setattr(_lib, 'HEADER', str(hdr))
+    real = _lib.header_abi_version
+    monkeypatch.setattr(_lib, 'header_abi_version', lambda path=str(hdr): real(path))
+    fresh = _lib._Lib()
+    with pytest.raises(RuntimeError, match='ABI revision'):
+        fresh.load()
+
+
+def test_rank_consistency_guard_tolerates_an_inexact_mean():
+    """The key count rides in the averaged loss vector: for a world size that is no power of two the mean of equal counts is
+    not the count in fp32 (7 keys on 6 ranks: 6.9999995).  The guard must pass there and still fail when one rank differs."""
+    import numpy as np
+    for world in (2, 3, 5, 6, 7, 8):
+        for n in (7, 13, 14, 25):
+            mean = np.float32(0)
+            for _ in range(world):
+                mean = np.float32(mean + np.float32(n) / np.float32(world))
+            assert abs(float(mean) - n) < 0.5 / world
+            other = np.float32(mean + np.float32(1) / np.float32(world))  # one rank logs one key more
+            assert not abs(float(other) - n) < 0.5 / world

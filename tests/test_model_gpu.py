@@ -4,7 +4,7 @@ bit-exact Hungarian indices.  Tolerance 1e-3 relative (BASELINE.json north_star)
 import pytest
 import torch
 
-from parity import check_step_pair, run_step_pair
+from parity import check_step_pair, ranges_checked, run_step_pair
 from util import build_model, load_model_cfg
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,9 @@ def test_train_step_main_config_512(task, prec, cuda):
     try:
         cfg, mcfg = load_model_cfg(tiny=False)
         model = build_model(mcfg, seed=4).to(cuda)
-        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda, fp64=True)
+        with ranges_checked() as R:  # (every carried / parameter range word of the iteration verified against its tensor)
+            out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda, fp64=True)
+            assert prec != 3 or not R.enabled or R.stats.get('checked', 0) > 100
     finally:
         lib.call('rscotr_gemm_set_precision', old)
     check_step_pair(model, out, oout, rec, orec, P)

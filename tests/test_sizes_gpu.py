@@ -7,7 +7,7 @@ and 1-3 minutes per case on the GPU box's cores."""
 import pytest
 import torch
 
-from parity import check_step_pair, run_step_pair
+from parity import check_step_pair, ranges_checked, run_step_pair
 from util import build_model, load_model_cfg
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +27,9 @@ def test_det_step_800_bs4_matches_oracle(cuda):
     configs/multi/MTL_slvlcls_...potsdam.py:59-112; G_i ~ U{1..50}."""
     cfg, mcfg = load_model_cfg(tiny=False)
     model = build_model(mcfg, seed=6).to(cuda)
-    out, oout, rec, orec, P = run_step_pair(model, mcfg, 'det', 800, seed=29, device=cuda, batch_size=4, max_gt=50)
+    with ranges_checked() as R:
+        out, oout, rec, orec, P = run_step_pair(model, mcfg, 'det', 800, seed=29, device=cuda, batch_size=4, max_gt=50)
+        assert not R.enabled or R.stats.get('checked', 0) > 100
     assert len(rec['match']) == 7 * 4
     assert max(len(r) for r, c in rec['match'].values()) > 20  # the batch really holds more ground truths than configs[1]'s 20
     check_step_pair(model, out, oout, rec, orec, P)
@@ -41,7 +43,8 @@ def test_swin_b_1024_step_matches_oracle(task, cuda):
     head on 256^2 stage-1 tokens)."""
     cfg, mcfg = swin_b_cfg()
     model = build_model(mcfg, seed=7).to(cuda)
-    out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 1024, seed=31, device=cuda, batch_size=1)
+    with ranges_checked():
+        out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 1024, seed=31, device=cuda, batch_size=1)
     # (median gate relative to the fp32 oracle's own distance from fp64: at this size the ORACLE's median is 2.4e-4 for det)
     check_step_pair(model, out, oout, rec, orec, P, median_rel=True)
 
