@@ -219,6 +219,28 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
                        const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
                        float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
                        const uint32_t* amax_b, uint32_t* amax_out, const void* b_planes, int b_rpad, void* stream);
+/* The two-layer FFN of the shared encoder as ONE launch (round 6, csrc/ffn.hip).  Replaces mmcv FFN (two nn.Linear around a
+ * ReLU) inside the encoder's BaseTransformerLayer — configs/multi/MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py:44-49,
+ * reached from models/multi/seg_head/pixel_decoder.py:134-146 and models/multi/bbox_head/transformer.py:211-221 — and, with
+ * gate = 1, the mirrored pair of its backward (dH = (g W2) * [h > 0], dX = dH W1):
+ *     hid = gate ? (X W1op^T) * bit : relu(X W1op^T + b1)      (M, H), stored fp32 (the weight gradients read it)
+ *     Y   = hid W2op^T + b2 (+ resid)                          (M, C)
+ * X (M, C) row-major fp32, C == 256, H % 256 == 0 (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight
+ * operands, W1op (H rows, reduction C) and W2op (C rows, reduction H), written by rscotr_gemm_split_weights_frag — table rows
+ * as rscotr_gemm_split_weights_h3 (column 5 unused); plane rows % 32 == 0, reduction % 16 == 0; layout uint4
+ * [row / 32][k / 16][h | l][lane]: the B operand of a wavefront's 32 x 32 x 16 MFMA is one contiguous 1 KB load; an entry takes
+ * rows * reduction / 8 / 256 blocks.  bits: rscotr_ffn_h3_bits_words(M, H) uint32 words, written with gate = 0 and read with
+ * gate = 1 (layout private to the kernel).  amax_x / amax_w1 / amax_w2 (required), amax_b1 (optional): range words of X, of the
+ * two weights (the ones the planes were split with) and of b1; amax_hid / amax_y (optional): range words of hid / Y, committed.
+ * The three-MFMA fp16 split product of rscotr_gemm_f32_r throughout: hid is bit-identical to what that entry computes for the
+ * first Linear; its planes for the second product are scaled from the a-priori bound C max|X| max|W1| + max|b1|. */
+int rscotr_ffn_h3_ok(int M, int C, int H);
+int64_t rscotr_ffn_h3_bits_words(int M, int H);
+int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks, void* stream);
+int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
+                  void* bits, int gate, float* Hid, const float* resid, float* Y, const uint32_t* amax_x,
+                  const uint32_t* amax_w1, const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid,
+                  uint32_t* amax_y, void* stream);
 /* > 0 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
  * product once both value ranges are supplied: callers ask before they go looking for ranges.  2: the interior pipelined
  * 64 x 64 kernel, which can take a weight operand B from pre-split planes (rscotr_gemm_f32_rb). */

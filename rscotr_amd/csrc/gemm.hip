@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmParams p) {
 // pack in one instruction), one mask + one shift for the way back and v_pk_add_f32 for the two subtractions: 9 VALU
 // instructions per pair against ~19 for two scalar splits + two packs (a VALU instruction occupies its SIMD's issue port
 // for 4 cycles: the conversion was 41 % of the 4096^3 kernel's SIMD time next to 43 % of MFMA, profiles/r3_bf16x6_pmc.txt).
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <int NPL>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[3]) {
@@ -480,19 +479,7 @@ __device__ __forceinline__ void split_rows4(const float4& e, const float4& o, ui
 // exponent; 2^27 with the scaled l).  The det step at 256^2, seed 4, then takes a ReLU gate of a decoder FFN on the other side
 // — a coin toss for any fp32-class product, but outside the band tests/parity.py flips (3e-6 of the mean |pre-activation|)
 // — and leaves the 1e-3 tier by 4e-3 on decoder layer 5.  Parity first: the two accumulator sets stay.)
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-struct H3Scale {
-  float sc, sc2;  // 2^s, 2^(s + 11)
-};
-__device__ __forceinline__ void split_pair_h(float a, float b, const H3Scale& k, unsigned (&out)[3]) {
-  const f32x2_t x = {a, b};
-  const f32x2_t y = x * k.sc, y2 = x * k.sc2;
-  const f16x2_t h = __builtin_convertvector(y, f16x2_t);
-  out[0] = __builtin_bit_cast(unsigned, h);
-  const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, y2.x), __builtin_fmaf((float)h.y, -2048.f, y2.y)};
-  out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
-}
+// (f16x2_t / f16x8 / H3Scale / split_pair_h: gemm_common.h — shared with csrc/ffn.hip)
 __device__ __forceinline__ void split_rows4_h(const float4& e, const float4& o, const H3Scale& k, uint4 (&out)[3]) {
   unsigned a[3], b[3], c[3], d[3];
   split_pair_h(e.x, o.x, k, a);

@@ -343,6 +343,23 @@ __device__ __forceinline__ unsigned pack_bf16(__bf16 a, __bf16 b) {
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
+// ---- the fp16 split ("h3") of one value pair, shared by csrc/gemm.hip and csrc/ffn.hip (the comment block in front of
+// split_rows4_h in gemm.hip describes the arithmetic)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct H3Scale {
+  float sc, sc2;  // 2^s, 2^(s + 11)
+};
+__device__ __forceinline__ void split_pair_h(float a, float b, const H3Scale& k, unsigned (&out)[3]) {
+  const f32x2_t x = {a, b};
+  const f32x2_t y = x * k.sc, y2 = x * k.sc2;
+  const f16x2_t h = __builtin_convertvector(y, f16x2_t);
+  out[0] = __builtin_bit_cast(unsigned, h);
+  const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, y2.x), __builtin_fmaf((float)h.y, -2048.f, y2.y)};
+  out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+
 // combine kernel for the split-K slabs of p (p.splits > 1): gemm.hip
 void splitk_reduce_launch(const GemmParams& p, const float* workspace, hipStream_t s);
 

@@ -33,12 +33,14 @@ class _WeightPlanes:
     def begin(self, group):
         self.current = group
         HPLANES.current = group
+        FPLANES.current = group
 
     def reset(self):
         """Forget every plane set (a new optimizer arena: addresses may be reused by other parameters)."""
         self.entries, self.groups, self.tables = {}, {}, {}
         self.version += 1
         HPLANES.reset()
+        FPLANES.reset()
 
     def bump(self, by_optimizer=False):
         """The parameters have changed.  by_optimizer: by the update kernel itself, which also rewrites their range words;
@@ -46,6 +48,7 @@ class _WeightPlanes:
         optimizer keeps stale — a stale-small word overflows the fp16 planes — so they are recomputed on next use."""
         self.version += 1
         HPLANES.version += 1
+        FPLANES.version += 1
         if not by_optimizer and STATE.grad_sink is not None:
             STATE.grad_sink.params_changed()
 
@@ -165,8 +168,48 @@ class _WeightPlanesH:
             self.entries[k]['version'] = self.version
 
 
+class _WeightPlanesF(_WeightPlanesH):
+    """FRAGMENT-MAJOR fp16 planes of the weights of a fused FFN (round 6, rscotr_gemm_split_weights_frag / rscotr_ffn_h3,
+    csrc/ffn.hip): the B operand of one wavefront's 32 x 32 x 16 MFMA as one contiguous 1 KB record.  Same life cycle as HPLANES
+    (scale of the parameter's range word at the time of the split, re-split with all of the task's sets after an optimizer step)."""
+
+    def get(self, W, tr, word):
+        """-> planes pointer for the operand Wop = W (tr = 0: plane rows = rows of W, reduction over its columns) or W^T (tr = 1)."""
+        wr, wc = W.shape
+        key = (W.data_ptr(), wr, wc, wc, int(tr))
+        e = self.entries.get(key)
+        if e is None:
+            rows, red = (wc, wr) if tr else (wr, wc)
+            assert rows % 32 == 0 and red % 16 == 0
+            e = self.entries[key] = dict(planes=torch.empty(wr * wc * 2, dtype=torch.int16, device=W.device), version=0,
+                                         blocks=(wr * wc // 8 + 255) // 256, word=int(word))
+        keys = self.groups.setdefault(self.current, [])
+        if key not in keys:
+            keys.append(key)
+        if e['version'] != self.version:
+            self._refresh(keys, W.device)
+        return e['planes'].data_ptr()
+
+    def _refresh(self, keys, dev):
+        stale = tuple(k for k in keys if self.entries[k]['version'] != self.version)
+        hit = self.tables.get(stale)
+        if hit is None:
+            import numpy as np
+            rows, first = [], 0
+            for key in stale:
+                ptr, wr, wc, ldw, tr = key
+                e = self.entries[key]
+                rows.append((ptr, e['planes'].data_ptr(), wr, wc, ldw, 0, first, tr, e['word']))
+                first += e['blocks']
+            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+        lib.call('rscotr_gemm_split_weights_frag', hit[0].data_ptr(), hit[1], hit[2], _stream())
+        for k in stale:
+            self.entries[k]['version'] = self.version
+
+
 WPLANES = _WeightPlanes()
 HPLANES = _WeightPlanesH()
+FPLANES = _WeightPlanesF()
 
 
 class _DeferredCombine:
@@ -697,6 +740,60 @@ class _ReluBits:
 RELU_BITS = _ReluBits()
 
 
+class _FusedFFN:
+    """The encoder FFN (Linear - ReLU - Linear, 256 -> H -> 256) as ONE launch per direction (rscotr_ffn_h3, csrc/ffn.hip): forward
+    y = relu(x W1^T + b1) W2^T + b2 (+ identity) with the hidden tensor leaving the kernel for the weight gradients only;
+    backward dH = (g W2) * gate, dX = dH W1 (+ g) with the mirrored call.  Taken where both weights are parameters of the
+    optimizer's arena (their planes and range words live there) and the value ranges are on."""
+
+    MIN_ROWS = int(os.environ.get('RSCOTR_FFN_FUSED_MIN_ROWS', 2048))
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_FFN_FUSED', '1') != '0'
+        self.calls = 0
+
+    def ok(self, x2, ws, act, out_scale, sum_with):
+        if not self.enabled or not RANGES.enabled or len(ws) != 2 or act != ACT_RELU or out_scale is not None or sum_with is not None:
+            return False
+        sink = STATE.grad_sink
+        (H, C), (C2, H2) = ws[0].shape, ws[1].shape
+        M = x2.shape[0]
+        if sink is None or STATE.profile is not None or C2 != C or H2 != H or M < self.MIN_ROWS or x2.data_ptr() % 16:
+            return False
+        if not (sink.is_param_ptr(ws[0].data_ptr()) and sink.is_param_ptr(ws[1].data_ptr())):
+            return False
+        return bool(lib.rscotr_ffn_h3_ok(M, C, H))
+
+    def run(self, x2, W1, b1, W2, b2, bits, gate, resid, want_y_range):
+        """gate = 0: (W1, W2) are the two Linear weights as stored, (out, in); gate = 1: the mirrored products, W1 := W2 and
+        W2 := W1 of the forward, both taken transposed.  -> (hid, y)."""
+        M, C = x2.shape
+        H = W1.shape[1] if gate else W1.shape[0]
+        dev = x2.device
+        sink = STATE.grad_sink
+        s_x = RANGES.of(x2, M, C, C)
+        s_w1, s_w2 = RANGES.of(W1, W1.shape[0], W1.shape[1], W1.shape[1]), RANGES.of(W2, W2.shape[0], W2.shape[1], W2.shape[1])
+        s_b1 = sink.amax_slot(b1.data_ptr()) if (b1 is not None and sink.is_param_ptr(b1.data_ptr())) else 0
+        if b1 is not None and not s_b1:
+            s_b1 = RANGES.of(b1.view(1, -1), 1, H, H)
+        w1f, w2f = FPLANES.get(W1, gate, s_w1), FPLANES.get(W2, gate, s_w2)
+        hid = torch.empty((M, H), dtype=torch.float32, device=dev)
+        y = torch.empty((M, C), dtype=torch.float32, device=dev)
+        s_h = RANGES.new_slot(dev)
+        RANGES.tag(hid, s_h)
+        s_y = 0
+        if want_y_range:
+            s_y = RANGES.new_slot(dev)
+            RANGES.tag(y, s_y)
+        lib.call('rscotr_ffn_h3', x2.data_ptr(), M, C, H, w1f, _ptr(b1), w2f, _ptr(b2), bits.data_ptr(), int(gate), hid.data_ptr(),
+                 _ptr(resid), y.data_ptr(), s_x, s_w1, s_w2, s_b1, s_h, s_y, _stream())
+        self.calls += 1
+        return hid, y
+
+
+FFN_FUSED = _FusedFFN()
+
+
 class _MLP(Function):
     """y = L_n(act(L_{n-1}(... act(L_1(x))))) [+ identity], L_i(h) = h W_i^T + b_i: every Linear is
     one MFMA GEMM with bias/activation/residual fused in its epilogue; backward folds act' into the
@@ -733,6 +830,15 @@ class _MLP(Function):
         # where the caller said so (ops.linear(range_out=False): qkv of a window attention, ...)
         want_last = RANGE_OUT.want(not RANGE_OUT.skip_next and id2 is None)
         RANGE_OUT.skip_next = False
+        ctx.fused = FFN_FUSED.ok(x2, ws, act, out_scale, sum_with)
+        if ctx.fused:
+            W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
+            W2 = ws[1] if ws[1].is_contiguous() else ws[1].contiguous()
+            bits = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, W1.shape[0])), dtype=torch.int32, device=x2.device)
+            hid, h = FFN_FUSED.run(x2, W1, bs[0], W2, bs[1], bits, 0, id2, want_last)
+            hs.append(hid)
+            auxs.append(bits)
+            n = 0  # (the loop below has nothing left to do)
         for i in range(n):
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
             N, K = W.shape
@@ -754,6 +860,7 @@ class _MLP(Function):
             if not last:
                 hs.append(h)
                 auxs.append(pre if pre is not None else h)  # (GELU: the pre-activation; ReLU: the gate bits, or h itself)
+        n = len(ws)
         ctx.save_for_backward(*hs, *auxs, *ws)
         ctx.h_slots = [RANGES.saved(t) for t in hs]  # ((generation, slot) of the saved activations: the weight gradients want their ranges)
         ctx.out_scale, ctx.rows_per = out_scale, rows_per
@@ -787,7 +894,8 @@ class _MLP(Function):
         grads_wb = [None] * (2 * n)
         gact = ACT_RELU_GRAD if act == ACT_RELU else ACT_GELU_GRAD
         dx = None
-        for i in range(n - 1, -1, -1):
+        def param_grads(i, g):
+            """dW_i = g^T h_i and db_i (riding the contraction) into the arena / grads_wb; -> (W_i, scr of the layer)"""
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
             N, K = W.shape
             want_w = ctx.needs_input_grad[5 + 2 * i]
@@ -823,6 +931,19 @@ class _MLP(Function):
                 colsum(g, M, N, out=rs, accumulate=rs_acc)
             if skb is not None:
                 STATE.grad_sink.grad_written(skb[0])
+            return W, scr
+
+        if getattr(ctx, 'fused', False):
+            # the mirrored pair dH = (g W2) * gate, dX = dH W1 (+ dy when the identity is the input) as ONE launch (ops.FFN_FUSED)
+            W2, _ = param_grads(1, g)
+            W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
+            dH, dx = FFN_FUSED.run(g, W2, None, W1, None, auxs[0], 1, g_out if ctx.id_is_x else None, False)
+            param_grads(0, dH)
+            dx = RANGES.carry(dx, dx.view(ctx.x_shape)) if ctx.needs_input_grad[0] else None
+            return (dx, d_id, None, None, None, *grads_wb)
+        for i in range(n - 1, -1, -1):
+            W, scr = param_grads(i, g)
+            N, K = W.shape
             if i > 0:
                 ga = ACT_RELU_GRAD_BITS if (act == ACT_RELU and auxs[i - 1].dtype == torch.int64) else gact
                 g = gemm(g, W, M, K, N, N, K, 0, 1, act=ga, aux=auxs[i - 1], **scr)  # dH = (g W) * act'

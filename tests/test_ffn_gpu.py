@@ -1,0 +1,121 @@
+"""The encoder FFN as one launch per direction (rscotr_ffn_h3, csrc/ffn.hip; ops.FFN_FUSED) against the two-product route it
+replaces and against fp64: the hidden tensor bit-identical to rscotr_gemm_f32_r's, outputs and gradients at fp32 rounding."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, ref):
+    ref = ref.double()
+    return float((a.detach().cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _setup(cuda, M, C, H, seed, bias_scale=0.5):
+    from rscotr_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C, generator=g).to(cuda)
+    dy = torch.randn(M, C, generator=g).to(cuda)
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * sc).to(cuda))
+          for s, sc in (((H, C), 0.06), ((H,), bias_scale), ((C, H), 0.03), ((C,), bias_scale))]
+    opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
+    return x, dy, ps, opt
+
+
+def _ref64(x, dy, ps, identity):
+    xd = x.double().cpu()
+    w1, b1, w2, b2 = [p.detach().double().cpu() for p in ps]
+    pre = xd @ w1.T + b1
+    h = torch.relu(pre)
+    y = h @ w2.T + b2 + (xd if identity else 0)
+    gy = dy.double().cpu()
+    gh = (gy @ w2) * (pre > 0)
+    dx = gh @ w1 + (gy if identity else 0)
+    return y, dx, (gh.T @ xd, gh.sum(0), gy.T @ h, gy.sum(0)), h
+
+
+def _run(ops, x, dy, ps, identity, fused):
+    old = ops.FFN_FUSED.enabled
+    ops.FFN_FUSED.enabled = fused
+    try:
+        for p in ps:
+            p.grad.zero_()
+        xx = x.clone().requires_grad_(True)
+        ops.RANGES.begin(x.device)
+        n0 = ops.FFN_FUSED.calls
+        y = ops.mlp(xx, [(ps[0], ps[1]), (ps[2], ps[3])], act='relu', identity=xx if identity else None)
+        y.backward(dy)
+        ops.flush_deferred()
+        torch.cuda.synchronize()
+        assert (ops.FFN_FUSED.calls - n0 == 2) == fused, 'route not taken' if fused else 'fused route taken although off'
+        return y.detach(), xx.grad.detach(), [p.grad.detach().clone() for p in ps]
+    finally:
+        ops.FFN_FUSED.enabled = old
+
+
+@pytest.mark.parametrize('M,H,identity', [(10880, 2048, True), (4352, 2048, False), (2200, 1024, True), (2049, 256, True)])
+def test_fused_ffn_matches_fp64_and_the_two_product_route(cuda, M, H, identity):
+    from rscotr_amd import ops
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    C = 256
+    x, dy, ps, opt = _setup(cuda, M, C, H, seed=M + H)
+    try:
+        y64, dx64, gp64, _ = _ref64(x, dy, ps, identity)
+        yf, dxf, gpf = _run(ops, x, dy, ps, identity, True)
+        yu, dxu, gpu = _run(ops, x, dy, ps, identity, False)
+        for got, un, ref in [(yf, yu, y64), (dxf, dxu, dx64)] + [(a, b, r) for a, b, r in zip(gpf, gpu, gp64)]:
+            assert torch.isfinite(got).all()
+            e_f, e_u = _rel(got, ref), _rel(un, ref)
+            # fp32-FMA-class error: the fused route within the bound the routed products are held to (tests/test_h3_gpu.py)
+            assert e_f <= max(1e-6, 1.5 * e_u), (e_f, e_u)
+    finally:
+        ops.DEFER.drop()
+        opt.close()
+
+
+def test_fused_ffn_hidden_is_bit_identical_to_the_product_entry(cuda):
+    """Same planes, same term order per k step: the hidden tensor the fused launch leaves for the weight gradients IS what
+    rscotr_gemm_f32_r computes for relu(x W1^T + b1) — and the gated dH of the mirrored call is what the gated product computes."""
+    from rscotr_amd import ops
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    M, C, H = 10880, 256, 2048
+    x, dy, ps, opt = _setup(cuda, M, C, H, seed=3)
+    try:
+        ops.RANGES.begin(cuda)
+        W1, b1, W2, b2 = [p.data for p in ps]
+        bits = torch.empty(int(ops.lib.rscotr_ffn_h3_bits_words(M, H)), dtype=torch.int32, device=cuda)
+        hid, y = ops.FFN_FUSED.run(x, W1, b1, W2, b2, bits, 0, None, True)
+        ref = ops.gemm(x, W1, M, H, C, C, C, 0, 0, bias=b1, act=ops.ACT_RELU)
+        assert torch.equal(hid, ref)
+        # range words: hid's is its true maximum, y's too
+        word = lambda s: float(ops.RANGES.buf[:, ops.RANGES.index(s)].view(torch.float32).max())
+        assert word(ops.RANGES.slot_of(hid)) == float(hid.abs().max())
+        assert word(ops.RANGES.slot_of(y)) == float(y.abs().max())
+        dH, dx = ops.FFN_FUSED.run(dy, W2, None, W1, None, bits, 1, None, False)
+        refH = ops.gemm(dy, W2, M, H, C, C, H, 0, 1, act=ops.ACT_RELU_GRAD, aux=ref)
+        assert torch.equal(dH, refH)
+    finally:
+        opt.close()
+
+
+def test_fused_ffn_with_a_loose_bound_keeps_fp32_accuracy(cuda):
+    """The hidden planes are scaled from C max|x| max|W1| + max|b1|, not from the hidden tensor's own maximum: one outlier in x
+    and in W1 makes the bound ~2^13 too loose for everything else — the second product must stay at fp32-class error."""
+    from rscotr_amd import ops
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    M, C, H = 4352, 256, 512
+    x, dy, ps, opt = _setup(cuda, M, C, H, seed=9, bias_scale=0.01)
+    try:
+        x[5, 7] = 90.0
+        ps[0].data[3, 100] = 6.0
+        opt.params_changed()
+        y64, dx64, gp64, _ = _ref64(x, dy, ps, True)
+        yf, dxf, gpf = _run(ops, x, dy, ps, True, True)
+        for got, ref in [(yf, y64), (dxf, dx64)] + list(zip(gpf, gp64)):
+            assert _rel(got, ref) <= 1e-6
+    finally:
+        ops.DEFER.drop()
+        opt.close()
