@@ -225,15 +225,16 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
  * gate = 1, the mirrored pair of its backward (dH = (g W2) * [h > 0], dX = dH W1):
  *     hid = gate ? (X W1op^T) * bit : relu(X W1op^T + b1)      (M, H), stored fp32 (the weight gradients read it)
  *     Y   = hid W2op^T + b2 (+ resid)                          (M, C)
- * X (M, C) row-major fp32, C == 256, H % 256 == 0 (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight
+ * X (M, C) row-major fp32, C == 256, H % 128 == 0 (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight
  * operands, W1op (H rows, reduction C) and W2op (C rows, reduction H), written by rscotr_gemm_split_weights_frag — table rows
- * as rscotr_gemm_split_weights_h3 (column 5 unused); plane rows % 32 == 0, reduction % 16 == 0; layout uint4
- * [row / 32][k / 16][h | l][lane]: the B operand of a wavefront's 32 x 32 x 16 MFMA is one contiguous 1 KB load; an entry takes
+ * as rscotr_gemm_split_weights_h3 (column 5 unused); plane rows % 16 == 0, reduction % 32 == 0; layout uint4
+ * [row / 16][k / 32][h | l][lane]: the weight operand of a wavefront's 16 x 16 x 32 MFMA is one contiguous 1 KB load; an entry takes
  * rows * reduction / 8 / 256 blocks.  bits: rscotr_ffn_h3_bits_words(M, H) uint32 words, written with gate = 0 and read with
  * gate = 1 (layout private to the kernel).  amax_x / amax_w1 / amax_w2 (required), amax_b1 (optional): range words of X, of the
  * two weights (the ones the planes were split with) and of b1; amax_hid / amax_y (optional): range words of hid / Y, committed.
- * The three-MFMA fp16 split product of rscotr_gemm_f32_r throughout: hid is bit-identical to what that entry computes for the
- * first Linear; its planes for the second product are scaled from the a-priori bound C max|X| max|W1| + max|b1|. */
+ * The three-term fp16 split product of rscotr_gemm_f32_r throughout (on 16 x 16 x 32 MFMAs: equal to that entry's results at fp32
+ * rounding, not bit for bit); the planes of hid for the second product are scaled from the a-priori bound
+ * C max|X| max|W1| + max|b1|. */
 int rscotr_ffn_h3_ok(int M, int C, int H);
 int64_t rscotr_ffn_h3_bits_words(int M, int H);
 int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks, void* stream);

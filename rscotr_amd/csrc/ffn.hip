@@ -5,37 +5,51 @@
 // configs/multi/MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py:44-49, built at models/multi/multitask_learner.py:51,
 // called from models/multi/seg_head/pixel_decoder.py:134-146 and models/multi/bbox_head/transformer.py:211-221): two
 // nn.Linear around a ReLU.  As two products (rscotr_gemm_f32_r twice) the 10880 x 2048 hidden tensor is written (89 MB), read
-// back by the second product (89 MB), and each launch pays its own ramp / drain and converts its operands again: 73 + 59 us per
-// layer forward, 65-76 + 57 us for the mirrored pair dH = (g W2) * gate, dX = dH W1 of backward — the largest block of the round.
+// back by the second product (89 MB), and each launch pays its own ramp / drain and converts its operands again: 122 us per
+// layer forward, 118 us for the mirrored pair dH = (g W2) * gate, dX = dH W1 of backward (cold operands, scripts/lab/ffn_cold.py)
+// — the largest block of the round.
 //
-// Structure.  A workgroup (512 threads = 8 wavefronts, one per CU: 144 KB of LDS) owns 64 rows.  The rows' fp16 planes
-// (h | l of the "h3" split product, gemm.hip) are staged in LDS ONCE; then, per chunk of 256 hidden columns:
-//   phase A   hidden chunk (64 x 256) = x W1[chunk]^T: wavefront w owns hidden columns 32 w .. 32 w + 31 of the chunk, both
-//             32-row tiles; A fragments from the LDS planes, B fragments straight from L2 into registers (below);
-//   epilogue  bias, ReLU (gate bits out) or gate (bits in), the fp32 chunk to global memory (the weight gradients of backward
-//             read it), its planes into LDS — the k block a wavefront writes is its own;
-//   phase B   y (64 x 256) += chunk W2[:, chunk]^T: wavefront w owns output columns 32 w .., A fragments from the chunk's planes.
-// The weights arrive as FRAGMENT-MAJOR fp16 planes (rscotr_gemm_split_weights_frag: [n tile of 32][k step of 16][h | l][lane][8
-// halfs], written once per optimizer step): the B operand of a wavefront's 32 x 32 x 16 MFMA is ONE contiguous 1 KB load, no
-// wavefront shares a fragment with another (each owns its n tile), so nothing goes through LDS and every weight byte is read
-// once per workgroup (4 MB for 256 -> 2048 -> 256; L2-resident).  A ring of eight such loads per wavefront runs ahead of the MFMAs
-// across phase and chunk boundaries.
+// Structure.  A workgroup (512 threads = 8 wavefronts, one per CU) owns BM = 32 or 48 rows (the host picks what balances the
+// 256 CUs: 10880 rows = 227 workgroups of 48).  The rows' fp16 planes (h | l of the "h3" split product, gemm.hip) are staged in
+// LDS ONCE.  Then the wavefronts split into two ROLES that work on different chunks of 128 hidden columns at the same time:
+//   wavefronts 0-3 (A)  hidden chunk c (BM x 128) = x W1[chunk]^T, 32 columns each; bias, ReLU (gate bits out) or gate (bits in);
+//                       the fp32 chunk to global memory (the weight gradients of backward read it), its planes into LDS image c % 2;
+//   wavefronts 4-7 (B)  y (BM x 256) += chunk (c - 1) W2[:, chunk]^T from LDS image (c - 1) % 2, 64 output columns each;
+// one barrier per chunk.  Every SIMD holds one wavefront of each role: while an A wavefront converts and stores its chunk
+// (VALU, LDS and memory instructions), its B partner has the matrix pipe to itself — the first version of this kernel ran both
+// phases on all eight wavefronts in lockstep and left the pipe idle for a quarter of its life (profiles/r6_ffn_lab.txt).
+// Both products are computed TRANSPOSED (the weight fragment is the MFMA's A operand, the activation fragment its B operand): a
+// lane's four accumulator registers are then four consecutive COLUMNS of one row — 16-byte stores, 8-byte LDS writes, float4
+// bias / residual loads instead of four scalar ones each.
+// The weights arrive as FRAGMENT-MAJOR fp16 planes (rscotr_gemm_split_weights_frag: [row tile of 16][k step of 32][h | l][lane][8
+// halfs], written once per optimizer step): the weight operand of a 16 x 16 x 32 MFMA is ONE contiguous 1 KB load per wavefront,
+// no wavefront shares a fragment with another, so nothing goes through LDS and every weight byte is read once per workgroup
+// (4 MB for 256 -> 2048 -> 256; L2-resident).  A ring of eight such loads per wavefront runs ahead of the MFMAs across chunks.
 //
-// Numerics: the same three-MFMA fp16 split product as gemm_h3_* (same term order per k step: the hidden chunk is BIT-IDENTICAL to
-// rscotr_gemm_f32_r's output for the first Linear).  The planes of the hidden chunk are scaled by a power of two taken from an
-// A-PRIORI bound, C * max|x| * max|W1| + max|b1| (the true maximum is only known after the last workgroup): any upper bound is a
-// valid range (ops/ranges.py); a bound 2^t too loose moves the point where the planes start to lose RELATIVE precision from
-// 2^-26 to 2^(t-26) of the maximum — below it the error is 2^-48 2^t of the maximum absolute, invisible in an fp32 product.
+// Numerics: the same three-term fp16 split product as gemm_h3_* (l h, h l into a second accumulator that enters with 2^-11; fp32
+// accumulate) — on v_mfma_f32_16x16x32_f16 instead of 32x32x16, so sums associate differently: equal to rscotr_gemm_f32_r's
+// result at fp32 rounding, not bit for bit.  The planes of the hidden chunk are scaled by a power of two taken from an A-PRIORI
+// bound, C * max|x| * max|W1| + max|b1| (the true maximum is only known after the last workgroup): any upper bound is a valid
+// range (ops/ranges.py); a bound 2^t too loose moves the point where the planes start to lose RELATIVE precision from 2^-26 to
+// 2^(t-26) of the maximum — below it the error is 2^-48 2^t of the maximum absolute, invisible in an fp32 product.
 #include "gemm_common.h"
 #include "rscotr.h"
 
 namespace rscotr {
 
-constexpr int FFN_BM = 64;    // rows per workgroup
-constexpr int FFN_HC = 256;   // hidden columns per chunk (8 wavefronts x 32)
-constexpr int FFN_LDR = 72;   // halfs per LDS row of a 32-k stage: h[32] | l[32] | 8 pad (144 bytes: conflict-free 16-byte fragment reads, as SplitOperand)
-constexpr int FFN_STAGE = FFN_BM * FFN_LDR / 2;  // dwords per 32-k stage
-constexpr int FFN_RING = 8;   // B fragment loads in flight per wavefront (= 4 k steps)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int FFN_C = 256;     // model width (reduction of the first product, columns of the second)
+constexpr int FFN_HC = 128;    // hidden columns per chunk (4 A wavefronts x 32)
+constexpr int FFN_LDRB = 160;  // bytes per LDS row of a 32-k stage: h[32] | l[32] | 32 bytes pad (conflict-free ds_read_b128 of the
+                               // 16 x 16 x 32 fragment pattern: row = lane & 15, 16 bytes at k = 8 (lane >> 4))
+#ifndef FFN_DA
+#define FFN_DA 2  // k steps (of 32) the A role's weight fragment loads run ahead of their MFMAs (4 loads each)
+#endif
+#ifndef FFN_DB
+#define FFN_DB 1  // ... the B role's (8 loads each)
+#endif
+constexpr int FFN_RING = 4 * FFN_DA > 8 * FFN_DB ? 4 * FFN_DA : 8 * FFN_DB;  // weight fragment loads in flight per wavefront
 
 struct FfnParams {
   const float* X;
@@ -52,70 +66,96 @@ struct FfnParams {
   unsigned *amax_hid, *amax_y;
 };
 
-template <int C>
-constexpr size_t ffn_lds_bytes() { return (size_t)(C / 32 + FFN_HC / 32) * FFN_STAGE * 4; }
+template <int NT>
+constexpr size_t ffn_lds_bytes() { return (size_t)(FFN_C / 32 + 2 * (FFN_HC / 32)) * (16 * NT) * FFN_LDRB; }
 
-// GATE = false: hidden = relu(x W1^T + b1), one bit per element [hidden > 0] written to p.bits; true: hidden = (x W1^T) gated by
-// the bits a forward launch of the same shape left (dH = (g W2) * [h > 0]).  Bit layout (opaque to callers, the same in both
-// directions): uint32 [row tile][chunk][wavefront][lane], bit i * 16 + r = accumulator element r of the lane's 32 x 32 tile i.
-template <int C, bool GATE>
+// 16-byte buffer store with a SCALAR offset register.  LLVM's hazard recognizer assumes that a buffer store of more than 8 bytes
+// whose soffset is an SGPR has read its data registers by the time the next instruction issues, and inserts no wait state; on
+// gfx950 that does not hold: a v_pk_mul_f32 right behind the store, allocated onto the same registers, reached memory instead of
+// the stored values in lanes 12-15 of every 16 (found by scripts/lab/ffn_debug.py: exactly the elements x 2^(s+11), the split's
+// second product).  One wait state pinned behind the store, as the ISA asks for the immediate-offset form.
+__device__ __forceinline__ void store_b128(float4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, voff, soff, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// NT: 16-row tiles per workgroup (BM = 16 NT).  GATE = false: hidden = relu(x W1^T + b1), one bit per element [hidden > 0] written
+// to p.bits; true: hidden = (x W1^T) gated by the bits a forward launch of the same shape (and NT) left (dH = (g W2) * [h > 0]).
+// Bit layout (opaque to callers, the same in both directions): uint32 [row tile][chunk][A wavefront][lane], bit
+// (it * NT + n) * 4 + r = accumulator register r of the lane's 16 x 16 tile (column tile it, row tile n).
+template <int NT, bool GATE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ffn_h3_kernel(FfnParams p) {
-  static_assert(C == 256, "phase B maps one 32-column output tile to each of the 8 wavefronts");
-  extern __shared__ __attribute__((aligned(16))) unsigned ffn_lds[];
-  constexpr int KS1 = C / 16, KS2 = FFN_HC / 16, XST = C / 32;
-  constexpr int D = FFN_RING;
-  static_assert((2 * KS1) % D == 0 && (2 * KS2) % D == 0, "the ring position is static across phases");
-  unsigned* xs = ffn_lds;
-  unsigned* hs = ffn_lds + XST * FFN_STAGE;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 31, g = lane >> 5;
-  const int m0 = blockIdx.x * FFN_BM;
-  const int nchunks = p.H / FFN_HC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
+  constexpr int C = FFN_C, BM = 16 * NT, STG = BM * FFN_LDRB;  // bytes per 32-k stage of a plane image
+  constexpr int XST = C / 32, HST = FFN_HC / 32;
+  unsigned char* xs = ffn_lds;                    // [XST][BM][160]
+  unsigned char* hs = ffn_lds + XST * STG;        // [2][HST][BM][160]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (provably uniform: the role branches below must be scalar branches)
+  const bool role_a = wv < 4;
+  const int wr = wv & 3;
+  const int m0 = blockIdx.x * BM;
+  const int nch = p.H / FFN_HC;
 
   // value-range words: requested first, reduced after the operand loads have been requested too (cold lines)
   const long sub = (long)(lane & (kAmaxPlanes - 1)) * kAmaxStride;
   const unsigned rx = p.amax_x[sub], r1 = p.amax_w1[sub], r2 = p.amax_w2[sub], rb = p.amax_b1 ? p.amax_b1[sub] : 0u;
 
-  // B fragments: ring of D loads; sequence A(0) B(0) A(1) B(1) ... of 2 * KS loads each
-  // (buffer loads: ONE address register per weight — the lane's and the wavefront's part — and the chunk / k-step part as a scalar
-  //  offset; with flat pointers the unrolled loop kept a 64-bit address per load alive and spilled)
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.W1f), 0, p.H * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.W2f), 0, p.H * C * 4, 0x00020000);
-  const int vA = (w * KS1 * 128 + lane) * 16;           // chunk c: + c * 8 * KS1 * 2048 bytes
-  const int vB = (w * (p.H / 16) * 128 + lane) * 16;    // chunk c: + c * KS2 * 2048 bytes
-  auto ldA = [&](int c, int j) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA, c * (8 * KS1 * 2048) + j * 1024, 0)); };
-  auto ldB = [&](int c, int j) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, c * (KS2 * 2048) + j * 1024, 0)); };
-  uint4 ring[D];
+  // weight fragments: buffer loads — ONE address register per wavefront (its lane and its tiles), the chunk / k step as a scalar
+  // offset.  A: tile = c * 8 + wr * 2 + it of W1op (H rows, 8 k steps);  B: tile = wr * 4 + it of W2op (256 rows, H / 32 k steps)
+  const int wbytes = p.H * C * 4;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(role_a ? p.W1f : p.W2f), 0, wbytes, 0x00020000);
+  const int nks2 = p.H / 32;
+  const int vW = lane * 16 + (role_a ? wr * 2 * XST * 2048 : wr * 4 * nks2 * 2048);
+  // load q (0 .. 7) of "step" t: A: t = c * 8 + ks (ks 0 .. 7), q = (t & 1) * 4 + it * 2 + pl  [4 loads per k step, ring = 2 k steps]
+  //                              B: t = c * 4 + ks (ks 0 .. 3), q = it * 2 + pl              [8 loads per k step, ring = 1 k step]
+  auto ld_a = [&](int t, int it, int pl) {  // t: global k-step index c * 8 + ks, clamped by the caller
+    const int c = t >> 3, ks = t & 7;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, c * (8 * XST * 2048) + it * (XST * 2048) + ks * 2048 + pl * 1024, 0));
+  };
+  auto ld_b = [&](int t, int it, int pl) {  // t: global k-step index c * 4 + ks = the k step of W2op
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, it * nks2 * 2048 + t * 2048 + pl * 1024, 0));
+  };
+  uint4 ring[FFN_RING];
+  if (role_a) {
 #pragma unroll
-  for (int j = 0; j < D; ++j) ring[j] = ldA(0, j);
-  // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores — no
-  // per-element guards (which cost a branch and a live 64-bit address per store of the chunk epilogue)
-  const int rows_ok = min(FFN_BM, p.M - m0);
+    for (int q = 0; q < 4 * FFN_DA; ++q) ring[q] = ld_a(min(q >> 2, nch * 8 - 1), (q >> 1) & 1, q & 1);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8 * FFN_DB; ++q) ring[q] = ld_b(min(q >> 3, nch * 4 - 1), (q >> 1) & 3, q & 1);
+  }
+
+  // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores
+  const int rows_ok = min(BM, p.M - m0);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.Hid + (long)m0 * p.H, 0, rows_ok * p.H * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * C : p.X), 0, rows_ok * C * 4, 0x00020000);
 
-  // the rows' planes -> LDS
+  // the rows' planes -> LDS (all eight wavefronts)
   {
-    constexpr int Q = C / 4, NV = FFN_BM * Q / 512;
+    constexpr int NV = BM * (C / 4) / 512;
     float4 v[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 512;  // (rows past M: out of the descriptor's range, zeros)
-      v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, idx * 16, 0, 0));
-    }
-    const int ex = h3_scale_exp(amax_fold(rx));
-    const H3Scale hx{__uint_as_float((unsigned)ex << 23), __uint_as_float((unsigned)(ex + 11) << 23)};
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (tid + i * 512) * 16, 0, 0));
+    const int ex0 = h3_scale_exp(amax_fold(rx));
+    const H3Scale hx{__uint_as_float((unsigned)ex0 << 23), __uint_as_float((unsigned)(ex0 + 11) << 23)};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 512;
-      const int row = idx / Q, kq = (idx % Q) * 4;
+      const int row = idx / (C / 4), kq = (idx % (C / 4)) * 4;
       unsigned ab[3], cd[3];
       split_pair_h(v[i].x, v[i].y, hx, ab);
       split_pair_h(v[i].z, v[i].w, hx, cd);
-      unsigned* dst = xs + (kq / 32) * FFN_STAGE + (row * FFN_LDR + (kq % 32)) / 2;
+      unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
       *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
-      *reinterpret_cast<uint2*>(dst + 16) = make_uint2(ab[1], cd[1]);
+      *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
     }
   }
   const unsigned ux = amax_fold(rx), u1 = amax_fold(r1), u2 = amax_fold(r2), ub = amax_fold(rb);
@@ -127,118 +167,225 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float invx = __uint_as_float((unsigned)(254 - ex) << 23), inv1 = __uint_as_float((unsigned)(254 - e1) << 23);
   const float invh = __uint_as_float((unsigned)(254 - eh) << 23), inv2 = __uint_as_float((unsigned)(254 - e2) << 23);
 
-  f32x16 ya[2], yb[2];  // y tiles (rows 32 i .., columns 32 w ..): h h terms / (l h + h l) 2^11
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ya[i][r] = 0.f; yb[i][r] = 0.f; }
-  float amx = 0.f;
+  const int fo = li * FFN_LDRB + kg * 16;  // the lane's part of a fragment address: row li of a 16-row tile, 16 bytes at k = 8 kg
   __syncthreads();
 
-  // Four k steps (64 k) of a phase: A fragments of both 32-row tiles from the plane image S (lane part of the address in `lo`), the
-  // eight ring entries as B fragments, each replaced by the load eight positions ahead (LAST: the first eight of the next phase).
-  // The k loop runs over such groups (not fully unrolled: the scheduler hoisted every fragment read of an unrolled phase to its
-  // top and spilled a hundred registers).
-  const int lo = (fr * FFN_LDR + 8 * g) / 2;  // dwords
-  auto steps4 = [&](const unsigned* S, int kg, f32x16 (&ta)[2], f32x16 (&tb)[2], auto ld_cur, auto ld_next, bool last) {
-    const unsigned* q0 = S + (kg >> 1) * FFN_STAGE + lo;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f16x8 ah[2], al[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned* q = q0 + (u >> 1) * FFN_STAGE + (i * 32 * FFN_LDR + 16 * (u & 1)) / 2;
-        ah[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q));
-        al[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q + 16));
-      }
-      const f16x8 bh = __builtin_bit_cast(f16x8, ring[2 * u]), bl = __builtin_bit_cast(f16x8, ring[2 * u + 1]);
-      if (last) {
-        ring[2 * u] = ld_next(2 * u);
-        ring[2 * u + 1] = ld_next(2 * u + 1);
-      } else {
-        ring[2 * u] = ld_cur(2 * kg + 2 * u + D);
-        ring[2 * u + 1] = ld_cur(2 * kg + 2 * u + 1 + D);
-      }
-      // term order of gemm_h3_*: l h, h l into the second accumulator, h h into the first
-#pragma unroll
-      for (int i = 0; i < 2; ++i) tb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, tb[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) tb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, tb[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) ta[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, ta[i], 0, 0, 0);
-    }
-  };
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int cn = min(c + 1, nchunks - 1);  // (past the last chunk: a harmless re-read)
-    auto a_cur = [&](int j) { return ldA(c, j); };
-    auto b_cur = [&](int j) { return ldB(c, j); };
-    auto a_next = [&](int j) { return ldA(cn, j); };
-    // ---- phase A
-    f32x16 ha[2], hb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { ha[i][r] = 0.f; hb[i][r] = 0.f; }
+  // The two roles are separate code paths (a scalar branch: wv is wave-uniform by construction), each with its own loop and its
+  // own nch + 1 barriers — A: [chunk c -> image c % 2; barrier] x nch, barrier;  B: barrier, [image c % 2 -> y; barrier] x nch — so
+  // that neither role's accumulators are live in the other's code (one loop with both roles inside kept 96 + 48 of them alive).
+  if (role_a) {
+#ifdef FFN_PRIO_A
+    __builtin_amdgcn_s_setprio(FFN_PRIO_A);
+#endif
+    unsigned amxu = 0u;
+    // (Measured and not kept, profiles/r6_ffn_lab.txt: the fp32 chunk held in registers and stored half a chunk later, so that the
+    //  weight loads issued behind the stores are not the next ones waited for — 92.7 against 86-89 us: the stores' wait states
+    //  and scheduling barriers inside the k loop cost more than the in-order completion they avoid.)
+    const int vH = (li * p.H + wr * 32 + 4 * kg) * 4;
 #pragma unroll 1
-    for (int kg = 0; kg < KS1 - 4; kg += 4) steps4(xs, kg, ha, hb, a_cur, b_cur, false);
-    steps4(xs, KS1 - 4, ha, hb, a_cur, b_cur, true);
-    __syncthreads();  // every wavefront has finished phase B of the previous chunk: the chunk image is free
-    // ---- epilogue of the chunk: column n of the hidden tensor = k of phase B, k block w of the image is this wavefront's
-    {
-      const int n = c * FFN_HC + w * 32 + fr;
-      const int vH = (4 * g * p.H + n) * 4;
-      const float bv = (!GATE && p.b1) ? p.b1[n] : 0.f;
-      const long widx = (((long)blockIdx.x * nchunks + c) * 8 + w) * 64 + lane;
-      unsigned bits = GATE ? p.bits[widx] : 0u;
-      unsigned short* img = reinterpret_cast<unsigned short*>(hs + w * FFN_STAGE);
+    for (int c = 0; c < nch; ++c) {
+      {
+        // ---- hidden chunk c: columns c * 128 + wr * 32 + it * 16 .., all rows; 8 k steps of 32 in pairs (ring position static)
+        f32x4_t ha[2][NT], hb[2][NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          float v = fmaf(hb[i][r], 0x1p-11f, ha[i][r]) * invx * inv1;
-          if (!GATE) {
-            v = fmaxf(v + bv, 0.f);
-            bits |= (unsigned)(v > 0.f) << (i * 16 + r);
-          } else {
-            v = ((bits >> (i * 16 + r)) & 1u) ? v : 0.f;
-          }
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rH, vH, (i * 32 + (r & 3) + 8 * (r >> 2)) * p.H * 4, 0);
-          amx = fmaxf(amx, fabsf(v));
-          const float y = v * hh.sc;
-          const _Float16 h16 = (_Float16)y;
-          const _Float16 l16 = (_Float16)fmaf((float)h16, -2048.f, v * hh.sc2);
-          img[row * FFN_LDR + fr] = __builtin_bit_cast(unsigned short, h16);
-          img[row * FFN_LDR + 32 + fr] = __builtin_bit_cast(unsigned short, l16);
+          for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        const int tmax = nch * 8 - 1;
+#ifdef FFN_LDS_PREFETCH
+        // the activation fragments of k step ks + 1 are requested before the MFMAs of k step ks (the image is the same for every
+        // chunk: the last step requests step 0 of the next chunk)
+        uint4 xf[2][2 * NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const unsigned char* q = xs + n * 16 * FFN_LDRB + fo;
+          xf[0][2 * n] = *reinterpret_cast<const uint4*>(q);
+          xf[0][2 * n + 1] = *reinterpret_cast<const uint4*>(q + 64);
         }
-      if (!GATE) p.bits[widx] = bits;
+#endif
+#pragma unroll 1
+        for (int kp = 0; kp < 8 / FFN_DA; ++kp) {
+#pragma unroll
+          for (int u = 0; u < FFN_DA; ++u) {
+            const int ks = kp * FFN_DA + u;
+            uint4 xh[NT], xl[NT];
+#ifdef FFN_LDS_PREFETCH
+            static_assert(FFN_DA % 2 == 0, "the fragment double buffer alternates with the k step");
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const unsigned char* q = xs + ((ks + 1) & 7) * STG + n * 16 * FFN_LDRB + fo;
+              xf[(u + 1) & 1][2 * n] = *reinterpret_cast<const uint4*>(q);
+              xf[(u + 1) & 1][2 * n + 1] = *reinterpret_cast<const uint4*>(q + 64);
+              xh[n] = xf[u & 1][2 * n];
+              xl[n] = xf[u & 1][2 * n + 1];
+            }
+#elif defined(FFN_ABL_NOLDS)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              xh[n] = make_uint4(0x3c003c00u + ks, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + n);
+              xl[n] = make_uint4(0x1c001c00u + ks, 0x1c001c00u, 0x1c001c00u, 0x1c001c00u + n);
+              asm volatile("" : "+v"(xh[n].x), "+v"(xl[n].x));
+            }
+#else
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const unsigned char* q = xs + ks * STG + n * 16 * FFN_LDRB + fo;
+              xh[n] = *reinterpret_cast<const uint4*>(q);
+              xl[n] = *reinterpret_cast<const uint4*>(q + 64);
+            }
+#endif
+            const int tn = min(c * 8 + ks + FFN_DA, tmax);  // FFN_DA k steps ahead (past the end: a harmless re-read)
+            // terms of gemm_h3_*: l h, h l into the second accumulator, h h into the first (weight = the MFMA's A operand).  A ring
+            // slot is refilled AFTER its last use, into the same registers (refilling it first made the compiler rotate the ring
+            // through copies, and every copy waits for the load it copies: the pipeline drained once per k step)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const uint4 wh = ring[u * 4 + it * 2], wl = ring[u * 4 + it * 2 + 1];
+#pragma unroll
+              for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wh, xl[n], hb[it][n]);
+#pragma unroll
+              for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wl, xh[n], hb[it][n]);
+#pragma unroll
+              for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
+#ifndef FFN_ABL_NOB
+              ring[u * 4 + it * 2] = ld_a(tn, it, 0);
+              ring[u * 4 + it * 2 + 1] = ld_a(tn, it, 1);
+#else
+              asm volatile("" : "+v"(ring[u * 4 + it * 2].x), "+v"(ring[u * 4 + it * 2 + 1].x) : "s"(tn));
+#endif
+            }
+          }
+        }
+        // ---- epilogue of the chunk: the lane holds columns col0 .. col0 + 3 of row n * 16 + li for every (it, n)
+#ifdef FFN_ABL_NOEPI
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(ha[it][n]), "v"(hb[it][n]));
+        if (false) {
+#else
+        {
+#endif
+        const long widx = (((long)blockIdx.x * nch + c) * 4 + wr) * 64 + lane;
+        unsigned bits = GATE ? p.bits[widx] : 0u;
+        unsigned char* img = hs + (c & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8;  // k block wr of the image is this wavefront's
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!GATE && p.b1) bv = *reinterpret_cast<const float4*>(p.b1 + c * FFN_HC + wr * 32 + it * 16 + 4 * kg);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(hb[it][n][r], 0x1p-11f, ha[it][n][r]) * invx * inv1;
+            if (!GATE) {
+              // relu as compare + select (fmaxf canonicalises its operands: a v_cmp_class + v_cndmask per element on top of the
+              // v_max); the compare is the gate bit
+              const float t[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const bool pos = t[r] > 0.f;
+                v[r] = pos ? t[r] : 0.f;
+                bits |= (unsigned)pos << ((it * NT + n) * 4 + r);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, (it * NT + n) * 4 + r, 1));
+            }
+#ifndef FFN_ABL_NOHID  // (FFN_ABL_*: timing ablations of scripts/lab/ffn_abl.sh — results are wrong with any of them)
+            store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, (n * 16 * p.H + c * FFN_HC + it * 16) * 4);
+#endif
+#pragma unroll
+            for (int r = 0; r < 4; ++r) amxu = max(amxu, __float_as_uint(v[r]) & 0x7fffffffu);  // (bit patterns of |v| order like the values)
+            unsigned ab[3], cd[3];
+            split_pair_h(v[0], v[1], hh, ab);
+            split_pair_h(v[2], v[3], hh, cd);
+#ifndef FFN_ABL_NOIMG
+            unsigned char* dst = img + n * 16 * FFN_LDRB + it * 32;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+            *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+#else
+            asm volatile("" ::"v"(ab[0]), "v"(ab[1]), "v"(cd[0]), "v"(cd[1]));
+#endif
+          }
+        }
+        if (!GATE) p.bits[widx] = bits;
+        }
+      }
+      __syncthreads();  // image c % 2 is complete
     }
     __syncthreads();
-    // ---- phase B
+    amax_commit(p.amax_hid, __uint_as_float(amxu));
+  } else {
+#ifdef FFN_PRIO_B
+    __builtin_amdgcn_s_setprio(FFN_PRIO_B);
+#endif
+    f32x4_t ya[4][NT], yb[4][NT];  // y tiles: columns wr * 64 + it * 16 .., rows n * 16 ..
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { ya[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; yb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();
 #pragma unroll 1
-    for (int kg = 0; kg < KS2 - 4; kg += 4) steps4(hs, kg, ya, yb, b_cur, a_next, false);
-    steps4(hs, KS2 - 4, ya, yb, b_cur, a_next, true);
-  }
-  amax_commit(p.amax_hid, amx);
-
-  // ---- y = (h h + (l h + h l) 2^-11) 2^-(s_hidden + s_w2) + b2 (+ resid)
-  {
-    const int n = w * 32 + fr;
-    const int vY = (4 * g * C + n) * 4;
-    const float bv = p.b2 ? p.b2[n] : 0.f;
+    for (int c = 0; c < nch; ++c) {
+      // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32, columns wr * 64 + it * 16 ..
+      const unsigned char* img = hs + (c & 1) * (HST * STG) + fo;
+      const int tmax = nch * 4 - 1;
+#ifndef FFN_ABL_NOPHASEB
+#pragma unroll 1
+      for (int kq = 0; kq < 4 / FFN_DB; ++kq)
+#pragma unroll
+      for (int u = 0; u < FFN_DB; ++u) {
+        const int ks = kq * FFN_DB + u;
+        uint4 gh[NT], gl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const unsigned char* q = img + ks * STG + n * 16 * FFN_LDRB;
+          gh[n] = *reinterpret_cast<const uint4*>(q);
+          gl[n] = *reinterpret_cast<const uint4*>(q + 64);
+        }
+        const int tn = min(c * 4 + ks + FFN_DB, tmax);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const uint4 wh = ring[u * 8 + it * 2], wl = ring[u * 8 + it * 2 + 1];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wh, gl[n], yb[it][n]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wl, gh[n], yb[it][n]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) ya[it][n] = mfma16(wh, gh[n], ya[it][n]);
+#ifndef FFN_ABL_NOB
+          ring[u * 8 + it * 2] = ld_b(tn, it, 0);  // (after the slot's last use: see the A role)
+          ring[u * 8 + it * 2 + 1] = ld_b(tn, it, 1);
+#else
+          asm volatile("" : "+v"(ring[u * 8 + it * 2].x), "+v"(ring[u * 8 + it * 2 + 1].x) : "s"(tn));
+#endif
+        }
+      }
+#endif
+      __syncthreads();  // image c % 2 has been consumed
+    }
+    // ---- y = (h h + (l h + h l) 2^-11) 2^-(s_hidden + s_w2) + b2 (+ resid): four consecutive columns of a row per lane
+    const int vY = (li * C + wr * 64 + 4 * kg) * 4;
     float amy = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float e[16];
+    for (int it = 0; it < 4; ++it) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.b2) bv = *reinterpret_cast<const float4*>(p.b2 + wr * 64 + it * 16 + 4 * kg);
+      float4 e[NT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        e[r] = p.resid ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, vY, (i * 32 + (r & 3) + 8 * (r >> 2)) * C * 4, 0)) : 0.f;
+      for (int n = 0; n < NT; ++n)
+        e[n] = p.resid ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, vY, (n * 16 * C + it * 16) * 4, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = fmaf(yb[i][r], 0x1p-11f, ya[i][r]) * invh * inv2 + bv + e[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rY, vY, (i * 32 + (r & 3) + 8 * (r >> 2)) * C * 4, 0);
-        amy = fmaxf(amy, fabsf(v));
+      for (int n = 0; n < NT; ++n) {
+        float4 v;
+        v.x = fmaf(yb[it][n][0], 0x1p-11f, ya[it][n][0]) * invh * inv2 + bv.x + e[n].x;
+        v.y = fmaf(yb[it][n][1], 0x1p-11f, ya[it][n][1]) * invh * inv2 + bv.y + e[n].y;
+        v.z = fmaf(yb[it][n][2], 0x1p-11f, ya[it][n][2]) * invh * inv2 + bv.z + e[n].z;
+        v.w = fmaf(yb[it][n][3], 0x1p-11f, ya[it][n][3]) * invh * inv2 + bv.w + e[n].w;
+        store_b128(v, rY, vY, (n * 16 * C + it * 16) * 4);
+        amy = amax4(amy, v);
       }
     }
     amax_commit(p.amax_y, amy);
@@ -248,9 +395,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Fragment-major fp16 planes of a weight for ffn_h3_kernel (rscotr_gemm_split_weights_frag): table rows {W, planes, rows of W,
 // cols of W, ldw, 0, first block, transposed, range word of the parameter} (int64 x 9, as rscotr_gemm_split_weights_h3).
 // transposed = 0: plane rows n = rows of W, reduction k over its columns (y = x W^T); 1: plane rows = columns of W, reduction over
-// its rows (dx = dy W).  Layout: uint4 [n / 32][k / 16][h | l][lane], lane l holding k = 16 ks + 8 (l >> 5) .. + 7 of row
-// n = 32 nt + (l & 31) — the B operand of v_mfma_f32_32x32x16_f16, one contiguous 1 KB load per wavefront.  Plane rows % 32 == 0,
-// reduction % 16 == 0 (host-checked); one thread per (n tile, k step, lane): 8 values in, two 16-byte records out.
+// its rows (dx = dy W).  Layout: uint4 [n / 16][k / 32][h | l][lane], lane l holding k = 32 ks + 8 (l >> 4) .. + 7 of row
+// n = 16 nt + (l & 15) — one operand of v_mfma_f32_16x16x32_f16, one contiguous 1 KB load per wavefront.  Plane rows % 16 == 0,
+// reduction % 32 == 0 (host-checked); one thread per (row tile, k step, lane): 8 values in, two 16-byte records out.
 __global__ __launch_bounds__(256) void split_weights_frag_kernel(const int64_t* __restrict__ table, int n_entries) {
   int e = 0;
   while (e + 1 < n_entries && (long)table[(long)(e + 1) * 9 + 6] <= (long)blockIdx.x) ++e;
@@ -262,12 +409,12 @@ __global__ __launch_bounds__(256) void split_weights_frag_kernel(const int64_t* 
   const int se = h3_scale_exp(amax_read(reinterpret_cast<const unsigned*>(t[8])));
   const H3Scale hs{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(se + 11) << 23)};
   const long idx = ((long)blockIdx.x - t[6]) * 256 + threadIdx.x;
-  const int nks = red / 16;
+  const int nks = red / 32;
   const int lane = (int)(idx & 63);
   const long rest = idx >> 6;
   const int ks = (int)(rest % nks), nt = (int)(rest / nks);
-  if (nt >= rows / 32) return;
-  const int n = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+  if (nt >= rows / 16) return;
+  const int n = nt * 16 + (lane & 15), k0 = ks * 32 + 8 * (lane >> 4);
   float v[8];
   if (!tr) {
     const float4* src = reinterpret_cast<const float4*>(W + (long)n * ldw + k0);
@@ -299,34 +446,51 @@ extern "C" int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int t
   return check_launch("split_weights_frag");
 }
 
-extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) { return (C == 256 && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0; }
+// rows per workgroup: what leaves the fewest rounds x rows on 256 CUs (one workgroup per CU); 48 on ties (fewer weight reads)
+static int ffn_rows(int M) {
+  const long c48 = ((long)((M + 47) / 48) + 255) / 256 * 48, c32 = ((long)((M + 31) / 32) + 255) / 256 * 32;
+  return c32 < c48 ? 32 : 48;
+}
 
-extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int H) { return (int64_t)((M + FFN_BM - 1) / FFN_BM) * (H / FFN_HC) * 512; }
+extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) { return (C == FFN_C && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0; }
+
+extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int H) {
+  const int bm = ffn_rows(M);
+  return (int64_t)((M + bm - 1) / bm) * (H / FFN_HC) * 256;
+}
+
+template <int NT>
+static void ffn_launch(const FfnParams& p, int gate, hipStream_t s) {
+  constexpr size_t lds = ffn_lds_bytes<NT>();
+  static bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return true;
+  }();
+  (void)attr_set;
+  const dim3 grid((unsigned)((p.M + 16 * NT - 1) / (16 * NT)));
+  if (gate) hipLaunchKernelGGL((ffn_h3_kernel<NT, true>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((ffn_h3_kernel<NT, false>), grid, dim3(512), lds, s, p);
+}
 
 extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
                              void* bits, int gate, float* Hid, const float* resid, float* Y, const uint32_t* amax_x,
                              const uint32_t* amax_w1, const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid,
                              uint32_t* amax_y, void* stream) {
-  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C == 256, H %% 256 == 0)", M, C, H);
+  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C == 256, H %% 128 == 0)", M, C, H);
   if (!X || !W1f || !W2f || !bits || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
-  if (((uintptr_t)X | (uintptr_t)W1f | (uintptr_t)W2f) & 15) return fail(RSCOTR_E_ALIGN, "ffn_h3: operands must be 16-byte aligned");
+  if (((uintptr_t)X | (uintptr_t)W1f | (uintptr_t)W2f | (uintptr_t)Hid | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)b1 | (uintptr_t)b2) & 15)
+    return fail(RSCOTR_E_ALIGN, "ffn_h3: operands must be 16-byte aligned");
+  if ((long)M * H * 4 >= (1l << 32)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M * H too large for 32-bit buffer offsets");
   FfnParams p{};
   p.X = X; p.M = M; p.H = H;
-  p.W1f = static_cast<const uint4*>(W1f); p.b1 = b1;
+  p.W1f = static_cast<const uint4*>(W1f); p.b1 = gate ? nullptr : b1;
   p.W2f = static_cast<const uint4*>(W2f); p.b2 = b2;
   p.bits = static_cast<unsigned*>(bits); p.Hid = Hid; p.resid = resid; p.Y = Y;
   p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = gate ? nullptr : amax_b1;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
-  constexpr size_t lds = ffn_lds_bytes<256>();
-  static bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return true;
-  }();
-  (void)attr_set;
-  const dim3 grid((unsigned)((M + FFN_BM - 1) / FFN_BM));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (gate) hipLaunchKernelGGL((ffn_h3_kernel<256, true>), grid, dim3(512), lds, s, p);
-  else hipLaunchKernelGGL((ffn_h3_kernel<256, false>), grid, dim3(512), lds, s, p);
+  if (ffn_rows(M) == 32) ffn_launch<2>(p, gate, s);
+  else ffn_launch<3>(p, gate, s);
   return check_launch("ffn_h3");
 }

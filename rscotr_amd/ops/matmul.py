@@ -170,7 +170,7 @@ class _WeightPlanesH:
 
 class _WeightPlanesF(_WeightPlanesH):
     """FRAGMENT-MAJOR fp16 planes of the weights of a fused FFN (round 6, rscotr_gemm_split_weights_frag / rscotr_ffn_h3,
-    csrc/ffn.hip): the B operand of one wavefront's 32 x 32 x 16 MFMA as one contiguous 1 KB record.  Same life cycle as HPLANES
+    csrc/ffn.hip): the weight operand of one wavefront's 16 x 16 x 32 MFMA as one contiguous 1 KB record.  Same life cycle as HPLANES
     (scale of the parameter's range word at the time of the split, re-split with all of the task's sets after an optimizer step)."""
 
     def get(self, W, tr, word):
@@ -180,7 +180,7 @@ class _WeightPlanesF(_WeightPlanesH):
         e = self.entries.get(key)
         if e is None:
             rows, red = (wc, wr) if tr else (wr, wc)
-            assert rows % 32 == 0 and red % 16 == 0
+            assert rows % 16 == 0 and red % 32 == 0
             e = self.entries[key] = dict(planes=torch.empty(wr * wc * 2, dtype=torch.int16, device=W.device), version=0,
                                          blocks=(wr * wc // 8 + 255) // 256, word=int(word))
         keys = self.groups.setdefault(self.current, [])

@@ -11,7 +11,9 @@ from rscotr_amd._lib import lib  # noqa: E402
 from rscotr_amd.optim import FlatAdamW  # noqa: E402
 
 dev = torch.device('cuda:0')
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 10880
+only_fused = 'fused' in sys.argv[1:]
+args = [a for a in sys.argv[1:] if a != 'fused']
+M = int(args[0]) if args else 10880
 C, H = 256, 2048
 
 
@@ -65,7 +67,7 @@ res = dict(M=M, C=C, H=H, nsets=nsets)
 relu_ok = ops.RELU_BITS.ok(M, H, C, C)
 res['relu_bits_unfused'] = bool(relu_ok)
 for name, f in (('fwd_fused', fwd_fused), ('bwd_fused', bwd_fused), ('fwd_unfused', fwd_unfused), ('bwd_unfused', bwd_unfused)):
-    if 'unfused' in name and not relu_ok:
+    if 'unfused' in name and (not relu_ok or only_fused):
         continue
     res[name + '_us'] = round(run([lambda i=i: f(i) for i in range(nsets)]), 1)
     res[name + '_warm_us'] = round(run([lambda: f(0)] * 6), 1)
