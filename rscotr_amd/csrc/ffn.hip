@@ -392,6 +392,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// (Measured and removed, profiles/r6_ffn_lab.txt: the same machinery for the ONE-product 256-wide Linears of the encoder — value /
+//  output projections, offsets | logits, their input gradients; rows' planes staged once, weight fragments from fragment-major
+//  planes, 16-byte stores — 12.9 us per 10880 x 256 x 256 launch against 14.1 for the tiled 64 x 64 kernel in the cold lab, but
+//  31.22 against 31.06 ms per round in the step: with one product per launch there is nothing to overlap the staging phase with.)
+
 // Fragment-major fp16 planes of a weight for ffn_h3_kernel (rscotr_gemm_split_weights_frag): table rows {W, planes, rows of W,
 // cols of W, ldw, 0, first block, transposed, range word of the parameter} (int64 x 9, as rscotr_gemm_split_weights_h3).
 // transposed = 0: plane rows n = rows of W, reduction k over its columns (y = x W^T); 1: plane rows = columns of W, reduction over
@@ -494,3 +499,4 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   else ffn_launch<3>(p, gate, s);
   return check_launch("ffn_h3");
 }
+

@@ -176,18 +176,22 @@ class _WeightPlanesF(_WeightPlanesH):
     def get(self, W, tr, word):
         """-> planes pointer for the operand Wop = W (tr = 0: plane rows = rows of W, reduction over its columns) or W^T (tr = 1)."""
         wr, wc = W.shape
-        key = (W.data_ptr(), wr, wc, wc, int(tr))
+        return self.get_raw(W.data_ptr(), wr, wc, tr, word, W.device)
+
+    def get_raw(self, ptr, wr, wc, tr, word, device):
+        """... of the contiguous (wr, wc) matrix at `ptr` (a parameter or a row block of one)."""
+        key = (ptr, wr, wc, wc, int(tr))
         e = self.entries.get(key)
         if e is None:
             rows, red = (wc, wr) if tr else (wr, wc)
             assert rows % 16 == 0 and red % 32 == 0
-            e = self.entries[key] = dict(planes=torch.empty(wr * wc * 2, dtype=torch.int16, device=W.device), version=0,
+            e = self.entries[key] = dict(planes=torch.empty(wr * wc * 2, dtype=torch.int16, device=device), version=0,
                                          blocks=(wr * wc // 8 + 255) // 256, word=int(word))
         keys = self.groups.setdefault(self.current, [])
         if key not in keys:
             keys.append(key)
         if e['version'] != self.version:
-            self._refresh(keys, W.device)
+            self._refresh(keys, device)
         return e['planes'].data_ptr()
 
     def _refresh(self, keys, dev):
