@@ -13,8 +13,9 @@
 // 256 CUs: 10880 rows = 227 workgroups of 48).  The rows' fp16 planes (h | l of the "h3" split product, gemm.hip) are staged in
 // LDS ONCE.  Then the wavefronts split into two ROLES that work on different chunks of 128 hidden columns at the same time:
 //   wavefronts 0-3 (A)  hidden chunk c (BM x 128) = x W1[chunk]^T, 32 columns each; bias, ReLU (gate bits out) or gate (bits in);
-//                       the fp32 chunk to global memory (the weight gradients of backward read it), its planes into LDS image c % 2;
-//   wavefronts 4-7 (B)  y (BM x 256) += chunk (c - 1) W2[:, chunk]^T from LDS image (c - 1) % 2, 64 output columns each;
+//                       the fp32 chunk to global memory (the weight gradients of backward read it), its planes into LDS image c % 2
+//                       — this epilogue one chunk late, spread over the k loop of chunk c + 1;
+//   wavefronts 4-7 (B)  y (BM x 256) += chunk (c - 2) W2[:, chunk]^T from its LDS image, 64 output columns each;
 // one barrier per chunk.  Every SIMD holds one wavefront of each role: while an A wavefront converts and stores its chunk
 // (VALU, LDS and memory instructions), its B partner has the matrix pipe to itself — the first version of this kernel ran both
 // phases on all eight wavefronts in lockstep and left the pipe idle for a quarter of its life (profiles/r6_ffn_lab.txt).
@@ -34,6 +35,7 @@
 // 2^(t-26) of the maximum — below it the error is 2^-48 2^t of the maximum absolute, invisible in an fp32 product.
 #include "gemm_common.h"
 #include "rscotr.h"
+#include <type_traits>
 
 namespace rscotr {
 
@@ -174,148 +176,115 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // own nch + 1 barriers — A: [chunk c -> image c % 2; barrier] x nch, barrier;  B: barrier, [image c % 2 -> y; barrier] x nch — so
   // that neither role's accumulators are live in the other's code (one loop with both roles inside kept 96 + 48 of them alive).
   if (role_a) {
-#ifdef FFN_PRIO_A
-    __builtin_amdgcn_s_setprio(FFN_PRIO_A);
-#endif
+    // The epilogue of chunk c - 1 (bias, gate, planes -> LDS image, fp32 chunk -> memory) RIDES IN THE K LOOP OF CHUNK c, one 16 x 16
+    // tile per k step: the matrix pipe takes an MFMA every 16 cycles and leaves three issue slots in between, so the ~65 VALU / LDS /
+    // memory instructions of a tile disappear between the 18 MFMAs of a step instead of standing alone at the end of the chunk,
+    // where the B partner — done with its own chunk — waited at the barrier (+20 us of 88: profiles/r6_ffn_lab.txt).  The k loop is
+    // fully unrolled (tile and ring indices static) with a scheduling barrier per k step (unfenced, the scheduler hoists the
+    // fragment reads of all eight steps to the top and spills).  The image of chunk c - 1 is complete at the barrier that ends
+    // chunk c's loop: the B role runs two barriers behind.
     unsigned amxu = 0u;
-    // (Measured and not kept, profiles/r6_ffn_lab.txt: the fp32 chunk held in registers and stored half a chunk later, so that the
-    //  weight loads issued behind the stores are not the next ones waited for — 92.7 against 86-89 us: the stores' wait states
-    //  and scheduling barriers inside the k loop cost more than the in-order completion they avoid.)
     const int vH = (li * p.H + wr * 32 + 4 * kg) * 4;
-#pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-      {
-        // ---- hidden chunk c: columns c * 128 + wr * 32 + it * 16 .., all rows; 8 k steps of 32 in pairs (ring position static)
-        f32x4_t ha[2][NT], hb[2][NT];
+    const int tmax = nch * 8 - 1;
+    float4 pv[2][NT];  // chunk c - 1 before bias / gate
+    float4 bvs[2];
+    unsigned bits = 0u;
+    auto slice = [&](int cp, int it, int n) {
+      float v[4] = {pv[it][n].x, pv[it][n].y, pv[it][n].z, pv[it][n].w};
+      if (!GATE) {
+        const float t[4] = {v[0] + bvs[it].x, v[1] + bvs[it].y, v[2] + bvs[it].z, v[3] + bvs[it].w};
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int r = 0; r < 4; ++r) {
+          const bool pos = t[r] > 0.f;
+          v[r] = pos ? t[r] : 0.f;
+          bits |= (unsigned)pos << ((it * NT + n) * 4 + r);
+        }
+      } else {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-        const int tmax = nch * 8 - 1;
-#ifdef FFN_LDS_PREFETCH
-        // the activation fragments of k step ks + 1 are requested before the MFMAs of k step ks (the image is the same for every
-        // chunk: the last step requests step 0 of the next chunk)
-        uint4 xf[2][2 * NT];
+        for (int r = 0; r < 4; ++r)
+          v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, (it * NT + n) * 4 + r, 1));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) amxu = max(amxu, __float_as_uint(v[r]) & 0x7fffffffu);
+      unsigned ab[3], cd[3];
+      split_pair_h(v[0], v[1], hh, ab);
+      split_pair_h(v[2], v[3], hh, cd);
+      unsigned char* dst = hs + (cp & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8 + n * 16 * FFN_LDRB + it * 32;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+      *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+#ifndef FFN_ABL_NOHID
+      store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, (n * 16 * p.H + cp * FFN_HC + it * 16) * 4);
+#endif
+    };
+    auto pre_epi = [&](int cp) {  // what the slices of chunk cp need from memory: requested a k loop ahead of their first use
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        bvs[it] = (!GATE && p.b1) ? *reinterpret_cast<const float4*>(p.b1 + cp * FFN_HC + wr * 32 + it * 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bits = GATE ? p.bits[(((long)blockIdx.x * nch + cp) * 4 + wr) * 64 + lane] : 0u;
+    };
+    auto kloop = [&](int c, auto with_epi) {
+      constexpr bool EPI = decltype(with_epi)::value;
+      f32x4_t ha[2][NT], hb[2][NT];
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        uint4 xh[NT], xl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const unsigned char* q = xs + n * 16 * FFN_LDRB + fo;
-          xf[0][2 * n] = *reinterpret_cast<const uint4*>(q);
-          xf[0][2 * n + 1] = *reinterpret_cast<const uint4*>(q + 64);
+          const unsigned char* q = xs + ks * STG + n * 16 * FFN_LDRB + fo;
+          xh[n] = *reinterpret_cast<const uint4*>(q);
+          xl[n] = *reinterpret_cast<const uint4*>(q + 64);
         }
-#endif
-#pragma unroll 1
-        for (int kp = 0; kp < 8 / FFN_DA; ++kp) {
-#pragma unroll
-          for (int u = 0; u < FFN_DA; ++u) {
-            const int ks = kp * FFN_DA + u;
-            uint4 xh[NT], xl[NT];
-#ifdef FFN_LDS_PREFETCH
-            static_assert(FFN_DA % 2 == 0, "the fragment double buffer alternates with the k step");
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const unsigned char* q = xs + ((ks + 1) & 7) * STG + n * 16 * FFN_LDRB + fo;
-              xf[(u + 1) & 1][2 * n] = *reinterpret_cast<const uint4*>(q);
-              xf[(u + 1) & 1][2 * n + 1] = *reinterpret_cast<const uint4*>(q + 64);
-              xh[n] = xf[u & 1][2 * n];
-              xl[n] = xf[u & 1][2 * n + 1];
-            }
-#elif defined(FFN_ABL_NOLDS)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              xh[n] = make_uint4(0x3c003c00u + ks, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + n);
-              xl[n] = make_uint4(0x1c001c00u + ks, 0x1c001c00u, 0x1c001c00u, 0x1c001c00u + n);
-              asm volatile("" : "+v"(xh[n].x), "+v"(xl[n].x));
-            }
-#else
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const unsigned char* q = xs + ks * STG + n * 16 * FFN_LDRB + fo;
-              xh[n] = *reinterpret_cast<const uint4*>(q);
-              xl[n] = *reinterpret_cast<const uint4*>(q + 64);
-            }
-#endif
-            const int tn = min(c * 8 + ks + FFN_DA, tmax);  // FFN_DA k steps ahead (past the end: a harmless re-read)
-            // terms of gemm_h3_*: l h, h l into the second accumulator, h h into the first (weight = the MFMA's A operand).  A ring
-            // slot is refilled AFTER its last use, into the same registers (refilling it first made the compiler rotate the ring
-            // through copies, and every copy waits for the load it copies: the pipeline drained once per k step)
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-              const uint4 wh = ring[u * 4 + it * 2], wl = ring[u * 4 + it * 2 + 1];
-#pragma unroll
-              for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wh, xl[n], hb[it][n]);
-#pragma unroll
-              for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wl, xh[n], hb[it][n]);
-#pragma unroll
-              for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
-#ifndef FFN_ABL_NOB
-              ring[u * 4 + it * 2] = ld_a(tn, it, 0);
-              ring[u * 4 + it * 2 + 1] = ld_a(tn, it, 1);
-#else
-              asm volatile("" : "+v"(ring[u * 4 + it * 2].x), "+v"(ring[u * 4 + it * 2 + 1].x) : "s"(tn));
-#endif
-            }
-          }
-        }
-        // ---- epilogue of the chunk: the lane holds columns col0 .. col0 + 3 of row n * 16 + li for every (it, n)
-#ifdef FFN_ABL_NOEPI
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(ha[it][n]), "v"(hb[it][n]));
-        if (false) {
-#else
-        {
-#endif
-        const long widx = (((long)blockIdx.x * nch + c) * 4 + wr) * 64 + lane;
-        unsigned bits = GATE ? p.bits[widx] : 0u;
-        unsigned char* img = hs + (c & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8;  // k block wr of the image is this wavefront's
+        const int tn = min(c * 8 + ks + FFN_DA, tmax);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (!GATE && p.b1) bv = *reinterpret_cast<const float4*>(p.b1 + c * FFN_HC + wr * 32 + it * 16 + 4 * kg);
+          const int slot = (ks % FFN_DA) * 4 + it * 2;
+          const uint4 wh = ring[slot], wl = ring[slot + 1];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            float v[4];
+          for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wh, xl[n], hb[it][n]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(hb[it][n][r], 0x1p-11f, ha[it][n][r]) * invx * inv1;
-            if (!GATE) {
-              // relu as compare + select (fmaxf canonicalises its operands: a v_cmp_class + v_cndmask per element on top of the
-              // v_max); the compare is the gate bit
-              const float t[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+          for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wl, xh[n], hb[it][n]);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const bool pos = t[r] > 0.f;
-                v[r] = pos ? t[r] : 0.f;
-                bits |= (unsigned)pos << ((it * NT + n) * 4 + r);
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, (it * NT + n) * 4 + r, 1));
-            }
-#ifndef FFN_ABL_NOHID  // (FFN_ABL_*: timing ablations of scripts/lab/ffn_abl.sh — results are wrong with any of them)
-            store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, (n * 16 * p.H + c * FFN_HC + it * 16) * 4);
-#endif
-#pragma unroll
-            for (int r = 0; r < 4; ++r) amxu = max(amxu, __float_as_uint(v[r]) & 0x7fffffffu);  // (bit patterns of |v| order like the values)
-            unsigned ab[3], cd[3];
-            split_pair_h(v[0], v[1], hh, ab);
-            split_pair_h(v[2], v[3], hh, cd);
-#ifndef FFN_ABL_NOIMG
-            unsigned char* dst = img + n * 16 * FFN_LDRB + it * 32;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
-            *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
-#else
-            asm volatile("" ::"v"(ab[0]), "v"(ab[1]), "v"(cd[0]), "v"(cd[1]));
-#endif
+          for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
+          ring[slot] = ld_a(tn, it, 0);
+          ring[slot + 1] = ld_a(tn, it, 1);
+        }
+        if constexpr (EPI) {
+          if (ks < 2 * NT) {
+            slice(c - 1, ks / NT, ks % NT);  // (ends in store_b128's scheduling barrier)
           }
         }
-        if (!GATE) p.bits[widx] = bits;
-        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();  // image c % 2 is complete
-    }
+      if constexpr (EPI) {
+        if (!GATE) p.bits[(((long)blockIdx.x * nch + (c - 1)) * 4 + wr) * 64 + lane] = bits;
+      }
+      pre_epi(c);
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          pv[it][n].x = fmaf(hb[it][n][0], 0x1p-11f, ha[it][n][0]) * invx * inv1;
+          pv[it][n].y = fmaf(hb[it][n][1], 0x1p-11f, ha[it][n][1]) * invx * inv1;
+          pv[it][n].z = fmaf(hb[it][n][2], 0x1p-11f, ha[it][n][2]) * invx * inv1;
+          pv[it][n].w = fmaf(hb[it][n][3], 0x1p-11f, ha[it][n][3]) * invx * inv1;
+        }
+    };
+    kloop(0, std::false_type{});
     __syncthreads();
+#pragma unroll 1
+    for (int c = 1; c < nch; ++c) {
+      kloop(c, std::true_type{});
+      __syncthreads();  // image (c - 1) % 2 is complete
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t) slice(nch - 1, t / NT, t % NT);
+    if (!GATE) p.bits[(((long)blockIdx.x * nch + (nch - 1)) * 4 + wr) * 64 + lane] = bits;
+    __syncthreads();  // the last image is complete
+    __syncthreads();  // (the B role's last barrier)
     amax_commit(p.amax_hid, __uint_as_float(amxu));
   } else {
 #ifdef FFN_PRIO_B
@@ -327,6 +296,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int n = 0; n < NT; ++n) { ya[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; yb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
+    __syncthreads();  // (image c is complete one barrier later: its epilogue rides in the k loop of chunk c + 1)
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
       // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32, columns wr * 64 + it * 16 ..

@@ -3,7 +3,7 @@
 #   bash scripts/lab/ffn_abl.sh build        -> rscotr_amd/_ab/lib_ffn_<variant>.so
 #   bash scripts/lab/ffn_abl.sh run <tag>    -> gpurun_out/<tag>/ffn_abl.txt
 cd "$(dirname "$0")/../.."
-variants="a:-DFFN_ABL_NOEPI,-DFFN_ABL_NOPHASEB a_nob:-DFFN_ABL_NOEPI,-DFFN_ABL_NOPHASEB,-DFFN_ABL_NOB a_nolds:-DFFN_ABL_NOEPI,-DFFN_ABL_NOPHASEB,-DFFN_ABL_NOLDS a_nob_nolds:-DFFN_ABL_NOEPI,-DFFN_ABL_NOPHASEB,-DFFN_ABL_NOB,-DFFN_ABL_NOLDS"
+variants="sgb3:-DFFN_SGB=3 sgb2:-DFFN_SGB=2 nohid:-DFFN_ABL_NOHID"
 if [ "$1" = build ]; then
   for v in $variants; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr ',' ' ')
