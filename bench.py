@@ -317,6 +317,11 @@ def main():
             lib.call('rscotr_prof_enable', PROF_EVERY_GEMM, 1, 1, 8192)
         for _ in range(a.roofline_rounds):
             one_round()
+        if rank == 0:
+            # what the bracketing itself costs: empty event pairs queued behind the same hold (subtracted from every sample below)
+            with torch.cuda.stream(runner.stream) if runner.stream is not None else contextlib.nullcontext():
+                torch.cuda._sleep(hold['cycles'])
+                lib.call('rscotr_prof_empty', 64, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         runner.force_eager = False
         hold['cycles'] = 0
@@ -333,6 +338,17 @@ def main():
             prof.append(dict(kind=('gemm', 'msda_fwd', 'msda_bwd', 'hbm', 'mfma')[kind.value], work=work.value, sec=ms.value * 1e-3,
                              name=name.value.decode()))
         lib.call('rscotr_prof_disable')
+        # HIP events around a launch add the processing of the second record's packet to the kernel's own duration (VERDICT r5 item 7:
+        # 26.1 us bracketed against 20.15 us for the same kernel in a replayed graph's trace).  Every sample is corrected by the
+        # MEDIAN duration of the empty brackets recorded next to them (never below a quarter of the raw sample).
+        empty = sorted(p['sec'] for p in prof if p['name'] == 'rscotr::empty_bracket')
+        bracket_s = empty[len(empty) // 2] if empty else 0.0
+        prof = [p for p in prof if p['name'] != 'rscotr::empty_bracket']
+        for p in prof:
+            p['raw_sec'] = p['sec']
+            p['sec'] = max(p['sec'] - bracket_s, 0.25 * p['sec'])
+    else:
+        bracket_s = 0.0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -375,7 +391,7 @@ def main():
             return 'bf16x6' in k or 'wplanes' in k or 'gemm_f32_group_kernel<6>' in k
 
         def is_h3(k):  # ... the three-term fp16 split (2500 / 3)
-            return 'gemm_h3' in k
+            return 'gemm_h3' in k or 'ffn_h3' in k
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12
@@ -392,7 +408,7 @@ def main():
                                  'v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate — fp32-FMA-class error: achieved = fp32-equivalent '
                                  '2MNK flops, peak = dense fp16 MFMA peak / 3; ')
                                 if split else 'fp32 in / fp32 accumulate MFMA (v_mfma_f32_32x32x2_f32); ') + '1 launch in '
-                               f'{PROF_EVERY_GEMM} sampled (events recorded inside the C entry, on the launch stream); ' + (
+                               f'{PROF_EVERY_GEMM} sampled (events recorded inside the C entry, on the launch stream; the median duration of an empty event bracket, roofline_bracket_us, is subtracted from every sample); ' + (
                                    f'sampled in {a.roofline_rounds} eager round(s) run right after the timed region '
                                    '(the timed region replays hipGraphs), each iteration queued behind a '
                                    f'{a.roofline_hold_ms:.0f} ms stream hold so that its kernels run back to back'
@@ -423,7 +439,7 @@ def main():
             fam = dict(bound='mfma', achieved=tf / tt / 1e12, peak=fam_peak, unit='TFLOP/s',
                        frac=tf / tt / 1e12 / fam_peak,
                        kernel='rscotr GEMM family: gemm_f32_kernel<*>, gemm_bf16x6_kernel<*>, gemm_wplanes_kernel<*>, gemm_small_kernel<*>, '
-                              'gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> / gemm_h3_group_kernel (the grouped weight-gradient launch), gemm_h3_kernel<*> / gemm_h3_128_kernel<*>',
+                              'gemm_dw_direct_kernel<*>, gemm_f32_group_kernel<*> / gemm_h3_group_kernel (the grouped weight-gradient launch), gemm_h3_kernel<*> / gemm_h3_128_kernel<*>, ffn_h3_kernel<*> (the fused encoder FFN: two products per launch)',
                        launches_sampled=sum(v[2] for v in gg.values()), split_product_flop_share=sf / tf if tf else 0.0,
                        split_product_time_share=st / tt if tt else 0.0,
                        note='fp32-equivalent flops; peak = flop-weighted harmonic mix of 157.3 (fp32 pipe), 2500/6 (bf16x6) and '
@@ -508,6 +524,7 @@ def main():
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
                    roofline_attn_fwd=r_af, roofline_attn_bwd=r_ab, roofline_swin_wattn=r_wa, roofline_layernorm=r_ln,
                    roofline_splitk=r_sk, roofline_adamw=r_ad,
+                   roofline_bracket_us=round(bracket_s * 1e6, 3),  # median empty event bracket, subtracted from every roofline sample
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.size, a.batch, a.cpu_rounds, a.workload)

@@ -43,6 +43,7 @@ int rscotr_device_count(void);
  * record i (the stream must be idle); rscotr_prof_disable() releases the events.  Not capturable in a hipGraph. */
 int rscotr_prof_enable(int every_gemm, int every_msda_fwd, int every_msda_bwd, int max_records);
 int rscotr_prof_pause(void);
+int rscotr_prof_empty(int n, void* stream); /* n empty brackets (name "rscotr::empty_bracket"): the cost of the bracketing itself */
 int rscotr_prof_get(int i, int* kind, double* work, float* ms, char* name, int name_len);
 int rscotr_prof_disable(void);
 

@@ -67,6 +67,14 @@ extern "C" int rscotr_prof_enable(int every_gemm, int every_msda_fwd, int every_
   return RSCOTR_OK;
 }
 
+// n EMPTY brackets (an event pair with nothing in between, kind PROF_HBM, name "rscotr::empty_bracket") on `stream`: what the
+// bracketing itself adds to every sampled duration (the second record's packet is processed after the first one's: ~5 us on
+// ROCm 7.2 / MI355X — a quarter of a 20 us launch).  bench.py subtracts their mean from every sample.
+extern "C" int rscotr_prof_empty(int n, void* stream) {
+  for (int i = 0; i < n; ++i) { rscotr::ProfScope prof(rscotr::PROF_HBM, 0.0, static_cast<hipStream_t>(stream), "rscotr::empty_bracket"); }
+  return RSCOTR_OK;
+}
+
 extern "C" int rscotr_prof_pause(void) {  // stop recording, keep the records
   std::lock_guard<std::mutex> lk(rscotr::g_prof_mu);
   for (int k = 0; k < rscotr::PROF_KINDS; ++k) rscotr::g_prof_every[k] = 0;

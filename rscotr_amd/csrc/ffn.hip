@@ -465,6 +465,7 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = gate ? nullptr : amax_b1;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %s>", ffn_rows(M) / 16, gate ? "true" : "false");
   if (ffn_rows(M) == 32) ffn_launch<2>(p, gate, s);
   else ffn_launch<3>(p, gate, s);
   return check_launch("ffn_h3");

@@ -180,6 +180,19 @@ class FolderClsDataset:
         path, label = self.items[i]
         return dict(img=_imread_bgr(path), gt_label=label, filename=path)
 
+    def evaluate(self, results, metric='accuracy', metric_options=None, indices=None, logger=None, **kwargs):
+        """mmcls BaseDataset.evaluate: `results` = per-sample score vectors in dataset order -> {'accuracy_top-1', 'accuracy_top-5'}
+        in percent (metric_options: topk, thrs)."""
+        from .metrics import accuracy
+        metrics = [metric] if isinstance(metric, str) else list(metric)
+        if set(metrics) - {'accuracy'}:
+            raise ValueError(f'metric {set(metrics) - {"accuracy"}} is not supported (accuracy only)')
+        opt = dict(topk=(1, 5)) if metric_options is None else dict(metric_options)
+        labels = [self.items[i][1] for i in (range(len(self.items)) if indices is None else indices)]
+        assert len(results) == len(labels), 'dataset testing results should be of the same length as gt_labels'
+        topk = opt.get('topk', (1, 5))
+        return accuracy(results, labels, topk=(topk,) if isinstance(topk, int) else tuple(topk), thrs=opt.get('thrs'))
+
 
 class CocoDetDataset:
     """mmdet CocoDataset on DIOR's converted annotations (configs/_base_/det/dior.py:41-47): images without boxes and
@@ -218,6 +231,22 @@ class CocoDetDataset:
         path, boxes, labels = self.items[i]
         return dict(img=_imread_bgr(path), gt_bboxes=boxes, gt_labels=labels, filename=path)
 
+    def evaluate(self, results, metric='bbox', logger=None, jsonfile_prefix=None, classwise=False, proposal_nums=(100, 300, 1000),
+                 iou_thrs=None, metric_items=None, **kwargs):
+        """mmdet CocoDataset.evaluate(metric='bbox'): `results` = per image a list (per class) of (k, 5) arrays in original-image
+        coordinates -> bbox_mAP / _50 / _75 / _s / _m / _l (COCOeval semantics, rscotr_amd/metrics.py)."""
+        from .metrics import coco_bbox_map
+        metrics = [metric] if isinstance(metric, str) else list(metric)
+        if metrics != ['bbox']:
+            raise KeyError(f'metric {metrics} is not supported (bbox only)')
+        assert len(results) == len(self.items), 'one result per image'
+        out = coco_bbox_map(results, [it[1] for it in self.items], [it[2] for it in self.items], self.CLASSES, iou_thrs=iou_thrs,
+                            max_det=proposal_nums[0], classwise=classwise)
+        if metric_items is not None:
+            keep = {f'bbox_{m}' for m in metric_items}
+            out = type(out)((k, v) for k, v in out.items() if k in keep or k == 'bbox_mAP_copypaste' or k.startswith('bbox_AP.'))
+        return out
+
 
 class TileSegDataset:
     """mmseg CustomDataset / PotsdamDataset: `img_dir/<name>.png` + `ann_dir/<name>.png` single-channel label tiles
@@ -225,9 +254,10 @@ class TileSegDataset:
     task = 'seg'
     CLASSES = ('impervious_surface', 'building', 'low_vegetation', 'tree', 'car', 'clutter')
 
-    def __init__(self, img_dir, ann_dir, img_suffix='.png', seg_map_suffix='.png'):
+    def __init__(self, img_dir, ann_dir, img_suffix='.png', seg_map_suffix='.png', reduce_zero_label=True, ignore_index=255):
         names = sorted(f[:-len(img_suffix)] for f in os.listdir(img_dir) if f.endswith(img_suffix))
         self.items = [(os.path.join(img_dir, n + img_suffix), os.path.join(ann_dir, n + seg_map_suffix)) for n in names]
+        self.reduce_zero_label, self.ignore_index = reduce_zero_label, ignore_index  # (mmseg PotsdamDataset: True, 255)
 
     def __len__(self):
         return len(self.items)
@@ -239,14 +269,39 @@ class TileSegDataset:
             seg = np.asarray(im).astype(np.uint8)
         return dict(img=_imread_bgr(ip), gt_semantic_seg=seg, filename=ip)
 
+    def evaluate(self, results, metric='mIoU', logger=None, gt_seg_maps=None, device=None, **kwargs):
+        """mmseg CustomDataset.evaluate: `results` = per-image label maps at the original size (dataset order) -> aAcc, mIoU / mAcc,
+        mFscore / mPrecision / mRecall, mDice and the per-class values, as fractions.  The confusion matrix is accumulated on the
+        device (rscotr_amd/metrics.py); `pre_eval` / `classwise` of the reference's config are accepted and change nothing here
+        (per-class values are always returned)."""
+        from PIL import Image
+        from .metrics import confusion_matrix, seg_metrics
+        assert len(results) == len(self.items), 'one label map per image'
+
+        def gts():
+            if gt_seg_maps is not None:
+                yield from gt_seg_maps
+                return
+            for _, ap in self.items:
+                with Image.open(ap) as im:
+                    yield np.asarray(im).astype(np.uint8)
+        cm = confusion_matrix(results, gts(), len(self.CLASSES), ignore_index=self.ignore_index,
+                              reduce_zero_label=self.reduce_zero_label, device=device)
+        return seg_metrics(cm, self.CLASSES, metrics=metric)
+
 
 class DeviceLoader:
     """Minimal batch loader over one of the datasets above: shuffled index batches, decoded on the host, everything
     else in `DeviceCollate`.  `len()` = batches per epoch; `.dataset.task` is what MultiDataLoader tags batches with."""
 
-    def __init__(self, dataset, collate, batch_size, shuffle=True, drop_last=True, seed=0):
+    def __init__(self, dataset, collate, batch_size, shuffle=True, drop_last=True, seed=0, test_mode=False):
         self.dataset, self.collate, self.batch_size = dataset, collate, batch_size
         self.shuffle, self.drop_last, self.rng = shuffle, drop_last, np.random.RandomState(seed)
+        # test_mode: dataset order, every sample, batches of {task, img, img_metas} only — what `engine.single_gpu_test` feeds
+        # `model(return_loss=False, **data)` (the collate should be built with flip_prob = 0 and no crop)
+        self.test_mode = test_mode
+        if test_mode:
+            self.shuffle, self.drop_last = False, False
 
     def __len__(self):
         n = len(self.dataset)
@@ -256,4 +311,5 @@ class DeviceLoader:
         order = self.rng.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.collate([self.dataset[int(i)] for i in idx], self.rng)
+            batch = self.collate([self.dataset[int(i)] for i in idx], self.rng)
+            yield dict(task=self.dataset.task, img=batch['img'], img_metas=batch['img_metas']) if self.test_mode else batch
