@@ -220,29 +220,33 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
                        const float* rowscale, int rows_per_scale, const float* kscale, int krows_per_scale,
                        float* out2, float* workspace, int64_t workspace_bytes, const uint32_t* amax_a,
                        const uint32_t* amax_b, uint32_t* amax_out, const void* b_planes, int b_rpad, void* stream);
-/* The two-layer FFN of the shared encoder as ONE launch (round 6, csrc/ffn.hip).  Replaces mmcv FFN (two nn.Linear around a
- * ReLU) inside the encoder's BaseTransformerLayer — configs/multi/MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py:44-49,
- * reached from models/multi/seg_head/pixel_decoder.py:134-146 and models/multi/bbox_head/transformer.py:211-221 — and, with
- * gate = 1, the mirrored pair of its backward (dH = (g W2) * [h > 0], dX = dH W1):
- *     hid = gate ? (X W1op^T) * bit : relu(X W1op^T + b1)      (M, H), stored fp32 (the weight gradients read it)
- *     Y   = hid W2op^T + b2 (+ resid)                          (M, C)
- * X (M, C) row-major fp32, C == 256, H % 128 == 0 (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight
- * operands, W1op (H rows, reduction C) and W2op (C rows, reduction H), written by rscotr_gemm_split_weights_frag — table rows
- * as rscotr_gemm_split_weights_h3 (column 5 unused); plane rows % 16 == 0, reduction % 32 == 0; layout uint4
- * [row / 16][k / 32][h | l][lane]: the weight operand of a wavefront's 16 x 16 x 32 MFMA is one contiguous 1 KB load; an entry takes
- * rows * reduction / 8 / 256 blocks.  bits: rscotr_ffn_h3_bits_words(M, H) uint32 words, written with gate = 0 and read with
- * gate = 1 (layout private to the kernel).  amax_x / amax_w1 / amax_w2 (required), amax_b1 (optional): range words of X, of the
- * two weights (the ones the planes were split with) and of b1; amax_hid / amax_y (optional): range words of hid / Y, committed.
- * The three-term fp16 split product of rscotr_gemm_f32_r throughout (on 16 x 16 x 32 MFMAs: equal to that entry's results at fp32
- * rounding, not bit for bit); the planes of hid for the second product are scaled from the a-priori bound
- * C max|X| max|W1| + max|b1|. */
+/* A two-layer MLP block as ONE launch (round 6, csrc/ffn.hip).  Replaces
+ *   - mmcv FFN (two nn.Linear around a ReLU) inside the shared encoder's BaseTransformerLayer —
+ *     configs/multi/MTL_slvlcls_swin-t-p4-w7_1x1_resisc&dior&potsdam.py:44-49, reached from
+ *     models/multi/seg_head/pixel_decoder.py:134-146 and models/multi/bbox_head/transformer.py:211-221 (C = 256, mode 0 / 1);
+ *   - the FFN of mmdet's SwinBlock (Linear - GELU - Linear with DropPath) in stages 1 and 2 of the backbone —
+ *     configs/multi/MTL_slvlcls_...potsdam.py:9-25, reached from models/multi/multitask_learner.py:81-85 (C = 96 / 192, mode 2 / 3);
+ * and the mirrored pair of each one's backward pass.  mode:
+ *     0  hid = relu(X' W1op^T + b1), the gate [hid > 0] written to `bits`        1  hid = (X' W1op^T) * bit read from `bits`
+ *     2  Pre = X' W1op^T + b1 stored, hid = gelu(Pre) (erf form)                  3  hid = (X' W1op^T) * gelu'(Pre), Pre read
+ *     Y = (hid W2op^T + b2) * yscale[row / rows_per] + resid,   X' = X * xscale[row / rows_per]   (scales / resid optional)
+ * hid (M, H) is stored fp32 (the weight gradients read it).  X (M, C) row-major fp32, C in {96, 192, 256}, H % 128 == 0
+ * (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight operands, W1op (H rows, reduction C) and W2op (C rows,
+ * reduction H), written by rscotr_gemm_split_weights_frag — table rows as rscotr_gemm_split_weights_h3 (column 5 unused); plane
+ * rows % 16 == 0, reduction % 32 == 0; layout uint4 [row / 16][k / 32][h | l][lane]: the weight operand of a wavefront's
+ * 16 x 16 x 32 MFMA is one contiguous 1 KB load; an entry takes rows * reduction / 8 / 256 blocks.  bits:
+ * rscotr_ffn_h3_bits_words(M, C, H) uint32 words (layout private to the kernel).  amax_x / amax_w1 / amax_w2 (required), amax_b1
+ * (optional): range words of X, of the two weights (the ones the planes were split with) and of b1; amax_hid / amax_y
+ * (optional): range words of hid / Y, committed.  The three-term fp16 split product of rscotr_gemm_f32_r throughout (on
+ * 16 x 16 x 32 MFMAs: equal to that entry's results at fp32 rounding, not bit for bit); the planes of hid for the second product
+ * are scaled from the a-priori bound C max|X| max|W1| + max|b1|. */
 int rscotr_ffn_h3_ok(int M, int C, int H);
-int64_t rscotr_ffn_h3_bits_words(int M, int H);
+int64_t rscotr_ffn_h3_bits_words(int M, int C, int H);
 int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks, void* stream);
 int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
-                  void* bits, int gate, float* Hid, const float* resid, float* Y, const uint32_t* amax_x,
-                  const uint32_t* amax_w1, const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid,
-                  uint32_t* amax_y, void* stream);
+                  int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
+                  const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
+                  const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, void* stream);
 /* > 0 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
  * product once both value ranges are supplied: callers ask before they go looking for ranges.  2: the interior pipelined
  * 64 x 64 kernel, which can take a weight operand B from pre-split planes (rscotr_gemm_f32_rb). */

@@ -41,17 +41,18 @@ namespace rscotr {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int FFN_C = 256;     // model width (reduction of the first product, columns of the second)
 constexpr int FFN_HC = 128;    // hidden columns per chunk (4 A wavefronts x 32)
 constexpr int FFN_LDRB = 160;  // bytes per LDS row of a 32-k stage: h[32] | l[32] | 32 bytes pad (conflict-free ds_read_b128 of the
                                // 16 x 16 x 32 fragment pattern: row = lane & 15, 16 bytes at k = 8 (lane >> 4))
-#ifndef FFN_DA
-#define FFN_DA 2  // k steps (of 32) the A role's weight fragment loads run ahead of their MFMAs (4 loads each)
-#endif
 #ifndef FFN_DB
-#define FFN_DB 1  // ... the B role's (8 loads each)
+#define FFN_DB 1  // k steps (of 32) the B role's weight fragment loads run ahead of their MFMAs
 #endif
-constexpr int FFN_RING = 4 * FFN_DA > 8 * FFN_DB ? 4 * FFN_DA : 8 * FFN_DB;  // weight fragment loads in flight per wavefront
+
+// MODE: what happens to a hidden chunk between the two products
+enum { FFN_RELU = 0,       // hidden = relu(x W1^T + b1); one bit per element [hidden > 0] -> bits
+       FFN_RELU_GATE = 1,  // hidden = (x W1^T) * bit                       (dH = (g W2) * [h > 0] of the backward pass)
+       FFN_GELU = 2,       // pre = x W1^T + b1 -> Pre; hidden = gelu(pre)  (the MLP of a Swin block: mmdet SwinBlock's FFN, erf GELU)
+       FFN_GELU_GRAD = 3 };// hidden = (x W1^T) * gelu'(Pre)               (dH = (g W2) * gelu'(pre))
 
 struct FfnParams {
   const float* X;
@@ -60,16 +61,21 @@ struct FfnParams {
   const float* b1;
   const uint4* W2f;
   const float* b2;
-  unsigned* bits;
+  unsigned* bits;      // FFN_RELU: written, FFN_RELU_GATE: read
+  float* Pre;          // FFN_GELU: written, FFN_GELU_GRAD: read (M, H)
   float* Hid;
   const float* resid;
   float* Y;
+  const float* xscale; // per-sample factor on the rows of X while they are staged (the upstream gradient of a DropPath'ed block) | null
+  const float* yscale; // per-sample factor on Y before the residual (DropPath folded into the block's last Linear) | null
+  int rows_per;        // rows per sample for the two
   const unsigned *amax_x, *amax_w1, *amax_w2, *amax_b1;
   unsigned *amax_hid, *amax_y;
 };
 
-template <int NT>
-constexpr size_t ffn_lds_bytes() { return (size_t)(FFN_C / 32 + 2 * (FFN_HC / 32)) * (16 * NT) * FFN_LDRB; }
+// C: model width (reduction of the first product, columns of the second); NT: 16-row tiles per workgroup
+template <int C, int NT>
+constexpr size_t ffn_lds_bytes() { return (size_t)(C / 32 + 2 * (FFN_HC / 32)) * (16 * NT) * FFN_LDRB; }
 
 // 16-byte buffer store with a SCALAR offset register.  LLVM's hazard recognizer assumes that a buffer store of more than 8 bytes
 // whose soffset is an SGPR has read its data registers by the time the next instruction issues, and inserts no wait state; on
@@ -87,17 +93,27 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// NT: 16-row tiles per workgroup (BM = 16 NT).  GATE = false: hidden = relu(x W1^T + b1), one bit per element [hidden > 0] written
-// to p.bits; true: hidden = (x W1^T) gated by the bits a forward launch of the same shape (and NT) left (dH = (g W2) * [h > 0]).
-// Bit layout (opaque to callers, the same in both directions): uint32 [row tile][chunk][A wavefront][lane], bit
-// (it * NT + n) * 4 + r = accumulator register r of the lane's 16 x 16 tile (column tile it, row tile n).
-template <int NT, bool GATE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ffn_h3_kernel(FfnParams p) {
+// Bit layout of FFN_RELU / FFN_RELU_GATE (opaque to callers, the same in both directions): uint32 [row tile][chunk][A wavefront][lane],
+// bit (it * NT + n) * 4 + r = accumulator register r of the lane's 16 x 16 tile (column tile it, row tile n).
+template <int C, int NT, int MODE>
+#ifndef FFN_SWIN_WAVES
+#define FFN_SWIN_WAVES 4  // wavefronts per SIMD the C = 96 kernels are held to (4 = 128 registers: two 8-wavefront workgroups per CU; stage 1 of
+                          // Swin-T at 512^2 is 1024 workgroups; C = 192 is 256 workgroups = one per CU, C = 256 needs its 123 KB of LDS alone)
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? FFN_SWIN_WAVES : 2, C == 96 ? FFN_SWIN_WAVES : 2))) void ffn_h3_kernel(FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
-  constexpr int C = FFN_C, BM = 16 * NT, STG = BM * FFN_LDRB;  // bytes per 32-k stage of a plane image
-  constexpr int XST = C / 32, HST = FFN_HC / 32;
-  unsigned char* xs = ffn_lds;                    // [XST][BM][160]
-  unsigned char* hs = ffn_lds + XST * STG;        // [2][HST][BM][160]
+  constexpr bool GATE = MODE == FFN_RELU_GATE, GELU = MODE == FFN_GELU, GGRAD = MODE == FFN_GELU_GRAD;
+  constexpr bool FWD = MODE == FFN_RELU || MODE == FFN_GELU;
+  constexpr int BM = 16 * NT, STG = BM * FFN_LDRB;  // bytes per 32-k stage of a plane image
+  constexpr int KS1 = C / 32, HST = FFN_HC / 32;    // k steps of the first product; stages (= k steps) of a chunk image
+  constexpr int DA = KS1 % 2 == 0 ? 2 : 1;          // k steps the A role's weight loads run ahead (ring position static: DA | KS1)
+  constexpr int TPB = C == 96 ? 2 : C / 64;         // 16-column output tiles per B wavefront
+  constexpr int NB = C / 16 / TPB;                  // B wavefronts with work (3 for C = 96, else 4)
+  constexpr int RING = 4 * DA > 2 * TPB * FFN_DB ? 4 * DA : 2 * TPB * FFN_DB;
+  constexpr int SPK = (2 * NT + KS1 - 1) / KS1;     // epilogue tiles riding in one k step of the next chunk
+  static_assert(C % 32 == 0 && (C / 16) % TPB == 0 && NB <= 4, "column tiles split evenly over the B wavefronts");
+  unsigned char* xs = ffn_lds;                      // [KS1][BM][160]
+  unsigned char* hs = ffn_lds + KS1 * STG;          // [2][HST][BM][160]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (provably uniform: the role branches below must be scalar branches)
   const bool role_a = wv < 4;
@@ -110,39 +126,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned rx = p.amax_x[sub], r1 = p.amax_w1[sub], r2 = p.amax_w2[sub], rb = p.amax_b1 ? p.amax_b1[sub] : 0u;
 
   // weight fragments: buffer loads — ONE address register per wavefront (its lane and its tiles), the chunk / k step as a scalar
-  // offset.  A: tile = c * 8 + wr * 2 + it of W1op (H rows, 8 k steps);  B: tile = wr * 4 + it of W2op (256 rows, H / 32 k steps)
+  // offset.  A: tile = c * 8 + wr * 2 + it of W1op (H rows, KS1 k steps);  B: tile = wr * TPB + it of W2op (C rows, H / 32 k steps)
   const int wbytes = p.H * C * 4;
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(role_a ? p.W1f : p.W2f), 0, wbytes, 0x00020000);
   const int nks2 = p.H / 32;
-  const int vW = lane * 16 + (role_a ? wr * 2 * XST * 2048 : wr * 4 * nks2 * 2048);
-  // load q (0 .. 7) of "step" t: A: t = c * 8 + ks (ks 0 .. 7), q = (t & 1) * 4 + it * 2 + pl  [4 loads per k step, ring = 2 k steps]
-  //                              B: t = c * 4 + ks (ks 0 .. 3), q = it * 2 + pl              [8 loads per k step, ring = 1 k step]
-  auto ld_a = [&](int t, int it, int pl) {  // t: global k-step index c * 8 + ks, clamped by the caller
-    const int c = t >> 3, ks = t & 7;
-    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, c * (8 * XST * 2048) + it * (XST * 2048) + ks * 2048 + pl * 1024, 0));
+  const int vW = lane * 16 + (role_a ? wr * 2 * KS1 * 2048 : wr * TPB * nks2 * 2048);
+  auto ld_a = [&](int c, int ks, int it, int pl) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, c * (8 * KS1 * 2048) + it * (KS1 * 2048) + ks * 2048 + pl * 1024, 0));
   };
   auto ld_b = [&](int t, int it, int pl) {  // t: global k-step index c * 4 + ks = the k step of W2op
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, it * nks2 * 2048 + t * 2048 + pl * 1024, 0));
   };
-  uint4 ring[FFN_RING];
+  uint4 ring[RING];
   if (role_a) {
 #pragma unroll
-    for (int q = 0; q < 4 * FFN_DA; ++q) ring[q] = ld_a(min(q >> 2, nch * 8 - 1), (q >> 1) & 1, q & 1);
-  } else {
+    for (int q = 0; q < 4 * DA; ++q) ring[q] = ld_a(0, q >> 2, (q >> 1) & 1, q & 1);  // (DA <= KS1: chunk 0)
+  } else if (wr < NB) {
 #pragma unroll
-    for (int q = 0; q < 8 * FFN_DB; ++q) ring[q] = ld_b(min(q >> 3, nch * 4 - 1), (q >> 1) & 3, q & 1);
+    for (int q = 0; q < 2 * TPB * FFN_DB; ++q) ring[q] = ld_b(min(q / (2 * TPB), nch * HST - 1), (q >> 1) % TPB, q & 1);
   }
 
-  // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores
+  // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores — no
+  // per-element guards (which cost a branch and a live 64-bit address per store of the chunk epilogue)
   const int rows_ok = min(BM, p.M - m0);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.Hid + (long)m0 * p.H, 0, rows_ok * p.H * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((GELU || GGRAD) ? p.Pre + (long)m0 * p.H : p.Hid, 0, rows_ok * p.H * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * C : p.X), 0, rows_ok * C * 4, 0x00020000);
 
   // the rows' planes -> LDS (all eight wavefronts)
   {
-    constexpr int NV = BM * (C / 4) / 512;
+    constexpr int TOT = BM * (C / 4), NV = (TOT + 511) / 512;
     float4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (tid + i * 512) * 16, 0, 0));
@@ -151,19 +166,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 512;
-      const int row = idx / (C / 4), kq = (idx % (C / 4)) * 4;
-      unsigned ab[3], cd[3];
-      split_pair_h(v[i].x, v[i].y, hx, ab);
-      split_pair_h(v[i].z, v[i].w, hx, cd);
-      unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
-      *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+      if (TOT % 512 == 0 || idx < TOT) {
+        const int row = idx / (C / 4), kq = (idx % (C / 4)) * 4;
+        if (p.xscale) {  // (the range word bounds the unscaled rows: a DropPath factor 1 / keep rides in the 8 x headroom of the scale)
+          const float f = p.xscale[min(m0 + row, p.M - 1) / p.rows_per];
+          v[i].x *= f; v[i].y *= f; v[i].z *= f; v[i].w *= f;
+        }
+        unsigned ab[3], cd[3];
+        split_pair_h(v[i].x, v[i].y, hx, ab);
+        split_pair_h(v[i].z, v[i].w, hx, cd);
+        unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+      }
     }
   }
   const unsigned ux = amax_fold(rx), u1 = amax_fold(r1), u2 = amax_fold(r2), ub = amax_fold(rb);
   const int ex = h3_scale_exp(ux), e1 = h3_scale_exp(u1), e2 = h3_scale_exp(u2);
-  // |hidden| <= C max|x| max|W1| + max|b1| (gating only shrinks it)
-  const float bound = (float)C * __uint_as_float(ux) * __uint_as_float(u1) + __uint_as_float(ub);
+  // |hidden| <= C max|x| max|W1| + max|b1|: relu / a gate only shrink it, |gelu(t)| <= |t|, |gelu'| < 1.13 (hence the 1.25); a
+  // DropPath factor on the rows of x (<= 2 for keep >= 0.5) rides in the scale's 8 x headroom
+  const float bound = ((float)C * __uint_as_float(ux) * __uint_as_float(u1) + __uint_as_float(ub)) * (GGRAD ? 1.25f : 1.f);
   const int eh = h3_scale_exp(__float_as_uint(bound));
   const H3Scale hh{__uint_as_float((unsigned)eh << 23), __uint_as_float((unsigned)(eh + 11) << 23)};
   const float invx = __uint_as_float((unsigned)(254 - ex) << 23), inv1 = __uint_as_float((unsigned)(254 - e1) << 23);
@@ -173,25 +195,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
 
   // The two roles are separate code paths (a scalar branch: wv is wave-uniform by construction), each with its own loop and its
-  // own nch + 1 barriers — A: [chunk c -> image c % 2; barrier] x nch, barrier;  B: barrier, [image c % 2 -> y; barrier] x nch — so
-  // that neither role's accumulators are live in the other's code (one loop with both roles inside kept 96 + 48 of them alive).
+  // own nch + 2 barriers, so that neither role's accumulators are live in the other's code.
   if (role_a) {
-    // The epilogue of chunk c - 1 (bias, gate, planes -> LDS image, fp32 chunk -> memory) RIDES IN THE K LOOP OF CHUNK c, one 16 x 16
-    // tile per k step: the matrix pipe takes an MFMA every 16 cycles and leaves three issue slots in between, so the ~65 VALU / LDS /
-    // memory instructions of a tile disappear between the 18 MFMAs of a step instead of standing alone at the end of the chunk,
+    // The epilogue of chunk c - 1 (bias, activation / gate, planes -> LDS image, fp32 chunk -> memory) RIDES IN THE K LOOP OF CHUNK c, SPK
+    // 16 x 16 tiles per k step: the matrix pipe takes an MFMA every 16 cycles and leaves three issue slots in between, so the VALU / LDS /
+    // memory instructions of a tile disappear between the MFMAs of a step instead of standing alone at the end of the chunk,
     // where the B partner — done with its own chunk — waited at the barrier (+20 us of 88: profiles/r6_ffn_lab.txt).  The k loop is
     // fully unrolled (tile and ring indices static) with a scheduling barrier per k step (unfenced, the scheduler hoists the
-    // fragment reads of all eight steps to the top and spills).  The image of chunk c - 1 is complete at the barrier that ends
+    // fragment reads of all steps to the top and spills).  The image of chunk c - 1 is complete at the barrier that ends
     // chunk c's loop: the B role runs two barriers behind.
     unsigned amxu = 0u;
     const int vH = (li * p.H + wr * 32 + 4 * kg) * 4;
-    const int tmax = nch * 8 - 1;
-    float4 pv[2][NT];  // chunk c - 1 before bias / gate
+    float4 pv[2][NT];  // chunk c - 1 before bias / activation
     float4 bvs[2];
+    float4 pres[GGRAD ? 2 : 1][GGRAD ? NT : 1];
     unsigned bits = 0u;
     auto slice = [&](int cp, int it, int n) {
       float v[4] = {pv[it][n].x, pv[it][n].y, pv[it][n].z, pv[it][n].w};
-      if (!GATE) {
+      const int soff = (n * 16 * p.H + cp * FFN_HC + it * 16) * 4;
+      if constexpr (MODE == FFN_RELU) {
+        // relu as compare + select (fmaxf canonicalises its operands: a v_cmp_class + v_cndmask per element on top of the v_max);
+        // the compare is the gate bit
         const float t[4] = {v[0] + bvs[it].x, v[1] + bvs[it].y, v[2] + bvs[it].z, v[3] + bvs[it].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -199,28 +223,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           v[r] = pos ? t[r] : 0.f;
           bits |= (unsigned)pos << ((it * NT + n) * 4 + r);
         }
-      } else {
+      } else if constexpr (GATE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe((int)bits, (it * NT + n) * 4 + r, 1));
+      } else if constexpr (GELU) {
+        const float4 t = make_float4(v[0] + bvs[it].x, v[1] + bvs[it].y, v[2] + bvs[it].z, v[3] + bvs[it].w);
+        store_b128(t, rP, vH, soff);
+        v[0] = gelu_f(t.x); v[1] = gelu_f(t.y); v[2] = gelu_f(t.z); v[3] = gelu_f(t.w);
+      } else {
+        const float4 t = pres[GGRAD ? it : 0][GGRAD ? n : 0];
+        v[0] *= gelu_grad_f(t.x); v[1] *= gelu_grad_f(t.y); v[2] *= gelu_grad_f(t.z); v[3] *= gelu_grad_f(t.w);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) amxu = max(amxu, __float_as_uint(v[r]) & 0x7fffffffu);
+      for (int r = 0; r < 4; ++r) amxu = max(amxu, __float_as_uint(v[r]) & 0x7fffffffu);  // (bit patterns of |v| order like the values)
       unsigned ab[3], cd[3];
       split_pair_h(v[0], v[1], hh, ab);
       split_pair_h(v[2], v[3], hh, cd);
+#ifndef FFN_ABL_NOIMG
       unsigned char* dst = hs + (cp & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8 + n * 16 * FFN_LDRB + it * 32;
       *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
       *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
-#ifndef FFN_ABL_NOHID
-      store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, (n * 16 * p.H + cp * FFN_HC + it * 16) * 4);
+#else
+      asm volatile("" ::"v"(ab[0]), "v"(ab[1]), "v"(cd[0]), "v"(cd[1]));
+#endif
+#ifndef FFN_ABL_NOHID  // (FFN_ABL_*: timing ablations of scripts/lab/ffn_abl.sh — results are wrong with any of them)
+      store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, soff);
 #endif
     };
-    auto pre_epi = [&](int cp) {  // what the slices of chunk cp need from memory: requested a k loop ahead of their first use
+    auto pre_epi = [&](int cp) {  // what the tiles of chunk cp need from memory: requested a k loop ahead of their first use
 #pragma unroll
       for (int it = 0; it < 2; ++it)
-        bvs[it] = (!GATE && p.b1) ? *reinterpret_cast<const float4*>(p.b1 + cp * FFN_HC + wr * 32 + it * 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
-      bits = GATE ? p.bits[(((long)blockIdx.x * nch + cp) * 4 + wr) * 64 + lane] : 0u;
+        bvs[it] = (FWD && p.b1) ? *reinterpret_cast<const float4*>(p.b1 + cp * FFN_HC + wr * 32 + it * 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (GATE) bits = p.bits[(((long)blockIdx.x * nch + cp) * 4 + wr) * 64 + lane];
+      else bits = 0u;
+      if constexpr (GGRAD) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            pres[it][n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, vH, (n * 16 * p.H + cp * FFN_HC + it * 16) * 4, 0));
+      }
     };
     auto kloop = [&](int c, auto with_epi) {
       constexpr bool EPI = decltype(with_epi)::value;
@@ -229,8 +272,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      const int cn = min(c + 1, nch - 1);  // (past the last chunk: a harmless re-read)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS1; ++ks) {
         uint4 xh[NT], xl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -238,10 +282,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           xh[n] = *reinterpret_cast<const uint4*>(q);
           xl[n] = *reinterpret_cast<const uint4*>(q + 64);
         }
-        const int tn = min(c * 8 + ks + FFN_DA, tmax);
+        // terms of gemm_h3_*: l h, h l into the second accumulator, h h into the first (weight = the MFMA's A operand).  A ring
+        // slot is refilled AFTER its last use, into the same registers (refilling it first made the compiler rotate the ring
+        // through copies, and every copy waits for the load it copies: the pipeline drained once per k step)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int slot = (ks % FFN_DA) * 4 + it * 2;
+          const int slot = (ks % DA) * 4 + it * 2;
           const uint4 wh = ring[slot], wl = ring[slot + 1];
 #pragma unroll
           for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wh, xl[n], hb[it][n]);
@@ -249,19 +295,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wl, xh[n], hb[it][n]);
 #pragma unroll
           for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
-          ring[slot] = ld_a(tn, it, 0);
-          ring[slot + 1] = ld_a(tn, it, 1);
+#ifndef FFN_ABL_NOB
+          if (ks + DA < KS1) { ring[slot] = ld_a(c, ks + DA, it, 0); ring[slot + 1] = ld_a(c, ks + DA, it, 1); }
+          else { ring[slot] = ld_a(cn, ks + DA - KS1, it, 0); ring[slot + 1] = ld_a(cn, ks + DA - KS1, it, 1); }
+#endif
         }
         if constexpr (EPI) {
-          if (ks < 2 * NT) {
-            slice(c - 1, ks / NT, ks % NT);  // (ends in store_b128's scheduling barrier)
-          }
+#pragma unroll
+          for (int t = ks * SPK; t < (ks + 1) * SPK; ++t)
+            if (t < 2 * NT) slice(c - 1, t / NT, t % NT);  // (ends in store_b128's scheduling barrier)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (EPI) {
-        if (!GATE) p.bits[(((long)blockIdx.x * nch + (c - 1)) * 4 + wr) * 64 + lane] = bits;
-      }
+      if constexpr (EPI && MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + (c - 1)) * 4 + wr) * 64 + lane] = bits;
       pre_epi(c);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
@@ -282,83 +328,87 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int t = 0; t < 2 * NT; ++t) slice(nch - 1, t / NT, t % NT);
-    if (!GATE) p.bits[(((long)blockIdx.x * nch + (nch - 1)) * 4 + wr) * 64 + lane] = bits;
+    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + (nch - 1)) * 4 + wr) * 64 + lane] = bits;
     __syncthreads();  // the last image is complete
     __syncthreads();  // (the B role's last barrier)
     amax_commit(p.amax_hid, __uint_as_float(amxu));
   } else {
-#ifdef FFN_PRIO_B
-    __builtin_amdgcn_s_setprio(FFN_PRIO_B);
-#endif
-    f32x4_t ya[4][NT], yb[4][NT];  // y tiles: columns wr * 64 + it * 16 .., rows n * 16 ..
+    f32x4_t ya[TPB][NT], yb[TPB][NT];  // y tiles: columns (wr * TPB + it) * 16 .., rows n * 16 ..
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < TPB; ++it)
 #pragma unroll
       for (int n = 0; n < NT; ++n) { ya[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; yb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const bool active = wr < NB;
     __syncthreads();
     __syncthreads();  // (image c is complete one barrier later: its epilogue rides in the k loop of chunk c + 1)
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-      // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32, columns wr * 64 + it * 16 ..
+      // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32
       const unsigned char* img = hs + (c & 1) * (HST * STG) + fo;
-      const int tmax = nch * 4 - 1;
+      const int tmax = nch * HST - 1;
 #ifndef FFN_ABL_NOPHASEB
+      if (active) {
 #pragma unroll 1
-      for (int kq = 0; kq < 4 / FFN_DB; ++kq)
+        for (int kq = 0; kq < HST / FFN_DB; ++kq)
 #pragma unroll
-      for (int u = 0; u < FFN_DB; ++u) {
-        const int ks = kq * FFN_DB + u;
-        uint4 gh[NT], gl[NT];
+          for (int u = 0; u < FFN_DB; ++u) {
+            const int ks = kq * FFN_DB + u;
+            uint4 gh[NT], gl[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const unsigned char* q = img + ks * STG + n * 16 * FFN_LDRB;
-          gh[n] = *reinterpret_cast<const uint4*>(q);
-          gl[n] = *reinterpret_cast<const uint4*>(q + 64);
-        }
-        const int tn = min(c * 4 + ks + FFN_DB, tmax);
+            for (int n = 0; n < NT; ++n) {
+              const unsigned char* q = img + ks * STG + n * 16 * FFN_LDRB;
+              gh[n] = *reinterpret_cast<const uint4*>(q);
+              gl[n] = *reinterpret_cast<const uint4*>(q + 64);
+            }
+            const int tn = min(c * HST + ks + FFN_DB, tmax);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const uint4 wh = ring[u * 8 + it * 2], wl = ring[u * 8 + it * 2 + 1];
+            for (int it = 0; it < TPB; ++it) {
+              const int slot = u * 2 * TPB + it * 2;
+              const uint4 wh = ring[slot], wl = ring[slot + 1];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wh, gl[n], yb[it][n]);
+              for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wh, gl[n], yb[it][n]);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wl, gh[n], yb[it][n]);
+              for (int n = 0; n < NT; ++n) yb[it][n] = mfma16(wl, gh[n], yb[it][n]);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) ya[it][n] = mfma16(wh, gh[n], ya[it][n]);
+              for (int n = 0; n < NT; ++n) ya[it][n] = mfma16(wh, gh[n], ya[it][n]);
 #ifndef FFN_ABL_NOB
-          ring[u * 8 + it * 2] = ld_b(tn, it, 0);  // (after the slot's last use: see the A role)
-          ring[u * 8 + it * 2 + 1] = ld_b(tn, it, 1);
-#else
-          asm volatile("" : "+v"(ring[u * 8 + it * 2].x), "+v"(ring[u * 8 + it * 2 + 1].x) : "s"(tn));
+              ring[slot] = ld_b(tn, it, 0);  // (after the slot's last use: see the A role)
+              ring[slot + 1] = ld_b(tn, it, 1);
 #endif
-        }
+            }
+          }
       }
 #endif
       __syncthreads();  // image c % 2 has been consumed
     }
-    // ---- y = (h h + (l h + h l) 2^-11) 2^-(s_hidden + s_w2) + b2 (+ resid): four consecutive columns of a row per lane
-    const int vY = (li * C + wr * 64 + 4 * kg) * 4;
-    float amy = 0.f;
+    // ---- y = ((h h + (l h + h l) 2^-11) 2^-(s_hidden + s_w2) + b2) * yscale (+ resid): four consecutive columns of a row per lane
+    if (active) {
+      const int vY = (li * C + wr * TPB * 16 + 4 * kg) * 4;
+      float amy = 0.f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.b2) bv = *reinterpret_cast<const float4*>(p.b2 + wr * 64 + it * 16 + 4 * kg);
-      float4 e[NT];
+      for (int it = 0; it < TPB; ++it) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.b2) bv = *reinterpret_cast<const float4*>(p.b2 + wr * TPB * 16 + it * 16 + 4 * kg);
+        float4 e[NT];
+        float ysc[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        e[n] = p.resid ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, vY, (n * 16 * C + it * 16) * 4, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < NT; ++n) {
+          e[n] = p.resid ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, vY, (n * 16 * C + it * 16) * 4, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ysc[n] = p.yscale ? p.yscale[min(m0 + n * 16 + li, p.M - 1) / p.rows_per] : 1.f;
+        }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        float4 v;
-        v.x = fmaf(yb[it][n][0], 0x1p-11f, ya[it][n][0]) * invh * inv2 + bv.x + e[n].x;
-        v.y = fmaf(yb[it][n][1], 0x1p-11f, ya[it][n][1]) * invh * inv2 + bv.y + e[n].y;
-        v.z = fmaf(yb[it][n][2], 0x1p-11f, ya[it][n][2]) * invh * inv2 + bv.z + e[n].z;
-        v.w = fmaf(yb[it][n][3], 0x1p-11f, ya[it][n][3]) * invh * inv2 + bv.w + e[n].w;
-        store_b128(v, rY, vY, (n * 16 * C + it * 16) * 4);
-        amy = amax4(amy, v);
+        for (int n = 0; n < NT; ++n) {
+          float4 v;
+          v.x = fmaf(fmaf(yb[it][n][0], 0x1p-11f, ya[it][n][0]) * invh * inv2 + bv.x, ysc[n], e[n].x);
+          v.y = fmaf(fmaf(yb[it][n][1], 0x1p-11f, ya[it][n][1]) * invh * inv2 + bv.y, ysc[n], e[n].y);
+          v.z = fmaf(fmaf(yb[it][n][2], 0x1p-11f, ya[it][n][2]) * invh * inv2 + bv.z, ysc[n], e[n].z);
+          v.w = fmaf(fmaf(yb[it][n][3], 0x1p-11f, ya[it][n][3]) * invh * inv2 + bv.w, ysc[n], e[n].w);
+          store_b128(v, rY, vY, (n * 16 * C + it * 16) * 4);
+          amy = amax4(amy, v);
+        }
       }
+      amax_commit(p.amax_y, amy);
     }
-    amax_commit(p.amax_y, amy);
   }
 }
 
@@ -421,53 +471,71 @@ extern "C" int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int t
   return check_launch("split_weights_frag");
 }
 
-// rows per workgroup: what leaves the fewest rounds x rows on 256 CUs (one workgroup per CU); 48 on ties (fewer weight reads)
-static int ffn_rows(int M) {
+// rows per workgroup: C = 256 (the encoder FFN, one 123 KB workgroup per CU): what leaves the fewest rounds x rows on 256 CUs, 48 on
+// ties (fewer weight reads); the Swin widths: 32 (two workgroups per CU: 56 / 72 KB of LDS)
+static int ffn_rows(int M, int C) {
+  if (C != 256) return 32;
   const long c48 = ((long)((M + 47) / 48) + 255) / 256 * 48, c32 = ((long)((M + 31) / 32) + 255) / 256 * 32;
   return c32 < c48 ? 32 : 48;
 }
 
-extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) { return (C == FFN_C && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0; }
+extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) {
+  return ((C == 256 || C == 192 || C == 96) && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0;
+}
 
-extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int H) {
-  const int bm = ffn_rows(M);
+extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int C, int H) {
+  const int bm = ffn_rows(M, C);
   return (int64_t)((M + bm - 1) / bm) * (H / FFN_HC) * 256;
 }
 
-template <int NT>
-static void ffn_launch(const FfnParams& p, int gate, hipStream_t s) {
-  constexpr size_t lds = ffn_lds_bytes<NT>();
+template <int C, int NT, int MODE>
+static void ffn_launch1(const FfnParams& p, hipStream_t s) {
+  constexpr size_t lds = ffn_lds_bytes<C, NT>();
   static bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<C, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return true;
   }();
   (void)attr_set;
-  const dim3 grid((unsigned)((p.M + 16 * NT - 1) / (16 * NT)));
-  if (gate) hipLaunchKernelGGL((ffn_h3_kernel<NT, true>), grid, dim3(512), lds, s, p);
-  else hipLaunchKernelGGL((ffn_h3_kernel<NT, false>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT))), dim3(512), lds, s, p);
+}
+
+template <int C, int NT>
+static void ffn_launch(const FfnParams& p, int mode, hipStream_t s) {
+  switch (mode) {
+    case FFN_RELU: ffn_launch1<C, NT, FFN_RELU>(p, s); break;
+    case FFN_RELU_GATE: ffn_launch1<C, NT, FFN_RELU_GATE>(p, s); break;
+    case FFN_GELU: ffn_launch1<C, NT, FFN_GELU>(p, s); break;
+    default: ffn_launch1<C, NT, FFN_GELU_GRAD>(p, s); break;
+  }
 }
 
 extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
-                             void* bits, int gate, float* Hid, const float* resid, float* Y, const uint32_t* amax_x,
-                             const uint32_t* amax_w1, const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid,
-                             uint32_t* amax_y, void* stream) {
-  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C == 256, H %% 128 == 0)", M, C, H);
-  if (!X || !W1f || !W2f || !bits || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
-  if (((uintptr_t)X | (uintptr_t)W1f | (uintptr_t)W2f | (uintptr_t)Hid | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)b1 | (uintptr_t)b2) & 15)
+                             int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
+                             const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
+                             const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, void* stream) {
+  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 192, 256}, H %% 128 == 0)", M, C, H);
+  if (mode < 0 || mode > 3) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d", mode);
+  if (!X || !W1f || !W2f || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
+  if (mode <= FFN_RELU_GATE ? !bits : !Pre) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d needs %s", mode, mode <= FFN_RELU_GATE ? "bits" : "Pre");
+  if ((xscale || yscale) && rows_per <= 0) return fail(RSCOTR_E_ARG, "ffn_h3: rows_per with a row scale");
+  if (((uintptr_t)X | (uintptr_t)W1f | (uintptr_t)W2f | (uintptr_t)Hid | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)b1 | (uintptr_t)b2 |
+       (uintptr_t)Pre) & 15)
     return fail(RSCOTR_E_ALIGN, "ffn_h3: operands must be 16-byte aligned");
   if ((long)M * H * 4 >= (1l << 32)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M * H too large for 32-bit buffer offsets");
+  const bool fwd = mode == FFN_RELU || mode == FFN_GELU;
   FfnParams p{};
   p.X = X; p.M = M; p.H = H;
-  p.W1f = static_cast<const uint4*>(W1f); p.b1 = gate ? nullptr : b1;
+  p.W1f = static_cast<const uint4*>(W1f); p.b1 = fwd ? b1 : nullptr;
   p.W2f = static_cast<const uint4*>(W2f); p.b2 = b2;
-  p.bits = static_cast<unsigned*>(bits); p.Hid = Hid; p.resid = resid; p.Y = Y;
-  p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = gate ? nullptr : amax_b1;
+  p.bits = static_cast<unsigned*>(bits); p.Pre = Pre; p.Hid = Hid; p.resid = resid; p.Y = Y;
+  p.xscale = xscale; p.yscale = yscale; p.rows_per = rows_per > 0 ? rows_per : 1;
+  p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = fwd ? amax_b1 : nullptr;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %s>", ffn_rows(M) / 16, gate ? "true" : "false");
-  if (ffn_rows(M) == 32) ffn_launch<2>(p, gate, s);
-  else ffn_launch<3>(p, gate, s);
+  const int bm = ffn_rows(M, C);
+  ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %d, %d>", C, bm / 16, mode);
+  if (C == 256) { if (bm == 32) ffn_launch<256, 2>(p, mode, s); else ffn_launch<256, 3>(p, mode, s); }
+  else if (C == 192) ffn_launch<192, 2>(p, mode, s);
+  else ffn_launch<96, 2>(p, mode, s);
   return check_launch("ffn_h3");
 }
-

@@ -745,19 +745,24 @@ RELU_BITS = _ReluBits()
 
 
 class _FusedFFN:
-    """The encoder FFN (Linear - ReLU - Linear, 256 -> H -> 256) as ONE launch per direction (rscotr_ffn_h3, csrc/ffn.hip): forward
-    y = relu(x W1^T + b1) W2^T + b2 (+ identity) with the hidden tensor leaving the kernel for the weight gradients only;
-    backward dH = (g W2) * gate, dX = dH W1 (+ g) with the mirrored call.  Taken where both weights are parameters of the
-    optimizer's arena (their planes and range words live there) and the value ranges are on."""
+    """A two-layer MLP block as ONE launch per direction (rscotr_ffn_h3, csrc/ffn.hip): the encoder FFN (Linear - ReLU - Linear,
+    256 -> H -> 256) and the MLP of the Swin blocks of stages 1 and 2 (Linear - GELU - Linear with DropPath, C = 96 / 192):
+    forward y = act(x W1^T + b1) W2^T + b2 [* out_scale] (+ identity) with the hidden tensor leaving the kernel for the weight
+    gradients only; backward dH = (g W2) * act', dX = dH W1 (+ g) with the mirrored call.  Taken where both weights are
+    parameters of the optimizer's arena (their planes and range words live there) and the value ranges are on."""
 
     MIN_ROWS = int(os.environ.get('RSCOTR_FFN_FUSED_MIN_ROWS', 2048))
+    MODE = {(ACT_RELU, 0): 0, (ACT_RELU, 1): 1, (ACT_GELU, 0): 2, (ACT_GELU, 1): 3}
 
     def __init__(self):
         self.enabled = os.environ.get('RSCOTR_FFN_FUSED', '1') != '0'
+        self.gelu = os.environ.get('RSCOTR_FFN_FUSED_GELU', '1') != '0'  # (the Swin route on its own switch: A/B runs)
         self.calls = 0
 
     def ok(self, x2, ws, act, out_scale, sum_with):
-        if not self.enabled or not RANGES.enabled or len(ws) != 2 or act != ACT_RELU or out_scale is not None or sum_with is not None:
+        if not self.enabled or not RANGES.enabled or len(ws) != 2 or act not in (ACT_RELU, ACT_GELU) or sum_with is not None:
+            return False
+        if act == ACT_GELU and not self.gelu:
             return False
         sink = STATE.grad_sink
         (H, C), (C2, H2) = ws[0].shape, ws[1].shape
@@ -768,9 +773,10 @@ class _FusedFFN:
             return False
         return bool(lib.rscotr_ffn_h3_ok(M, C, H))
 
-    def run(self, x2, W1, b1, W2, b2, bits, gate, resid, want_y_range):
+    def run(self, x2, W1, b1, W2, b2, act, aux, gate, resid, want_y_range, xscale=None, yscale=None, rows_per=0):
         """gate = 0: (W1, W2) are the two Linear weights as stored, (out, in); gate = 1: the mirrored products, W1 := W2 and
-        W2 := W1 of the forward, both taken transposed.  -> (hid, y)."""
+        W2 := W1 of the forward, both taken transposed.  aux: the gate bits (ReLU) or the pre-activation (GELU), written by the
+        forward call and read by the mirrored one.  -> (hid, y)."""
         M, C = x2.shape
         H = W1.shape[1] if gate else W1.shape[0]
         dev = x2.device
@@ -789,8 +795,10 @@ class _FusedFFN:
         if want_y_range:
             s_y = RANGES.new_slot(dev)
             RANGES.tag(y, s_y)
-        lib.call('rscotr_ffn_h3', x2.data_ptr(), M, C, H, w1f, _ptr(b1), w2f, _ptr(b2), bits.data_ptr(), int(gate), hid.data_ptr(),
-                 _ptr(resid), y.data_ptr(), s_x, s_w1, s_w2, s_b1, s_h, s_y, _stream())
+        relu = act == ACT_RELU
+        lib.call('rscotr_ffn_h3', x2.data_ptr(), M, C, H, w1f, _ptr(b1), w2f, _ptr(b2), self.MODE[(act, int(gate))],
+                 aux.data_ptr() if relu else 0, 0 if relu else aux.data_ptr(), hid.data_ptr(), _ptr(resid), y.data_ptr(),
+                 _ptr(xscale), _ptr(yscale), int(rows_per), s_x, s_w1, s_w2, s_b1, s_h, s_y, _stream())
         self.calls += 1
         return hid, y
 
@@ -838,10 +846,13 @@ class _MLP(Function):
         if ctx.fused:
             W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
             W2 = ws[1] if ws[1].is_contiguous() else ws[1].contiguous()
-            bits = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, W1.shape[0])), dtype=torch.int32, device=x2.device)
-            hid, h = FFN_FUSED.run(x2, W1, bs[0], W2, bs[1], bits, 0, id2, want_last)
+            if act == ACT_RELU:  # the gate as one bit per element
+                aux = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, K0, W1.shape[0])), dtype=torch.int32, device=x2.device)
+            else:  # GELU: the pre-activation
+                aux = torch.empty((M, W1.shape[0]), dtype=torch.float32, device=x2.device)
+            hid, h = FFN_FUSED.run(x2, W1, bs[0], W2, bs[1], act, aux, 0, id2, want_last, yscale=out_scale, rows_per=rows_per)
             hs.append(hid)
-            auxs.append(bits)
+            auxs.append(aux)
             n = 0  # (the loop below has nothing left to do)
         for i in range(n):
             W = ws[i] if ws[i].is_contiguous() else ws[i].contiguous()
@@ -941,7 +952,9 @@ class _MLP(Function):
             # the mirrored pair dH = (g W2) * gate, dX = dH W1 (+ dy when the identity is the input) as ONE launch (ops.FFN_FUSED)
             W2, _ = param_grads(1, g)
             W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
-            dH, dx = FFN_FUSED.run(g, W2, None, W1, None, auxs[0], 1, g_out if ctx.id_is_x else None, False)
+            # (a DropPath'ed block: the upstream gradient of both products is s_b * dy — the rows are scaled while they are staged)
+            dH, dx = FFN_FUSED.run(g, W2, None, W1, None, act, auxs[0], 1, g_out if ctx.id_is_x else None, False,
+                                   xscale=ctx.out_scale, rows_per=ctx.rows_per)
             param_grads(0, dH)
             dx = RANGES.carry(dx, dx.view(ctx.x_shape)) if ctx.needs_input_grad[0] else None
             return (dx, d_id, None, None, None, *grads_wb)

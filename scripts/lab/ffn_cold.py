@@ -14,7 +14,10 @@ dev = torch.device('cuda:0')
 only_fused = 'fused' in sys.argv[1:]
 args = [a for a in sys.argv[1:] if a != 'fused']
 M = int(args[0]) if args else 10880
-C, H = 256, 2048
+C = int(args[1]) if len(args) > 1 else 256
+H = int(args[2]) if len(args) > 2 else (2048 if C == 256 else 4 * C)
+GELU = C != 256
+ACT = ops.ACT_GELU if GELU else ops.ACT_RELU
 
 
 def run(fns, reps=3):
@@ -40,31 +43,37 @@ gs = [torch.randn(M, C, device=dev) for _ in range(nsets)]
 ops.RANGES.begin(dev)
 for t in xs + gs:
     ops.RANGES.of(t, M, C, C)
-bits_f = [torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, H)), dtype=torch.int32, device=dev) for _ in range(nsets)]
-bits_u = [torch.empty(M * H // 64, dtype=torch.int64, device=dev) for _ in range(nsets)]
+bits_f = [torch.empty((M, H), dtype=torch.float32, device=dev) if GELU else torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, C, H)), dtype=torch.int32, device=dev) for _ in range(nsets)]
+bits_u = [torch.empty(max(M * H // 64, 1), dtype=torch.int64, device=dev) for _ in range(nsets)]
 hids = [None] * nsets
 
 
 def fwd_fused(i):
-    hids[i], _ = ops.FFN_FUSED.run(xs[i], W1, b1, W2, b2, bits_f[i], 0, xs[i], False)
+    hids[i], _ = ops.FFN_FUSED.run(xs[i], W1, b1, W2, b2, ACT, bits_f[i], 0, xs[i], False)
 
 
 def bwd_fused(i):
-    ops.FFN_FUSED.run(gs[i], W2, None, W1, None, bits_f[i], 1, gs[i], False)
+    ops.FFN_FUSED.run(gs[i], W2, None, W1, None, ACT, bits_f[i], 1, gs[i], False)
 
 
 def fwd_unfused(i):
-    h = ops.gemm(xs[i], W1, M, H, C, C, C, 0, 0, bias=b1, act=ops.ACT_RELU_BITS, pre=bits_u[i])
+    if GELU:
+        h = ops.gemm(xs[i], W1, M, H, C, C, C, 0, 0, bias=b1, act=ops.ACT_GELU, pre=bits_f[i])
+    else:
+        h = ops.gemm(xs[i], W1, M, H, C, C, C, 0, 0, bias=b1, act=ops.ACT_RELU_BITS, pre=bits_u[i])
     ops.gemm(h, W2, M, C, H, H, H, 0, 0, bias=b2, resid=xs[i], range_out=False)
 
 
 def bwd_unfused(i):
-    dh = ops.gemm(gs[i], W2, M, H, C, C, H, 0, 1, act=ops.ACT_RELU_GRAD_BITS, aux=bits_u[i])
+    if GELU:
+        dh = ops.gemm(gs[i], W2, M, H, C, C, H, 0, 1, act=ops.ACT_GELU_GRAD, aux=bits_f[i])
+    else:
+        dh = ops.gemm(gs[i], W2, M, H, C, C, H, 0, 1, act=ops.ACT_RELU_GRAD_BITS, aux=bits_u[i])
     ops.gemm(dh, W1, M, C, H, H, C, 0, 1, resid=gs[i], range_out=False)
 
 
 res = dict(M=M, C=C, H=H, nsets=nsets)
-relu_ok = ops.RELU_BITS.ok(M, H, C, C)
+relu_ok = GELU or ops.RELU_BITS.ok(M, H, C, C)
 res['relu_bits_unfused'] = bool(relu_ok)
 for name, f in (('fwd_fused', fwd_fused), ('bwd_fused', bwd_fused), ('fwd_unfused', fwd_unfused), ('bwd_unfused', bwd_unfused)):
     if 'unfused' in name and (not relu_ok or only_fused):

@@ -12,9 +12,9 @@ ps = [torch.nn.Parameter((torch.randn(s, generator=g) * sc).to(dev)) for s, sc i
 opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
 W1, b1, W2, b2 = [p.data for p in ps]
 ops.RANGES.begin(dev)
-bits = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, H)), dtype=torch.int32, device=dev)
+bits = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, C, H)), dtype=torch.int32, device=dev)
 for rep in range(3):
-    hid, y = ops.FFN_FUSED.run(x, W1, b1, W2, b2, bits, 0, None, True)
+    hid, y = ops.FFN_FUSED.run(x, W1, b1, W2, b2, ops.ACT_RELU, bits, 0, None, True)
     h64 = torch.relu(x.double() @ W1.double().T + b1.double())
     bad = ((hid.double() - h64).abs() > 1e-4) | ~torch.isfinite(hid)
     idx = bad.nonzero()

@@ -87,8 +87,8 @@ def test_fused_ffn_hidden_and_range_words(cuda):
     try:
         ops.RANGES.begin(cuda)
         W1, b1, W2, b2 = [p.data for p in ps]
-        bits = torch.empty(int(ops.lib.rscotr_ffn_h3_bits_words(M, H)), dtype=torch.int32, device=cuda)
-        hid, y = ops.FFN_FUSED.run(x, W1, b1, W2, b2, bits, 0, None, True)
+        bits = torch.empty(int(ops.lib.rscotr_ffn_h3_bits_words(M, C, H)), dtype=torch.int32, device=cuda)
+        hid, y = ops.FFN_FUSED.run(x, W1, b1, W2, b2, ops.ACT_RELU, bits, 0, None, True)
         pre64 = x.double() @ W1.double().T + b1.double()
         h64 = torch.relu(pre64)
         assert float((hid.double() - h64).abs().max() / h64.abs().max()) < 1e-6
@@ -97,7 +97,7 @@ def test_fused_ffn_hidden_and_range_words(cuda):
         word = lambda s: float(ops.RANGES.buf[:, ops.RANGES.index(s)].view(torch.float32).max())
         assert word(ops.RANGES.slot_of(hid)) == float(hid.abs().max())
         assert word(ops.RANGES.slot_of(y)) == float(y.abs().max())
-        dH, dx = ops.FFN_FUSED.run(dy, W2, None, W1, None, bits, 1, None, False)
+        dH, dx = ops.FFN_FUSED.run(dy, W2, None, W1, None, ops.ACT_RELU, bits, 1, None, False)
         dH64 = (dy.double() @ W2.double()) * (hid > 0)  # gated by the bits the forward left = [hid > 0]
         assert float((dH.double() - dH64).abs().max() / dH64.abs().max()) < 1e-6
         assert bool(((dH != 0) <= (hid > 0)).all())
@@ -122,5 +122,63 @@ def test_fused_ffn_with_a_loose_bound_keeps_fp32_accuracy(cuda):
         for got, ref in [(yf, y64), (dxf, dx64)] + list(zip(gpf, gp64)):
             assert _rel(got, ref) <= 1e-6
     finally:
+        ops.DEFER.drop()
+        opt.close()
+
+
+def _gelu64(t):
+    return 0.5 * t * (1.0 + torch.erf(t * 0.7071067811865476))
+
+
+def _gelu_grad64(t):
+    return 0.5 * (1.0 + torch.erf(t * 0.7071067811865476)) + t * torch.exp(-0.5 * t * t) * 0.3989422804014327
+
+
+@pytest.mark.parametrize('B,L,C,drop', [(2, 16384, 96, True), (2, 4096, 192, True), (2, 4096, 192, False), (1, 2500, 96, True), (3, 1000, 192, True)])
+def test_fused_swin_mlp_matches_fp64_and_the_two_product_route(cuda, B, L, C, drop):
+    """The MLP of a Swin block (Linear - GELU - Linear, H = 4 C, DropPath folded in as a per-sample factor, the identity a separate
+    tensor) on the fused route: output, input gradient and the four parameter gradients against fp64 and against the
+    two-product route, ragged row counts included."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    H = 4 * C
+    g = torch.Generator().manual_seed(B * L + C)
+    x = torch.randn(B, L, C, generator=g).to(cuda)
+    ident = torch.randn(B, L, C, generator=g).to(cuda)
+    dy = torch.randn(B, L, C, generator=g).to(cuda)
+    scale = (torch.tensor([1.25, 0.0, 1.25][:B]) if drop else None)
+    ps = [torch.nn.Parameter((torch.randn(sh, generator=g) * sc).to(cuda)) for sh, sc in (((H, C), 0.1), ((H,), 0.3), ((C, H), 0.05), ((C,), 0.3))]
+    opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
+    old = ops.FFN_FUSED.enabled
+    try:
+        xd, w1, b1, w2, b2 = x.double().cpu(), *[p.detach().double().cpu() for p in ps]
+        sd = torch.ones(B, dtype=torch.float64) if scale is None else scale.double()
+        pre = xd @ w1.T + b1
+        h = _gelu64(pre)
+        y64 = (h @ w2.T + b2) * sd[:, None, None] + ident.double().cpu()
+        gy = dy.double().cpu() * sd[:, None, None]
+        gh = (gy @ w2) * _gelu_grad64(pre)
+        ref = [y64, gh @ w1, gh.reshape(-1, H).T @ xd.reshape(-1, C), gh.sum((0, 1)), gy.reshape(-1, C).T @ h.reshape(-1, H), gy.sum((0, 1))]
+        res = {}
+        for fused in (True, False):
+            ops.FFN_FUSED.enabled = fused
+            for p in ps:
+                p.grad.zero_()
+            xx = x.clone().requires_grad_(True)
+            ops.RANGES.begin(cuda)
+            n0 = ops.FFN_FUSED.calls
+            y = ops.mlp(xx, [(ps[0], ps[1]), (ps[2], ps[3])], act='gelu', identity=ident, out_scale=None if scale is None else scale.to(cuda))
+            y.backward(dy)
+            ops.flush_deferred()
+            torch.cuda.synchronize()
+            assert (ops.FFN_FUSED.calls - n0 == 2) == fused
+            res[fused] = [y.detach(), xx.grad.detach()] + [p.grad.detach().clone() for p in ps]
+        errs = [(i, _rel(a, r), _rel(b, r)) for i, (a, b, r) in enumerate(zip(res[True], res[False], ref))]
+        assert all(torch.isfinite(a).all() for a in res[True])
+        assert all(e_f <= max(1e-6, 1.5 * e_u) for _, e_f, e_u in errs), errs
+    finally:
+        ops.FFN_FUSED.enabled = old
         ops.DEFER.drop()
         opt.close()
