@@ -319,6 +319,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
           pv[it][n].w = fmaf(hb[it][n][3], 0x1p-11f, ha[it][n][3]) * invx * inv1;
         }
     };
+#ifdef FFN_ABL_NOPIPE  // (timing ablation: every chunk's epilogue right behind its own k loop; the B role then reads an image too early)
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      kloop(c, std::false_type{});
+#pragma unroll
+      for (int t = 0; t < 2 * NT; ++t) slice(c, t / NT, t % NT);
+      if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + c) * 4 + wr) * 64 + lane] = bits;
+      __syncthreads();
+    }
+    __syncthreads();
+    __syncthreads();
+#else
     kloop(0, std::false_type{});
     __syncthreads();
 #pragma unroll 1
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + (nch - 1)) * 4 + wr) * 64 + lane] = bits;
     __syncthreads();  // the last image is complete
     __syncthreads();  // (the B role's last barrier)
+#endif
     amax_commit(p.amax_hid, __uint_as_float(amxu));
   } else {
     f32x4_t ya[TPB][NT], yb[TPB][NT];  // y tiles: columns (wr * TPB + it) * 16 .., rows n * 16 ..

@@ -72,7 +72,12 @@ def oracle_step_fp64(P, model_cfg, batch_cpu, rnd_cpu, orec32=None, relu_band=No
 
 
 def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2, P=None, inject_decisions=True,
-                  fp64=False, **batch_kw):
+                  fp64=False, opt=None, **batch_kw):
+    """opt: a FlatAdamW over the model's parameters — the step then runs as it does under the runner: parameters and gradients
+    in the optimizer's flat arenas, weight gradients written / accumulated straight into the gradient arena (ops.STATE.grad_sink),
+    the deferred grouped contractions flushed after backward, and the routes that need a parameter's arena address (pre-split
+    weight planes, the fused FFN / Swin MLP launches) ACTIVE.  Without it those routes are off and every gradient goes through
+    autograd's AccumulateGrad."""
     batch_cpu = synth.make_batch(task, batch_size, size, seed=seed, **batch_kw)
     rnd_cpu = synth.make_rnd(model, batch_cpu, seed=seed)
     batch_dev = synth.make_batch(task, batch_size, size, seed=seed, device=device, **batch_kw)
@@ -82,10 +87,16 @@ def run_step_pair(model, model_cfg, task, size, seed, device='cpu', batch_size=2
     for p in P.values():
         if p.requires_grad:
             p.grad = None
-    model.zero_grad(set_to_none=True)
+    if opt is None:
+        model.zero_grad(set_to_none=True)
+    else:
+        opt.zero_grad()
     rec, orec = {}, {}
     out = model.train_step(dict(batch_dev, rnd=rnd_dev, record=rec))
     out['loss'].backward()
+    if opt is not None:
+        from rscotr_amd import ops
+        ops.flush_deferred()
     if task == 'seg' and inject_decisions:
         # hard decisions of the step (the `sigmoid(mask) < 0.5` attention masks) are compared
         # bit-wise in check_step_pair; the continuous part is compared under identical decisions

@@ -117,3 +117,28 @@ def test_mlvl_cls_head_variant(cuda, scheme, size):
     # (scheme 7 at 224^2: every tensor within 1.2 x max(eo, amb), the median inside the step's coin-toss band — the one case of
     # this file where the median gate is the relative one: tests/parity.py, ANCHOR_K_MED)
     check_step_pair(model, out, oout, rec, orec, P, median_rel=scheme == 7)
+
+
+@pytest.mark.parametrize('task', ['cls', 'det', 'seg'])
+def test_train_step_main_config_512_on_the_optimizer_arena(task, cuda):
+    """BASELINE configs[1] against the oracle AS THE RUNNER EXECUTES IT: parameters and gradients in FlatAdamW's arenas, the gradient
+    sink armed — which is what switches on the routes keyed by a parameter's arena address: weight operands from pre-split fp16
+    planes (ops.HPLANES) and the fused two-Linear launches (ops.FFN_FUSED: encoder FFN in det / seg, Swin stage 1-2 MLPs in all
+    three).  The plain whole-step tests above run without an optimizer and never take them."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW, build_param_groups
+    cfg, mcfg = load_model_cfg(tiny=False)
+    model = build_model(mcfg, seed=4).to(cuda)
+    opt = FlatAdamW(build_param_groups(model, dict(type='AdamW', lr=1e-4, weight_decay=0.05)))
+    try:
+        n0, h0 = ops.FFN_FUSED.calls, len(ops.HPLANES.entries)
+        with ranges_checked():
+            out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda, fp64=True, opt=opt)
+        if ops.RANGES.enabled and ops.FFN_FUSED.enabled:
+            # Swin stages 1-2: 4 blocks x (forward + backward); the shared encoder: 6 layers x 2 (det, seg)
+            assert ops.FFN_FUSED.calls - n0 == (8 if task == 'cls' else 20), ops.FFN_FUSED.calls - n0
+            assert len(ops.HPLANES.entries) > h0
+        check_step_pair(model, out, oout, rec, orec, P)
+    finally:
+        ops.DEFER.drop()
+        opt.close()
