@@ -230,7 +230,7 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
  *     0  hid = relu(X' W1op^T + b1), the gate [hid > 0] written to `bits`        1  hid = (X' W1op^T) * bit read from `bits`
  *     2  Pre = X' W1op^T + b1 stored, hid = gelu(Pre) (erf form)                  3  hid = (X' W1op^T) * gelu'(Pre), Pre read
  *     Y = (hid W2op^T + b2) * yscale[row / rows_per] + resid,   X' = X * xscale[row / rows_per]   (scales / resid optional)
- * hid (M, H) is stored fp32 (the weight gradients read it).  X (M, C) row-major fp32, C in {96, 192, 256}, H % 128 == 0
+ * hid (M, H) is stored fp32 (the weight gradients read it).  X (M, C) row-major fp32, C in {96, 128, 192, 256}, H % 128 == 0
  * (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight operands, W1op (H rows, reduction C) and W2op (C rows,
  * reduction H), written by rscotr_gemm_split_weights_frag — table rows as rscotr_gemm_split_weights_h3 (column 5 unused); plane
  * rows % 16 == 0, reduction % 32 == 0; layout uint4 [row / 16][k / 32][h | l][lane]: the weight operand of a wavefront's

@@ -484,6 +484,8 @@ extern "C" int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int t
   return check_launch("split_weights_frag");
 }
 
+// (C = 384 — Swin-T stage 3, 2048 rows — was instantiated and measured: 71 / 67 us against 45 / 46 for the two products; 64 workgroups each
+// stream 4.7 MB of weight planes: profiles/r6_ffn_lab.txt.  C = 128 is Swin-B's stage 1.)
 // rows per workgroup: C = 256 (the encoder FFN, one 123 KB workgroup per CU): what leaves the fewest rounds x rows on 256 CUs, 48 on
 // ties (fewer weight reads); the Swin widths: 32 (two workgroups per CU: 56 / 72 KB of LDS)
 static int ffn_rows(int M, int C) {
@@ -493,7 +495,7 @@ static int ffn_rows(int M, int C) {
 }
 
 extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) {
-  return ((C == 256 || C == 192 || C == 96) && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0;
+  return ((C == 256 || C == 192 || C == 128 || C == 96) && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0;
 }
 
 extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int C, int H) {
@@ -526,7 +528,7 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
                              int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
                              const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
                              const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, void* stream) {
-  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 192, 256}, H %% 128 == 0)", M, C, H);
+  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 128, 192, 256}, H %% 128 == 0)", M, C, H);
   if (mode < 0 || mode > 3) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d", mode);
   if (!X || !W1f || !W2f || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
   if (mode <= FFN_RELU_GATE ? !bits : !Pre) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d needs %s", mode, mode <= FFN_RELU_GATE ? "bits" : "Pre");
@@ -549,6 +551,7 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %d, %d>", C, bm / 16, mode);
   if (C == 256) { if (bm == 32) ffn_launch<256, 2>(p, mode, s); else ffn_launch<256, 3>(p, mode, s); }
   else if (C == 192) ffn_launch<192, 2>(p, mode, s);
+  else if (C == 128) ffn_launch<128, 2>(p, mode, s);
   else ffn_launch<96, 2>(p, mode, s);
   return check_launch("ffn_h3");
 }

@@ -134,7 +134,8 @@ def _gelu_grad64(t):
     return 0.5 * (1.0 + torch.erf(t * 0.7071067811865476)) + t * torch.exp(-0.5 * t * t) * 0.3989422804014327
 
 
-@pytest.mark.parametrize('B,L,C,drop', [(2, 16384, 96, True), (2, 4096, 192, True), (2, 4096, 192, False), (1, 2500, 96, True), (3, 1000, 192, True)])
+@pytest.mark.parametrize('B,L,C,drop', [(2, 16384, 96, True), (2, 4096, 192, True), (2, 4096, 192, False), (1, 2500, 96, True), (3, 1000, 192, True),
+                                        (1, 4100, 128, True)])
 def test_fused_swin_mlp_matches_fp64_and_the_two_product_route(cuda, B, L, C, drop):
     """The MLP of a Swin block (Linear - GELU - Linear, H = 4 C, DropPath folded in as a per-sample factor, the identity a separate
     tensor) on the fused route: output, input gradient and the four parameter gradients against fp64 and against the
