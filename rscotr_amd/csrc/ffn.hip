@@ -430,6 +430,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 //  planes, 16-byte stores — 12.9 us per 10880 x 256 x 256 launch against 14.1 for the tiled 64 x 64 kernel in the cold lab, but
 //  31.22 against 31.06 ms per round in the step: with one product per launch there is nothing to overlap the staging phase with.)
 
+// (Measured and removed, second attempt, profiles/r6_ffn_lab.txt item 8: a rows-resident ONE-product kernel for the small row counts
+//  — Swin stage 3 / 4 at 2048 / 512 rows, the decoders' 1600- / 200-row Linears; a workgroup = 32 rows x a column slice, all of K staged
+//  once, no barrier in the k loop.  Kernel durations 11.1 us against 15.3 (2048 x 384 x 384), 11.1 against 20.7 (512 x 768 x 768), 8.0
+//  against 9.5-10.1 (1600 x 256 x 256), equal at N >= 1536, 36-40 against 19.7 at K = 2048; in the step +1.35 ms per round.)
+
 // Fragment-major fp16 planes of a weight for ffn_h3_kernel (rscotr_gemm_split_weights_frag): table rows {W, planes, rows of W,
 // cols of W, ldw, 0, first block, transposed, range word of the parameter} (int64 x 9, as rscotr_gemm_split_weights_h3).
 // transposed = 0: plane rows n = rows of W, reduction k over its columns (y = x W^T); 1: plane rows = columns of W, reduction over
@@ -555,3 +560,4 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   else ffn_launch<96, 2>(p, mode, s);
   return check_launch("ffn_h3");
 }
+
