@@ -159,7 +159,11 @@ class _WeightPlanesH:
                 # W itself; a k-major one is the (K, N) matrix W whose TRANSPOSE is multiplied
                 rows.append((ptr, e['planes'].data_ptr(), K if tr else N, N if tr else K, ldb, e['rpad'], first, tr, e['word']))
                 first += e['blocks']
-            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+            # (a table first needed while a hipGraph is being captured — a parameter set no warm-up iteration touched — goes through
+            #  the pinned staging buffers of the deferred-work tables: a pageable host-to-device copy is not capturable)
+            hit = (DEFER._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first)
+            if not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+                self.tables[stale] = hit  # (a table built inside a capture lives in the graph's private pool: not for later eager calls)
         if os.environ.get('RSCOTR_HPLANES_DEBUG'):
             import sys
             print(f'[hplanes] group {self.current}: re-split {hit[1]} of {len(keys)} sets, {hit[2]} blocks (version {self.version})', file=sys.stderr, flush=True)
@@ -205,7 +209,9 @@ class _WeightPlanesF(_WeightPlanesH):
                 e = self.entries[key]
                 rows.append((ptr, e['planes'].data_ptr(), wr, wc, ldw, 0, first, tr, e['word']))
                 first += e['blocks']
-            hit = self.tables[stale] = (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), first)
+            hit = (DEFER._upload(np.asarray(rows, dtype=np.int64), dev), len(rows), first)
+            if not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+                self.tables[stale] = hit
         lib.call('rscotr_gemm_split_weights_frag', hit[0].data_ptr(), hit[1], hit[2], _stream())
         for k in stale:
             self.entries[k]['version'] = self.version
