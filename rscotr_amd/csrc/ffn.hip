@@ -137,13 +137,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   auto ld_b = [&](int t, int it, int pl) {  // t: global k-step index c * 4 + ks = the k step of W2op
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, it * nks2 * 2048 + t * 2048 + pl * 1024, 0));
   };
+#ifdef FFN_NO_STAGGER
+  const int c0r = 0;
+#else
+  const int c0r = C == 256 ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;  // (= c0 below: the first chunk of this workgroup)
+#endif
   uint4 ring[RING];
   if (role_a) {
 #pragma unroll
-    for (int q = 0; q < 4 * DA; ++q) ring[q] = ld_a(0, q >> 2, (q >> 1) & 1, q & 1);  // (DA <= KS1: chunk 0)
+    for (int q = 0; q < 4 * DA; ++q) ring[q] = ld_a(c0r, q >> 2, (q >> 1) & 1, q & 1);  // (DA <= KS1: the first chunk)
   } else if (wr < NB) {
 #pragma unroll
-    for (int q = 0; q < 2 * TPB * FFN_DB; ++q) ring[q] = ld_b(min(q / (2 * TPB), nch * HST - 1), (q >> 1) % TPB, q & 1);
+    for (int q = 0; q < 2 * TPB * FFN_DB; ++q) ring[q] = ld_b(c0r * HST + min(q / (2 * TPB), HST - 1), (q >> 1) % TPB, q & 1);
   }
 
   // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores — no
@@ -192,6 +197,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const float invh = __uint_as_float((unsigned)(254 - eh) << 23), inv2 = __uint_as_float((unsigned)(254 - e2) << 23);
 
   const int fo = li * FFN_LDRB + kg * 16;  // the lane's part of a fragment address: row li of a 16-row tile, 16 bytes at k = 8 kg
+  // Chunk ORDER is rotated per workgroup: the ~28 workgroups of an XCD otherwise all want the same weight fragments at the same time —
+  // cold for that L2 in the step, where twelve layers' plane sets pass through it per iteration — and then all hit the same lines.
+  // Loop index c -> chunk (c + c0) % nch; the image parity stays the loop index's.  (The order of the output's partial sums
+  // becomes a function of the row tile: still fixed by the launch geometry, bit-reproducible.)
+#ifdef FFN_NO_STAGGER
+  const int c0 = 0;
+#else
+  const int c0 = C == 256 ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
+#endif
+  auto chunk_of = [&](int c) {
+    if constexpr (C != 256) return c;
+    const int v = c + c0;
+    return v >= nch ? v - nch : v;
+  };
   __syncthreads();
 
   // The two roles are separate code paths (a scalar branch: wv is wave-uniform by construction), each with its own loop and its
@@ -210,7 +229,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     float4 bvs[2];
     float4 pres[GGRAD ? 2 : 1][GGRAD ? NT : 1];
     unsigned bits = 0u;
-    auto slice = [&](int cp, int it, int n) {
+    auto slice = [&](int cl, int it, int n) {  // cl: loop index of the chunk (image parity), cp: the chunk itself
+      const int cp = chunk_of(cl);
       float v[4] = {pv[it][n].x, pv[it][n].y, pv[it][n].z, pv[it][n].w};
       const int soff = (n * 16 * p.H + cp * FFN_HC + it * 16) * 4;
       if constexpr (MODE == FFN_RELU) {
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       split_pair_h(v[0], v[1], hh, ab);
       split_pair_h(v[2], v[3], hh, cd);
 #ifndef FFN_ABL_NOIMG
-      unsigned char* dst = hs + (cp & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8 + n * 16 * FFN_LDRB + it * 32;
+      unsigned char* dst = hs + (cl & 1) * (HST * STG) + wr * STG + li * FFN_LDRB + kg * 8 + n * 16 * FFN_LDRB + it * 32;
       *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
       *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
 #else
@@ -251,7 +271,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       store_b128(make_float4(v[0], v[1], v[2], v[3]), rH, vH, soff);
 #endif
     };
-    auto pre_epi = [&](int cp) {  // what the tiles of chunk cp need from memory: requested a k loop ahead of their first use
+    auto pre_epi = [&](int cl) {  // what the tiles of chunk cl need from memory: requested a k loop ahead of their first use
+      const int cp = chunk_of(cl);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
         bvs[it] = (FWD && p.b1) ? *reinterpret_cast<const float4*>(p.b1 + cp * FFN_HC + wr * 32 + it * 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-      const int cn = min(c + 1, nch - 1);  // (past the last chunk: a harmless re-read)
+      const int cw = chunk_of(c), cn = chunk_of(min(c + 1, nch - 1));  // (past the last chunk: a harmless re-read)
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         uint4 xh[NT], xl[NT];
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #pragma unroll
           for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
 #ifndef FFN_ABL_NOB
-          if (ks + DA < KS1) { ring[slot] = ld_a(c, ks + DA, it, 0); ring[slot + 1] = ld_a(c, ks + DA, it, 1); }
+          if (ks + DA < KS1) { ring[slot] = ld_a(cw, ks + DA, it, 0); ring[slot + 1] = ld_a(cw, ks + DA, it, 1); }
           else { ring[slot] = ld_a(cn, ks + DA - KS1, it, 0); ring[slot + 1] = ld_a(cn, ks + DA - KS1, it, 1); }
 #endif
         }
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (EPI && MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + (c - 1)) * 4 + wr) * 64 + lane] = bits;
+      if constexpr (EPI && MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(c - 1)) * 4 + wr) * 64 + lane] = bits;
       pre_epi(c);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       kloop(c, std::false_type{});
 #pragma unroll
       for (int t = 0; t < 2 * NT; ++t) slice(c, t / NT, t % NT);
-      if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + c) * 4 + wr) * 64 + lane] = bits;
+      if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(c)) * 4 + wr) * 64 + lane] = bits;
       __syncthreads();
     }
     __syncthreads();
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     }
 #pragma unroll
     for (int t = 0; t < 2 * NT; ++t) slice(nch - 1, t / NT, t % NT);
-    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + (nch - 1)) * 4 + wr) * 64 + lane] = bits;
+    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(nch - 1)) * 4 + wr) * 64 + lane] = bits;
     __syncthreads();  // the last image is complete
     __syncthreads();  // (the B role's last barrier)
 #endif
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     for (int c = 0; c < nch; ++c) {
       // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32
       const unsigned char* img = hs + (c & 1) * (HST * STG) + fo;
-      const int tmax = nch * HST - 1;
+      const int cb = chunk_of(c);
 #ifndef FFN_ABL_NOPHASEB
       if (active) {
 #pragma unroll 1
@@ -373,7 +394,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
               gh[n] = *reinterpret_cast<const uint4*>(q);
               gl[n] = *reinterpret_cast<const uint4*>(q + 64);
             }
-            const int tn = min(c * HST + ks + FFN_DB, tmax);
+            // (k step ks + FFN_DB of this chunk, or the first ones of the next chunk in this workgroup's order)
+            int tn;
+            if constexpr (C != 256) tn = min(c * HST + ks + FFN_DB, nch * HST - 1);
+            else tn = ks + FFN_DB < HST ? cb * HST + ks + FFN_DB : chunk_of(min(c + 1, nch - 1)) * HST + (ks + FFN_DB - HST);
 #pragma unroll
             for (int it = 0; it < TPB; ++it) {
               const int slot = u * 2 * TPB + it * 2;
