@@ -31,7 +31,7 @@ extern "C" {
  * `stream` in the LayerNorm, window-attention, MSDA backward, pack4, splitk_flush and grouped-dW entries = revision 6;
  * round 6 = 7).  rscotr_version() returns the revision the shared object was BUILT with; a binding compares the two before
  * its first call (rscotr_amd/_lib.py does) — a stale .so would take a stream handle for a pointer. */
-#define RSCOTR_ABI_VERSION 7
+#define RSCOTR_ABI_VERSION 8
 int rscotr_version(void);
 const char* rscotr_last_error(void);
 int rscotr_device_count(void);
@@ -230,8 +230,10 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
  *     0  hid = relu(X' W1op^T + b1), the gate [hid > 0] written to `bits`        1  hid = (X' W1op^T) * bit read from `bits`
  *     2  Pre = X' W1op^T + b1 stored, hid = gelu(Pre) (erf form)                  3  hid = (X' W1op^T) * gelu'(Pre), Pre read
  *     Y = (hid W2op^T + b2) * yscale[row / rows_per] + resid,   X' = X * xscale[row / rows_per]   (scales / resid optional)
- * hid (M, H) is stored fp32 (the weight gradients read it).  X (M, C) row-major fp32, C in {96, 128, 192, 256}, H % 128 == 0
- * (rscotr_ffn_h3_ok).  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight operands, W1op (H rows, reduction C) and W2op (C rows,
+ * hid (M, H) is stored fp32 (the weight gradients read it).  X (M, C) row-major fp32, C in {96, 128, 192, 256, 384}, H % 128 == 0
+ * (rscotr_ffn_h3_ok).  Launches with few rows (< 200 row tiles of 32: Swin-T stage 3, the detection decoder's FFN) cut the hidden width
+ * into rscotr_ffn_h3_splits(M, C, H) runs, one workgroup per (row tile, run), whose partial Y meet in `workspace` (splits * M * C floats,
+ * 16-byte aligned; unused and may be null when splits == 1) and are combined in fixed order by a second launch.  W1f / W2f: FRAGMENT-MAJOR fp16 planes of the two weight operands, W1op (H rows, reduction C) and W2op (C rows,
  * reduction H), written by rscotr_gemm_split_weights_frag — table rows as rscotr_gemm_split_weights_h3 (column 5 unused); plane
  * rows % 16 == 0, reduction % 32 == 0; layout uint4 [row / 16][k / 32][h | l][lane]: the weight operand of a wavefront's
  * 16 x 16 x 32 MFMA is one contiguous 1 KB load; an entry takes rows * reduction / 8 / 256 blocks.  bits:
@@ -241,12 +243,14 @@ int rscotr_gemm_f32_rb(const float* A, const float* B, float* C, int M, int N, i
  * 16 x 16 x 32 MFMAs: equal to that entry's results at fp32 rounding, not bit for bit); the planes of hid for the second product
  * are scaled from the a-priori bound C max|X| max|W1| + max|b1|. */
 int rscotr_ffn_h3_ok(int M, int C, int H);
+int rscotr_ffn_h3_splits(int M, int C, int H);
 int64_t rscotr_ffn_h3_bits_words(int M, int C, int H);
 int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks, void* stream);
 int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
                   int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
                   const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
-                  const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, void* stream);
+                  const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, float* workspace,
+                  int64_t workspace_bytes, void* stream);
 /* > 0 if rscotr_gemm_f32 with these arguments (aligned operands) takes the split-product kernels, i.e. runs as the fp16 split
  * product once both value ranges are supplied: callers ask before they go looking for ranges.  2: the interior pipelined
  * 64 x 64 kernel, which can take a weight operand B from pre-split planes (rscotr_gemm_f32_rb). */

@@ -71,6 +71,8 @@ struct FfnParams {
   int rows_per;        // rows per sample for the two
   const unsigned *amax_x, *amax_w1, *amax_w2, *amax_b1;
   unsigned *amax_hid, *amax_y;
+  int splits;          // > 1: blockIdx.y = s takes the hidden chunks [s, s + 1) * (H / 128 / splits) and stores its PARTIAL y (no bias /
+  float* slabs;        //      scale / residual / range word) into slabs[s] (M x C); gemm_splitk_reduce_kernel adds them up and finishes
 };
 
 // C: model width (reduction of the first product, columns of the second); NT: 16-row tiles per workgroup
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const bool role_a = wv < 4;
   const int wr = wv & 3;
   const int m0 = blockIdx.x * BM;
-  const int nch = p.H / FFN_HC;
+  const int nch = p.H / FFN_HC;                   // chunks of the hidden width
+  const int nloc = nch / p.splits;                // ... of this workgroup: chunks cbase .. cbase + nloc - 1
+  const int cbase = (int)blockIdx.y * nloc;
 
   // value-range words: requested first, reduced after the operand loads have been requested too (cold lines)
   const long sub = (long)(lane & (kAmaxPlanes - 1)) * kAmaxStride;
@@ -138,9 +142,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, it * nks2 * 2048 + t * 2048 + pl * 1024, 0));
   };
 #ifdef FFN_NO_STAGGER
-  const int c0r = 0;
+  const int c0r = cbase;
 #else
-  const int c0r = C == 256 ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;  // (= c0 below: the first chunk of this workgroup)
+  const int c0r = cbase + (C >= 256 ? (int)((blockIdx.x >> 3) % (unsigned)nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
 #endif
   uint4 ring[RING];
   if (role_a) {
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     for (int q = 0; q < 4 * DA; ++q) ring[q] = ld_a(c0r, q >> 2, (q >> 1) & 1, q & 1);  // (DA <= KS1: the first chunk)
   } else if (wr < NB) {
 #pragma unroll
-    for (int q = 0; q < 2 * TPB * FFN_DB; ++q) ring[q] = ld_b(c0r * HST + min(q / (2 * TPB), HST - 1), (q >> 1) % TPB, q & 1);
+    for (int q = 0; q < 2 * TPB * FFN_DB; ++q) ring[q] = ld_b(c0r * HST + min(q / (2 * TPB), HST - 1), (q >> 1) % TPB, q & 1);  // (FFN_DB <= HST)
   }
 
   // the row tile's tensors through descriptors that end at row M: rows past the end read zeros and drop their stores — no
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.Hid + (long)m0 * p.H, 0, rows_ok * p.H * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((GELU || GGRAD) ? p.Pre + (long)m0 * p.H : p.Hid, 0, rows_ok * p.H * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
+  float* const ybase = p.splits > 1 ? p.slabs + (long)blockIdx.y * p.M * C : p.Y;
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(ybase + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * C : p.X), 0, rows_ok * C * 4, 0x00020000);
 
   // the rows' planes -> LDS (all eight wavefronts)
@@ -204,12 +209,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0 = 0;
 #else
-  const int c0 = C == 256 ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
+  const int c0 = C >= 256 ? (int)((blockIdx.x >> 3) % (unsigned)nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
 #endif
   auto chunk_of = [&](int c) {
-    if constexpr (C != 256) return c;
+    if constexpr (C < 256) return cbase + c;
     const int v = c + c0;
-    return v >= nch ? v - nch : v;
+    return cbase + (v >= nloc ? v - nloc : v);
   };
   __syncthreads();
 
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-      const int cw = chunk_of(c), cn = chunk_of(min(c + 1, nch - 1));  // (past the last chunk: a harmless re-read)
+      const int cw = chunk_of(c), cn = chunk_of(min(c + 1, nloc - 1));  // (past the last chunk: a harmless re-read)
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         uint4 xh[NT], xl[NT];
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     };
 #ifdef FFN_ABL_NOPIPE  // (timing ablation: every chunk's epilogue right behind its own k loop; the B role then reads an image too early)
 #pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nloc; ++c) {
       kloop(c, std::false_type{});
 #pragma unroll
       for (int t = 0; t < 2 * NT; ++t) slice(c, t / NT, t % NT);
@@ -355,13 +360,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     kloop(0, std::false_type{});
     __syncthreads();
 #pragma unroll 1
-    for (int c = 1; c < nch; ++c) {
+    for (int c = 1; c < nloc; ++c) {
       kloop(c, std::true_type{});
       __syncthreads();  // image (c - 1) % 2 is complete
     }
 #pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) slice(nch - 1, t / NT, t % NT);
-    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(nch - 1)) * 4 + wr) * 64 + lane] = bits;
+    for (int t = 0; t < 2 * NT; ++t) slice(nloc - 1, t / NT, t % NT);
+    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(nloc - 1)) * 4 + wr) * 64 + lane] = bits;
     __syncthreads();  // the last image is complete
     __syncthreads();  // (the B role's last barrier)
 #endif
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     __syncthreads();
     __syncthreads();  // (image c is complete one barrier later: its epilogue rides in the k loop of chunk c + 1)
 #pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nloc; ++c) {
       // ---- y += chunk c W2[:, chunk]^T: 4 k steps of 32
       const unsigned char* img = hs + (c & 1) * (HST * STG) + fo;
       const int cb = chunk_of(c);
@@ -396,8 +401,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
             }
             // (k step ks + FFN_DB of this chunk, or the first ones of the next chunk in this workgroup's order)
             int tn;
-            if constexpr (C != 256) tn = min(c * HST + ks + FFN_DB, nch * HST - 1);
-            else tn = ks + FFN_DB < HST ? cb * HST + ks + FFN_DB : chunk_of(min(c + 1, nch - 1)) * HST + (ks + FFN_DB - HST);
+            if constexpr (C < 256) tn = cbase * HST + min(c * HST + ks + FFN_DB, nloc * HST - 1);
+            else tn = ks + FFN_DB < HST ? cb * HST + ks + FFN_DB : chunk_of(min(c + 1, nloc - 1)) * HST + (ks + FFN_DB - HST);
 #pragma unroll
             for (int it = 0; it < TPB; ++it) {
               const int slot = u * 2 * TPB + it * 2;
@@ -523,8 +528,25 @@ static int ffn_rows(int M, int C) {
   return c32 < c48 ? 32 : 48;
 }
 
+// FEW ROWS (Swin-T stage 3: 2048 x 384 -> 1536 -> 384, the detection decoder's FFN: 1600 x 256 -> 2048 -> 256): 64 / 50 row tiles leave
+// three quarters of the CUs idle and each workgroup streams all of both weights (the C = 384 instantiation alone: 71 us against 45 for the
+// two tiled products).  The hidden width is then CUT into `splits` runs of chunks, one workgroup per (row tile, run): every run makes its
+// own partial y from its own slice of both weights, stored into a slab; gemm_splitk_reduce_kernel adds the slabs in fixed order and
+// applies bias / scale / residual / range word.  splits = the smallest divisor of the chunk count that brings the launch to 200
+// workgroups, runs of at least two chunks (the roles' pipeline); 1 for every launch that fills the chip by its rows.
+extern "C" int rscotr_ffn_h3_splits(int M, int C, int H) {
+  static const int forced = getenv("RSCOTR_FFN_SPLITS") ? atoi(getenv("RSCOTR_FFN_SPLITS")) : 0;  // (A/B runs: 1 = never)
+  if (H < FFN_HC || H % FFN_HC) return 1;
+  const int bm = ffn_rows(M, C), tiles = (M + bm - 1) / bm, nch = H / FFN_HC;
+  if (forced > 0) return nch % forced == 0 ? forced : 1;
+  if (tiles >= 200) return 1;
+  for (int d = 2; d <= nch / 2; ++d)
+    if (nch % d == 0 && tiles * d >= 200) return d;
+  return 1;
+}
+
 extern "C" int rscotr_ffn_h3_ok(int M, int C, int H) {
-  return ((C == 256 || C == 192 || C == 128 || C == 96) && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0;
+  return ((C == 384 || C == 256 || C == 192 || C == 128 || C == 96) && H >= FFN_HC && H % FFN_HC == 0 && M >= 1) ? 1 : 0;
 }
 
 extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int C, int H) {
@@ -540,7 +562,7 @@ static void ffn_launch1(const FfnParams& p, hipStream_t s) {
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT))), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT)), (unsigned)p.splits), dim3(512), lds, s, p);
 }
 
 template <int C, int NT>
@@ -556,8 +578,13 @@ static void ffn_launch(const FfnParams& p, int mode, hipStream_t s) {
 extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
                              int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
                              const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
-                             const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, void* stream) {
-  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 128, 192, 256}, H %% 128 == 0)", M, C, H);
+                             const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, float* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 128, 192, 256, 384}, H %% 128 == 0)", M, C, H);
+  const int splits = rscotr_ffn_h3_splits(M, C, H);
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * C * 4 || ((uintptr_t)workspace & 15)))
+    return fail(RSCOTR_E_ARG, "ffn_h3: M=%d C=%d H=%d runs as %d partial sums: workspace of %lld bytes (16-byte aligned), got %lld", M, C, H,
+                splits, (long long)splits * M * C * 4, (long long)workspace_bytes);
   if (mode < 0 || mode > 3) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d", mode);
   if (!X || !W1f || !W2f || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
   if (mode <= FFN_RELU_GATE ? !bits : !Pre) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d needs %s", mode, mode <= FFN_RELU_GATE ? "bits" : "Pre");
@@ -575,13 +602,27 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   p.xscale = xscale; p.yscale = yscale; p.rows_per = rows_per > 0 ? rows_per : 1;
   p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = fwd ? amax_b1 : nullptr;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
+  p.splits = splits; p.slabs = workspace;
+  if (splits > 1) { p.b2 = nullptr; p.resid = nullptr; p.yscale = nullptr; p.amax_y = nullptr; }  // (the combine's)
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int bm = ffn_rows(M, C);
-  ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %d, %d>", C, bm / 16, mode);
-  if (C == 256) { if (bm == 32) ffn_launch<256, 2>(p, mode, s); else ffn_launch<256, 3>(p, mode, s); }
-  else if (C == 192) ffn_launch<192, 2>(p, mode, s);
-  else if (C == 128) ffn_launch<128, 2>(p, mode, s);
-  else ffn_launch<96, 2>(p, mode, s);
-  return check_launch("ffn_h3");
+  {
+    ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %d, %d>", C, bm / 16, mode);
+    if (C == 384) ffn_launch<384, 2>(p, mode, s);
+    else if (C == 256) { if (bm == 32) ffn_launch<256, 2>(p, mode, s); else ffn_launch<256, 3>(p, mode, s); }
+    else if (C == 192) ffn_launch<192, 2>(p, mode, s);
+    else if (C == 128) ffn_launch<128, 2>(p, mode, s);
+    else ffn_launch<96, 2>(p, mode, s);
+  }
+  if (int rc = check_launch("ffn_h3")) return rc;
+  if (splits > 1) {  // y = (sum of the slabs + b2) * yscale + resid, its range word
+    GemmParams q{};
+    q.C = Y; q.M = M; q.N = C; q.ldc = C; q.vecC = 1;
+    q.bias = b2; q.resid = resid; q.rowscale = yscale; q.rows_per = p.rows_per;
+    q.slabs = workspace; q.splits = splits; q.amax_out = amax_y;
+    splitk_reduce_launch(q, workspace, s);
+    return check_launch("ffn_h3 combine");
+  }
+  return 0;
 }
 

@@ -757,7 +757,7 @@ class _FusedFFN:
     gradients only; backward dH = (g W2) * act', dX = dH W1 (+ g) with the mirrored call.  Taken where both weights are
     parameters of the optimizer's arena (their planes and range words live there) and the value ranges are on."""
 
-    MIN_ROWS = int(os.environ.get('RSCOTR_FFN_FUSED_MIN_ROWS', 2048))
+    MIN_ROWS = int(os.environ.get('RSCOTR_FFN_FUSED_MIN_ROWS', 1024))
     MODE = {(ACT_RELU, 0): 0, (ACT_RELU, 1): 1, (ACT_GELU, 0): 2, (ACT_GELU, 1): 3}
 
     def __init__(self):
@@ -802,9 +802,12 @@ class _FusedFFN:
             s_y = RANGES.new_slot(dev)
             RANGES.tag(y, s_y)
         relu = act == ACT_RELU
+        splits = int(lib.rscotr_ffn_h3_splits(M, C, H))  # (few rows: partial sums over runs of the hidden width, combined by a second launch)
+        ws = torch.empty(splits * M * C, dtype=torch.float32, device=dev) if splits > 1 else None
         lib.call('rscotr_ffn_h3', x2.data_ptr(), M, C, H, w1f, _ptr(b1), w2f, _ptr(b2), self.MODE[(act, int(gate))],
                  aux.data_ptr() if relu else 0, 0 if relu else aux.data_ptr(), hid.data_ptr(), _ptr(resid), y.data_ptr(),
-                 _ptr(xscale), _ptr(yscale), int(rows_per), s_x, s_w1, s_w2, s_b1, s_h, s_y, _stream())
+                 _ptr(xscale), _ptr(yscale), int(rows_per), s_x, s_w1, s_w2, s_b1, s_h, s_y, _ptr(ws),
+                 0 if ws is None else ws.numel() * 4, _stream())
         self.calls += 1
         return hid, y
 

@@ -53,8 +53,11 @@ def _run(ops, x, dy, ps, identity, fused):
         ops.FFN_FUSED.enabled = old
 
 
-@pytest.mark.parametrize('M,H,identity', [(10880, 2048, True), (4352, 2048, False), (2200, 1024, True), (2049, 256, True), (12300, 128, False)])
+@pytest.mark.parametrize('M,H,identity', [(10880, 2048, True), (4352, 2048, False), (2200, 1024, True), (2049, 256, True), (12300, 128, False),
+                                          (1600, 2048, True), (1100, 2048, False), (1031, 768, True)])
 def test_fused_ffn_matches_fp64_and_the_two_product_route(cuda, M, H, identity):
+    """(1600 / 1100 x 2048 and 2200 x 1024 are FEW-ROW launches: the hidden width cut into 4 / 8 / 4 runs whose partial outputs a second
+    launch adds up, rscotr_ffn_h3_splits; 1031 x 768 has too few chunks to cut.)"""
     from rscotr_amd import ops
     if not ops.RANGES.enabled:
         pytest.skip('value ranges are off')
@@ -75,14 +78,16 @@ def test_fused_ffn_matches_fp64_and_the_two_product_route(cuda, M, H, identity):
         opt.close()
 
 
-def test_fused_ffn_hidden_and_range_words(cuda):
+@pytest.mark.parametrize('M', [10880, 1600])
+def test_fused_ffn_hidden_and_range_words(cuda, M):
     """What the fused launch leaves for the weight gradients: the hidden tensor (and the gated dH of the mirrored call) at
     fp32-product accuracy against fp64, the SAME gate as the two-product route takes wherever the pre-activation is not within
     rounding of zero, and range words equal to the true maxima."""
     from rscotr_amd import ops
     if not ops.RANGES.enabled:
         pytest.skip('value ranges are off')
-    M, C, H = 10880, 256, 2048
+    C, H = 256, 2048
+    assert int(ops.lib.rscotr_ffn_h3_splits(M, C, H)) == (1 if M == 10880 else 4)
     x, dy, ps, opt = _setup(cuda, M, C, H, seed=3)
     try:
         ops.RANGES.begin(cuda)
@@ -135,11 +140,12 @@ def _gelu_grad64(t):
 
 
 @pytest.mark.parametrize('B,L,C,drop', [(2, 16384, 96, True), (2, 4096, 192, True), (2, 4096, 192, False), (1, 2500, 96, True), (3, 1000, 192, True),
-                                        (1, 4100, 128, True)])
+                                        (1, 4100, 128, True), (2, 1024, 384, True), (2, 1024, 384, False), (3, 500, 384, True), (2, 1024, 192, True)])
 def test_fused_swin_mlp_matches_fp64_and_the_two_product_route(cuda, B, L, C, drop):
     """The MLP of a Swin block (Linear - GELU - Linear, H = 4 C, DropPath folded in as a per-sample factor, the identity a separate
     tensor) on the fused route: output, input gradient and the four parameter gradients against fp64 and against the
-    two-product route, ragged row counts included."""
+    two-product route, ragged row counts included.  C = 384 (stage 3 of Swin-T: 2048 rows) and the 2048-row case at C = 192 run as
+    partial sums over runs of the hidden width."""
     from rscotr_amd import ops
     from rscotr_amd.optim import FlatAdamW
     if not ops.RANGES.enabled:
