@@ -71,8 +71,10 @@ struct FfnParams {
   int rows_per;        // rows per sample for the two
   const unsigned *amax_x, *amax_w1, *amax_w2, *amax_b1;
   unsigned *amax_hid, *amax_y;
-  int splits;          // > 1: blockIdx.y = s takes the hidden chunks [s, s + 1) * (H / 128 / splits) and stores its PARTIAL y (no bias /
+  int splits;          // > 1: run s takes the hidden chunks [s, s + 1) * (H / 128 / splits) and stores its PARTIAL y (no bias /
   float* slabs;        //      scale / residual / range word) into slabs[s] (M x C); gemm_splitk_reduce_kernel adds them up and finishes
+  int by_xcd;          // splits > 1 and splits | 8: 1-D grid of 8 * tpx workgroups, workgroup b (XCD b % 8) = run (b % 8) % splits,
+  int tpx;             //      row tile (b % 8) / splits + (8 / splits) * (b / 8): an XCD's L2 then holds ONE run's slice of the weights
 };
 
 // C: model width (reduction of the first product, columns of the second); NT: 16-row tiles per workgroup
@@ -120,10 +122,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (provably uniform: the role branches below must be scalar branches)
   const bool role_a = wv < 4;
   const int wr = wv & 3;
-  const int m0 = blockIdx.x * BM;
+  // row tile bx, run by of the hidden width, rank jx of this workgroup among the ones that share its weights through one L2
+  int bx = blockIdx.x, by = blockIdx.y, jx = blockIdx.x >> 3;
+  if (p.by_xcd) {
+    const int xcd = (int)(blockIdx.x & 7);
+    jx = (int)(blockIdx.x >> 3);
+    by = xcd % p.splits;
+    bx = xcd / p.splits + (8 / p.splits) * jx;
+    if (bx * BM >= p.M) return;  // (the grid is rounded up to whole XCD rounds; before any barrier)
+  }
+  const int m0 = bx * BM;
   const int nch = p.H / FFN_HC;                   // chunks of the hidden width
   const int nloc = nch / p.splits;                // ... of this workgroup: chunks cbase .. cbase + nloc - 1
-  const int cbase = (int)blockIdx.y * nloc;
+  const int cbase = by * nloc;
 
   // value-range words: requested first, reduced after the operand loads have been requested too (cold lines)
   const long sub = (long)(lane & (kAmaxPlanes - 1)) * kAmaxStride;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0r = cbase;
 #else
-  const int c0r = cbase + (C >= 256 ? (int)((blockIdx.x >> 3) % (unsigned)nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
+  const int c0r = cbase + (C >= 256 ? (int)((unsigned)jx % (unsigned)nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
 #endif
   uint4 ring[RING];
   if (role_a) {
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.Hid + (long)m0 * p.H, 0, rows_ok * p.H * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((GELU || GGRAD) ? p.Pre + (long)m0 * p.H : p.Hid, 0, rows_ok * p.H * 4, 0x00020000);
-  float* const ybase = p.splits > 1 ? p.slabs + (long)blockIdx.y * p.M * C : p.Y;
+  float* const ybase = p.splits > 1 ? p.slabs + (long)by * p.M * C : p.Y;
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(ybase + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * C : p.X), 0, rows_ok * C * 4, 0x00020000);
 
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0 = 0;
 #else
-  const int c0 = C >= 256 ? (int)((blockIdx.x >> 3) % (unsigned)nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
+  const int c0 = C >= 256 ? (int)((unsigned)jx % (unsigned)nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
 #endif
   auto chunk_of = [&](int c) {
     if constexpr (C < 256) return cbase + c;
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #pragma unroll
       for (int it = 0; it < 2; ++it)
         bvs[it] = (FWD && p.b1) ? *reinterpret_cast<const float4*>(p.b1 + cp * FFN_HC + wr * 32 + it * 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (GATE) bits = p.bits[(((long)blockIdx.x * nch + cp) * 4 + wr) * 64 + lane];
+      if constexpr (GATE) bits = p.bits[(((long)bx * nch + cp) * 4 + wr) * 64 + lane];
       else bits = 0u;
       if constexpr (GGRAD) {
 #pragma unroll
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (EPI && MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(c - 1)) * 4 + wr) * 64 + lane] = bits;
+      if constexpr (EPI && MODE == FFN_RELU) p.bits[(((long)bx * nch + chunk_of(c - 1)) * 4 + wr) * 64 + lane] = bits;
       pre_epi(c);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
       kloop(c, std::false_type{});
 #pragma unroll
       for (int t = 0; t < 2 * NT; ++t) slice(c, t / NT, t % NT);
-      if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(c)) * 4 + wr) * 64 + lane] = bits;
+      if constexpr (MODE == FFN_RELU) p.bits[(((long)bx * nch + chunk_of(c)) * 4 + wr) * 64 + lane] = bits;
       __syncthreads();
     }
     __syncthreads();
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
     }
 #pragma unroll
     for (int t = 0; t < 2 * NT; ++t) slice(nloc - 1, t / NT, t % NT);
-    if constexpr (MODE == FFN_RELU) p.bits[(((long)blockIdx.x * nch + chunk_of(nloc - 1)) * 4 + wr) * 64 + lane] = bits;
+    if constexpr (MODE == FFN_RELU) p.bits[(((long)bx * nch + chunk_of(nloc - 1)) * 4 + wr) * 64 + lane] = bits;
     __syncthreads();  // the last image is complete
     __syncthreads();  // (the B role's last barrier)
 #endif
@@ -562,7 +573,9 @@ static void ffn_launch1(const FfnParams& p, hipStream_t s) {
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT)), (unsigned)p.splits), dim3(512), lds, s, p);
+  const unsigned tiles = (unsigned)((p.M + 16 * NT - 1) / (16 * NT));
+  const dim3 grid = p.by_xcd ? dim3(8u * (unsigned)p.tpx) : dim3(tiles, (unsigned)p.splits);
+  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), grid, dim3(512), lds, s, p);
 }
 
 template <int C, int NT>
@@ -603,6 +616,11 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = fwd ? amax_b1 : nullptr;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
   p.splits = splits; p.slabs = workspace;
+  static const int xcd_ok = getenv("RSCOTR_FFN_SPLIT_XCD") ? atoi(getenv("RSCOTR_FFN_SPLIT_XCD")) : 1;  // (A/B runs)
+  if (splits > 1 && 8 % splits == 0 && xcd_ok) {
+    const int bm0 = ffn_rows(M, C), tiles = (M + bm0 - 1) / bm0, per = 8 / splits;  // XCDs per run
+    p.by_xcd = 1; p.tpx = (tiles + per - 1) / per;
+  }
   if (splits > 1) { p.b2 = nullptr; p.resid = nullptr; p.yscale = nullptr; p.amax_y = nullptr; }  // (the combine's)
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int bm = ffn_rows(M, C);

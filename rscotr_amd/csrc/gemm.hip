@@ -1434,7 +1434,8 @@ static Split6Cfg choose_split6(const GemmParams& p, int a_kmajor, int b_kmajor, 
   else if (mid_split && t64 >= mid_t64 && p.K >= mid_k) {
     // mid-size outputs with a long reduction (Swin stage 3: 2048 x 384 x 1536): too few 64 x 64 tiles for the chip, so the
     // reduction is cut into k-slices whose slabs the combine launch sums and runs the epilogue on
-    long sp = std::min<long>((512 + t64 - 1) / t64, p.K / 256);
+    static const int mid_kslice = getenv("RSCOTR_BF16X6_MID_KSLICE") ? atoi(getenv("RSCOTR_BF16X6_MID_KSLICE")) : 256;  // shortest k-slice
+    long sp = std::min<long>((512 + t64 - 1) / t64, p.K / mid_kslice);
     const int64_t per = ((int64_t)p.M * p.N + p.M) * 4;
     sp = std::min<long>(sp, ws_bytes / per);
     if (sp >= 2) {
