@@ -246,6 +246,20 @@ int rscotr_ffn_h3_ok(int M, int C, int H);
 int rscotr_ffn_h3_splits(int M, int C, int H);
 int64_t rscotr_ffn_h3_bits_words(int M, int C, int H);
 int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks, void* stream);
+/* rscotr_ffn_h3 mode 2 with the LayerNorm of a pre-norm block in front (mmdet SwinBlock.forward: x = x + ffn(norm2(x)), reached from
+ * models/multi/multitask_learner.py:83 through the backbone of configs/multi/...potsdam.py:9-25): X is the block input; its rows are
+ * normalised (two-pass mean / variance, eps inside the root, affine ln_weight / ln_bias) while they are staged, and LayerNorm(X)
+ * leaves the launch as ln_out (M, C) with ln_mean / ln_rstd (M) — what rscotr_layernorm_fwd would have written, equal at fp32
+ * rounding (the sums run over another lane layout) — for the weight gradient of the first Linear and rscotr_layernorm_bwd.
+ * C in {96, 192, 384}.  amax_ln_weight (required) / amax_ln_bias: range words of the affine parameters — the planes of the
+ * normalised rows are scaled from sqrt(C) max|weight| + max|bias|; amax_ln_out (optional): range word of ln_out, committed.
+ * Everything else as rscotr_ffn_h3 (no bits, no xscale). */
+int rscotr_ffn_h3_ln(const float* X, int M, int C, int H, const float* ln_weight, const float* ln_bias, float ln_eps, float* ln_out,
+                     float* ln_mean, float* ln_rstd, const void* W1f, const float* b1, const void* W2f, const float* b2, float* Pre,
+                     float* Hid, const float* resid, float* Y, const float* yscale, int rows_per, const uint32_t* amax_ln_weight,
+                     const uint32_t* amax_ln_bias, const uint32_t* amax_w1, const uint32_t* amax_w2, const uint32_t* amax_b1,
+                     uint32_t* amax_ln_out, uint32_t* amax_hid, uint32_t* amax_y, float* workspace, int64_t workspace_bytes,
+                     void* stream);
 int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
                   int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
                   const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,

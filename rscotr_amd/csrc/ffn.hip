@@ -73,6 +73,14 @@ struct FfnParams {
   unsigned *amax_hid, *amax_y;
   int splits;          // > 1: run s takes the hidden chunks [s, s + 1) * (H / 128 / splits) and stores its PARTIAL y (no bias /
   float* slabs;        //      scale / residual / range word) into slabs[s] (M x C); gemm_splitk_reduce_kernel adds them up and finishes
+  // LN instantiations (a pre-norm block, x + MLP(LayerNorm(x)): mmdet SwinBlock's norm2 + FFN): X is the block input, the rows are
+  // normalised while they are staged; LayerNorm(X) leaves the kernel too (the weight gradient of the first Linear and the norm's own
+  // backward read it, with the row statistics)
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  float *ln_out, *ln_mean, *ln_rstd;
+  const unsigned *amax_g, *amax_bt;
+  unsigned* amax_ln;
   int by_xcd;          // splits > 1 and splits | 8: 1-D grid of 8 * tpx workgroups, workgroup b (XCD b % 8) = run (b % 8) % splits,
   int tpx;             //      row tile (b % 8) / splits + (8 / splits) * (b / 8): an XCD's L2 then holds ONE run's slice of the weights
 };
@@ -99,7 +107,7 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 
 // Bit layout of FFN_RELU / FFN_RELU_GATE (opaque to callers, the same in both directions): uint32 [row tile][chunk][A wavefront][lane],
 // bit (it * NT + n) * 4 + r = accumulator register r of the lane's 16 x 16 tile (column tile it, row tile n).
-template <int C, int NT, int MODE>
+template <int C, int NT, int MODE, bool LN = false>
 #ifndef FFN_SWIN_WAVES
 #define FFN_SWIN_WAVES 4  // wavefronts per SIMD the C = 96 kernels are held to (4 = 128 registers: two 8-wavefront workgroups per CU; stage 1 of
                           // Swin-T at 512^2 is 1024 workgroups; C = 192 is 256 workgroups = one per CU, C = 256 needs its 123 KB of LDS alone)
@@ -138,7 +146,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 
   // value-range words: requested first, reduced after the operand loads have been requested too (cold lines)
   const long sub = (long)(lane & (kAmaxPlanes - 1)) * kAmaxStride;
-  const unsigned rx = p.amax_x[sub], r1 = p.amax_w1[sub], r2 = p.amax_w2[sub], rb = p.amax_b1 ? p.amax_b1[sub] : 0u;
+  const unsigned rx = LN ? 0u : p.amax_x[sub], r1 = p.amax_w1[sub], r2 = p.amax_w2[sub], rb = p.amax_b1 ? p.amax_b1[sub] : 0u;
+  const unsigned rg = LN ? p.amax_g[sub] : 0u, rbt = (LN && p.amax_bt) ? p.amax_bt[sub] : 0u;
 
   // weight fragments: buffer loads — ONE address register per wavefront (its lane and its tiles), the chunk / k step as a scalar
   // offset.  A: tile = c * 8 + wr * 2 + it of W1op (H rows, KS1 k steps);  B: tile = wr * TPB + it of W2op (C rows, H / 32 k steps)
@@ -176,13 +185,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(ybase + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * C : p.X), 0, rows_ok * C * 4, 0x00020000);
 
-  // the rows' planes -> LDS (all eight wavefronts)
-  {
+  // the rows' planes -> LDS (all eight wavefronts).  LN: |LayerNorm(x)| <= sqrt(C) max|gamma| + max|beta| — a normalised row has
+  // no entry above sqrt(C - 1) — is the range the planes are scaled with (the row maxima are only known afterwards; a loose bound
+  // costs nothing above 2^-26 of it, see the header)
+  const unsigned ux = LN ? __float_as_uint(sqrtf((float)C) * __uint_as_float(amax_fold(rg)) + __uint_as_float(amax_fold(rbt))) : amax_fold(rx);
+  if constexpr (!LN) {
     constexpr int TOT = BM * (C / 4), NV = (TOT + 511) / 512;
     float4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (tid + i * 512) * 16, 0, 0));
-    const int ex0 = h3_scale_exp(amax_fold(rx));
+    const int ex0 = h3_scale_exp(ux);
     const H3Scale hx{__uint_as_float((unsigned)ex0 << 23), __uint_as_float((unsigned)(ex0 + 11) << 23)};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -201,8 +213,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
         *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
       }
     }
+  } else {
+    // G = C / 12 lanes per row, three float4 each (columns 4 (sub + j G)): 512 / G rows per pass; mean, then the centred sum of
+    // squares, both in registers (the arithmetic of layernorm_fwd_kernel on another lane layout: equal at rounding, not bit for bit)
+    static_assert(C % 48 == 0 && (C / 12 == 8 || C / 12 == 16 || C / 12 == 32), "LN rows: 8 / 16 / 32 lanes x 3 float4");
+    constexpr int G = C / 12, RPP = 512 / G, NP = (BM + RPP - 1) / RPP;
+    const int sub = tid % G, rr = tid / G;
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (long)m0 * C, 0, (by == 0 ? rows_ok : 0) * C * 4, 0x00020000);
+    const int ex0 = h3_scale_exp(ux);
+    const H3Scale hx{__uint_as_float((unsigned)ex0 << 23), __uint_as_float((unsigned)(ex0 + 11) << 23)};
+    float amx = 0.f;
+    if (RPP <= BM || wv < 8 * BM / RPP) {  // (C = 96: 64 rows per pass, 32 to stage — wavefronts 4-7 have none)
+      float4 gw[3], gb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        gw[j] = reinterpret_cast<const float4*>(p.ln_g)[sub + j * G];
+        gb[j] = p.ln_b ? reinterpret_cast<const float4*>(p.ln_b)[sub + j * G] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int row = ps * RPP + rr;
+        float4 v[3];
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (row * C + 4 * (sub + j * G)) * 4, 0, 0));
+          sm += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const float mu = sm * (1.f / (float)C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+          q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q * (1.f / (float)C) + p.ln_eps);
+        if (sub == 0 && by == 0 && row < rows_ok) { p.ln_mean[m0 + row] = mu; p.ln_rstd[m0 + row] = rs; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float4 o;
+          o.x = v[j].x * rs * gw[j].x + gb[j].x; o.y = v[j].y * rs * gw[j].y + gb[j].y;
+          o.z = v[j].z * rs * gw[j].z + gb[j].z; o.w = v[j].w * rs * gw[j].w + gb[j].w;
+          if (row >= rows_ok) o = make_float4(0.f, 0.f, 0.f, 0.f);  // (rows past M: beta would leak into the planes — harmless, their outputs are dropped, but not into the range word)
+          const int kq = 4 * (sub + j * G);
+          store_b128(o, rL, (row * C + kq) * 4, 0);
+          amx = amax4(amx, o);
+          unsigned ab[3], cd[3];
+          split_pair_h(o.x, o.y, hx, ab);
+          split_pair_h(o.z, o.w, hx, cd);
+          unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+        }
+      }
+    }
+    if (by == 0) amax_commit(p.amax_ln, amx);
   }
-  const unsigned ux = amax_fold(rx), u1 = amax_fold(r1), u2 = amax_fold(r2), ub = amax_fold(rb);
+  const unsigned u1 = amax_fold(r1), u2 = amax_fold(r2), ub = amax_fold(rb);
   const int ex = h3_scale_exp(ux), e1 = h3_scale_exp(u1), e2 = h3_scale_exp(u2);
   // |hidden| <= C max|x| max|W1| + max|b1|: relu / a gate only shrink it, |gelu(t)| <= |t|, |gelu'| < 1.13 (hence the 1.25); a
   // DropPath factor on the rows of x (<= 2 for keep >= 0.5) rides in the scale's 8 x headroom
@@ -565,17 +636,17 @@ extern "C" int64_t rscotr_ffn_h3_bits_words(int M, int C, int H) {
   return (int64_t)((M + bm - 1) / bm) * (H / FFN_HC) * 256;
 }
 
-template <int C, int NT, int MODE>
+template <int C, int NT, int MODE, bool LN = false>
 static void ffn_launch1(const FfnParams& p, hipStream_t s) {
   constexpr size_t lds = ffn_lds_bytes<C, NT>();
   static bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<C, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_h3_kernel<C, NT, MODE, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return true;
   }();
   (void)attr_set;
   const unsigned tiles = (unsigned)((p.M + 16 * NT - 1) / (16 * NT));
   const dim3 grid = p.by_xcd ? dim3(8u * (unsigned)p.tpx) : dim3(tiles, (unsigned)p.splits);
-  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((ffn_h3_kernel<C, NT, MODE, LN>), grid, dim3(512), lds, s, p);
 }
 
 template <int C, int NT>
@@ -588,18 +659,32 @@ static void ffn_launch(const FfnParams& p, int mode, hipStream_t s) {
   }
 }
 
-extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
-                             int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
-                             const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
-                             const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, float* workspace,
-                             int64_t workspace_bytes, void* stream) {
+struct FfnNorm {  // the LayerNorm in front of the block (rscotr_ffn_h3_ln) | all null
+  const float *g, *b;
+  float eps;
+  float *out, *mean, *rstd;
+  const uint32_t *amax_g, *amax_b;
+  uint32_t* amax_out;
+};
+
+static int ffn_h3_run(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
+                      int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
+                      const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
+                      const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, float* workspace,
+                      int64_t workspace_bytes, const FfnNorm& ln, void* stream) {
   if (!rscotr_ffn_h3_ok(M, C, H)) return fail(RSCOTR_E_SHAPE, "ffn_h3: M=%d C=%d H=%d (C in {96, 128, 192, 256, 384}, H %% 128 == 0)", M, C, H);
   const int splits = rscotr_ffn_h3_splits(M, C, H);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * C * 4 || ((uintptr_t)workspace & 15)))
     return fail(RSCOTR_E_ARG, "ffn_h3: M=%d C=%d H=%d runs as %d partial sums: workspace of %lld bytes (16-byte aligned), got %lld", M, C, H,
                 splits, (long long)splits * M * C * 4, (long long)workspace_bytes);
   if (mode < 0 || mode > 3) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d", mode);
-  if (!X || !W1f || !W2f || !Hid || !Y || !amax_x || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
+  if (!X || !W1f || !W2f || !Hid || !Y || (!amax_x && !ln.g) || !amax_w1 || !amax_w2) return fail(RSCOTR_E_ARG, "ffn_h3: null argument");
+  if (ln.g) {
+    if (mode != FFN_GELU || !(C == 96 || C == 192 || C == 384))
+      return fail(RSCOTR_E_SHAPE, "ffn_h3_ln: the norm prologue exists for mode 2 (GELU forward) at C in {96, 192, 384} (mode %d, C=%d)", mode, C);
+    if (!ln.out || !ln.mean || !ln.rstd || !ln.amax_g || xscale) return fail(RSCOTR_E_ARG, "ffn_h3_ln: null argument (or a row scale on X)");
+    if (((uintptr_t)ln.g | (uintptr_t)ln.b | (uintptr_t)ln.out) & 15) return fail(RSCOTR_E_ALIGN, "ffn_h3_ln: operands must be 16-byte aligned");
+  }
   if (mode <= FFN_RELU_GATE ? !bits : !Pre) return fail(RSCOTR_E_ARG, "ffn_h3: mode %d needs %s", mode, mode <= FFN_RELU_GATE ? "bits" : "Pre");
   if ((xscale || yscale) && rows_per <= 0) return fail(RSCOTR_E_ARG, "ffn_h3: rows_per with a row scale");
   if (((uintptr_t)X | (uintptr_t)W1f | (uintptr_t)W2f | (uintptr_t)Hid | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)b1 | (uintptr_t)b2 |
@@ -616,6 +701,8 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   p.amax_x = amax_x; p.amax_w1 = amax_w1; p.amax_w2 = amax_w2; p.amax_b1 = fwd ? amax_b1 : nullptr;
   p.amax_hid = amax_hid; p.amax_y = amax_y;
   p.splits = splits; p.slabs = workspace;
+  p.ln_g = ln.g; p.ln_b = ln.b; p.ln_eps = ln.eps; p.ln_out = ln.out; p.ln_mean = ln.mean; p.ln_rstd = ln.rstd;
+  p.amax_g = ln.amax_g; p.amax_bt = ln.amax_b; p.amax_ln = ln.amax_out;
   static const int xcd_ok = getenv("RSCOTR_FFN_SPLIT_XCD") ? atoi(getenv("RSCOTR_FFN_SPLIT_XCD")) : 1;  // (A/B runs)
   if (splits > 1 && 8 % splits == 0 && xcd_ok) {
     const int bm0 = ffn_rows(M, C), tiles = (M + bm0 - 1) / bm0, per = 8 / splits;  // XCDs per run
@@ -626,7 +713,11 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   const int bm = ffn_rows(M, C);
   {
     ProfScope prof(PROF_GEMM, 4.0 * M * (double)C * H, s, "rscotr::ffn_h3_kernel<%d, %d, %d>", C, bm / 16, mode);
-    if (C == 384) ffn_launch<384, 2>(p, mode, s);
+    if (ln.g) {
+      if (C == 384) ffn_launch1<384, 2, FFN_GELU, true>(p, s);
+      else if (C == 192) ffn_launch1<192, 2, FFN_GELU, true>(p, s);
+      else ffn_launch1<96, 2, FFN_GELU, true>(p, s);
+    } else if (C == 384) ffn_launch<384, 2>(p, mode, s);
     else if (C == 256) { if (bm == 32) ffn_launch<256, 2>(p, mode, s); else ffn_launch<256, 3>(p, mode, s); }
     else if (C == 192) ffn_launch<192, 2>(p, mode, s);
     else if (C == 128) ffn_launch<128, 2>(p, mode, s);
@@ -644,3 +735,24 @@ extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1
   return 0;
 }
 
+
+extern "C" int rscotr_ffn_h3(const float* X, int M, int C, int H, const void* W1f, const float* b1, const void* W2f, const float* b2,
+                             int mode, void* bits, float* Pre, float* Hid, const float* resid, float* Y, const float* xscale,
+                             const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w1,
+                             const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_hid, uint32_t* amax_y, float* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  return ffn_h3_run(X, M, C, H, W1f, b1, W2f, b2, mode, bits, Pre, Hid, resid, Y, xscale, yscale, rows_per, amax_x, amax_w1, amax_w2, amax_b1,
+                    amax_hid, amax_y, workspace, workspace_bytes, FfnNorm{}, stream);
+}
+
+extern "C" int rscotr_ffn_h3_ln(const float* X, int M, int C, int H, const float* ln_weight, const float* ln_bias, float ln_eps,
+                                float* ln_out, float* ln_mean, float* ln_rstd, const void* W1f, const float* b1, const void* W2f,
+                                const float* b2, float* Pre, float* Hid, const float* resid, float* Y, const float* yscale, int rows_per,
+                                const uint32_t* amax_ln_weight, const uint32_t* amax_ln_bias, const uint32_t* amax_w1,
+                                const uint32_t* amax_w2, const uint32_t* amax_b1, uint32_t* amax_ln_out, uint32_t* amax_hid,
+                                uint32_t* amax_y, float* workspace, int64_t workspace_bytes, void* stream) {
+  if (!ln_weight) return fail(RSCOTR_E_ARG, "ffn_h3_ln: null LayerNorm weight");
+  const FfnNorm ln{ln_weight, ln_bias, ln_eps, ln_out, ln_mean, ln_rstd, amax_ln_weight, amax_ln_bias, amax_ln_out};
+  return ffn_h3_run(X, M, C, H, W1f, b1, W2f, b2, FFN_GELU, nullptr, Pre, Hid, resid, Y, nullptr, yscale, rows_per, nullptr, amax_w1, amax_w2,
+                    amax_b1, amax_hid, amax_y, workspace, workspace_bytes, ln, stream);
+}

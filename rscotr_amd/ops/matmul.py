@@ -763,7 +763,9 @@ class _FusedFFN:
     def __init__(self):
         self.enabled = os.environ.get('RSCOTR_FFN_FUSED', '1') != '0'
         self.gelu = os.environ.get('RSCOTR_FFN_FUSED_GELU', '1') != '0'  # (the Swin route on its own switch: A/B runs)
+        self.ln = os.environ.get('RSCOTR_FFN_FUSED_LN', '1') != '0'      # (the norm in front of a Swin MLP as the launch's prologue)
         self.calls = 0
+        self.ln_calls = 0
 
     def ok(self, x2, ws, act, out_scale, sum_with):
         if not self.enabled or not RANGES.enabled or len(ws) != 2 or act not in (ACT_RELU, ACT_GELU) or sum_with is not None:
@@ -779,15 +781,22 @@ class _FusedFFN:
             return False
         return bool(lib.rscotr_ffn_h3_ok(M, C, H))
 
-    def run(self, x2, W1, b1, W2, b2, act, aux, gate, resid, want_y_range, xscale=None, yscale=None, rows_per=0):
+    def ln_ok(self, lz, C, act):
+        """Can the forward launch take the LayerNorm in front of the block (a pending ops.norm.LazyNorm) as its prologue?"""
+        sink = STATE.grad_sink
+        return (self.ln and act == ACT_GELU and C in (96, 192, 384) and lz.w is not None and sink is not None
+                and sink.is_param_ptr(lz.w.data_ptr()) and (lz.b is None or sink.is_param_ptr(lz.b.data_ptr())))
+
+    def run(self, x2, W1, b1, W2, b2, act, aux, gate, resid, want_y_range, xscale=None, yscale=None, rows_per=0, ln=None):
         """gate = 0: (W1, W2) are the two Linear weights as stored, (out, in); gate = 1: the mirrored products, W1 := W2 and
         W2 := W1 of the forward, both taken transposed.  aux: the gate bits (ReLU) or the pre-activation (GELU), written by the
-        forward call and read by the mirrored one.  -> (hid, y)."""
+        forward call and read by the mirrored one.  ln: a pending LazyNorm whose output x2 is — the launch normalises ln.x2's rows
+        itself and fills x2 and the norm's statistics (rscotr_ffn_h3_ln).  -> (hid, y)."""
         M, C = x2.shape
         H = W1.shape[1] if gate else W1.shape[0]
         dev = x2.device
         sink = STATE.grad_sink
-        s_x = RANGES.of(x2, M, C, C)
+        s_x = 0 if ln is not None else RANGES.of(x2, M, C, C)
         s_w1, s_w2 = RANGES.of(W1, W1.shape[0], W1.shape[1], W1.shape[1]), RANGES.of(W2, W2.shape[0], W2.shape[1], W2.shape[1])
         s_b1 = sink.amax_slot(b1.data_ptr()) if (b1 is not None and sink.is_param_ptr(b1.data_ptr())) else 0
         if b1 is not None and not s_b1:
@@ -804,6 +813,17 @@ class _FusedFFN:
         relu = act == ACT_RELU
         splits = int(lib.rscotr_ffn_h3_splits(M, C, H))  # (few rows: partial sums over runs of the hidden width, combined by a second launch)
         ws = torch.empty(splits * M * C, dtype=torch.float32, device=dev) if splits > 1 else None
+        if ln is not None:
+            assert not gate and not relu and xscale is None and ln.y.data_ptr() == x2.data_ptr()
+            lib.call('rscotr_ffn_h3_ln', ln.x2.data_ptr(), M, C, H, _ptr(ln.w), _ptr(ln.b), float(ln.eps), x2.data_ptr(),
+                     ln.stats[0].data_ptr(), ln.stats[1].data_ptr(), w1f, _ptr(b1), w2f, _ptr(b2), aux.data_ptr(), hid.data_ptr(),
+                     _ptr(resid), y.data_ptr(), _ptr(yscale), int(rows_per), sink.amax_slot(ln.w.data_ptr()),
+                     0 if ln.b is None else sink.amax_slot(ln.b.data_ptr()), s_w1, s_w2, s_b1, ln.slot, s_h, s_y, _ptr(ws),
+                     0 if ws is None else ws.numel() * 4, _stream())
+            ln.done = True
+            self.calls += 1
+            self.ln_calls += 1
+            return hid, y
         lib.call('rscotr_ffn_h3', x2.data_ptr(), M, C, H, w1f, _ptr(b1), w2f, _ptr(b2), self.MODE[(act, int(gate))],
                  aux.data_ptr() if relu else 0, 0 if relu else aux.data_ptr(), hid.data_ptr(), _ptr(resid), y.data_ptr(),
                  _ptr(xscale), _ptr(yscale), int(rows_per), s_x, s_w1, s_w2, s_b1, s_h, s_y, _ptr(ws),
@@ -852,6 +872,11 @@ class _MLP(Function):
         want_last = RANGE_OUT.want(not RANGE_OUT.skip_next and id2 is None)
         RANGE_OUT.skip_next = False
         ctx.fused = FFN_FUSED.ok(x2, ws, act, out_scale, sum_with)
+        lz = getattr(x, '_lazy_ln', None)  # (the norm in front has not run yet: ops.layer_norm_fork(lazy=True))
+        if lz is not None and not lz.done and not (ctx.fused and FFN_FUSED.ln_ok(lz, K0, act)):
+            lz.run()
+        if lz is not None and lz.done:
+            lz = None
         if ctx.fused:
             W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
             W2 = ws[1] if ws[1].is_contiguous() else ws[1].contiguous()
@@ -859,7 +884,7 @@ class _MLP(Function):
                 aux = torch.empty(int(lib.rscotr_ffn_h3_bits_words(M, K0, W1.shape[0])), dtype=torch.int32, device=x2.device)
             else:  # GELU: the pre-activation
                 aux = torch.empty((M, W1.shape[0]), dtype=torch.float32, device=x2.device)
-            hid, h = FFN_FUSED.run(x2, W1, bs[0], W2, bs[1], act, aux, 0, id2, want_last, yscale=out_scale, rows_per=rows_per)
+            hid, h = FFN_FUSED.run(x2, W1, bs[0], W2, bs[1], act, aux, 0, id2, want_last, yscale=out_scale, rows_per=rows_per, ln=lz)
             hs.append(hid)
             auxs.append(aux)
             n = 0  # (the loop below has nothing left to do)

@@ -10,23 +10,53 @@ from .state import STATE
 LN_EPS = 1e-5
 
 
+class LazyNorm:
+    """A LayerNorm whose forward launch has been left to its ONLY consumer (layer_norm_fork(lazy=True) -> ops.mlp): the fused
+    two-Linear kernel normalises the rows while it stages them (rscotr_ffn_h3_ln) and fills `y` / `stats` on the way; a consumer
+    that cannot take that route calls run() first.  The autograd node of the norm is the ordinary one: it saved x, the weight and
+    the `stats` tensor, which is full by the time backward runs."""
+
+    def __init__(self, x2, w, b, eps, y, stats, slot):
+        self.x2, self.w, self.b, self.eps, self.y, self.stats, self.slot = x2, w, b, eps, y, stats, slot
+        self.done = False
+
+    def run(self):
+        if not self.done:
+            M, C = self.x2.shape
+            with _Prof('layernorm_fwd', 8 * M * C):
+                lib.call('rscotr_layernorm_fwd', self.x2.data_ptr(), _ptr(self.w), _ptr(self.b), self.y.data_ptr(),
+                         self.stats[0].data_ptr(), self.stats[1].data_ptr(), M, C, float(self.eps), self.slot, _stream())
+            self.done = True
+
+
+def materialize(t):
+    """Run the launch a lazy norm output `t` is still waiting for (no-op for every other tensor)."""
+    lz = getattr(t, '_lazy_ln', None)
+    if lz is not None:
+        lz.run()
+    return t
+
+
 class _LayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, lazy=False):
         C = x.shape[-1]
         x2 = _f32c(x).reshape(-1, C)
         M = x2.shape[0]
         _chk(x2, w, b)
         y = torch.empty_like(x2)
         stats = torch.empty((2, M), dtype=torch.float32, device=x2.device)
-        with _Prof('layernorm_fwd', 8 * M * C):
-            slot = RANGES.out_slot(x2.device)
-            lib.call('rscotr_layernorm_fwd', x2.data_ptr(), _ptr(w), _ptr(b), y.data_ptr(), stats[0].data_ptr(),
-                     stats[1].data_ptr(), M, C, float(eps), slot, _stream())
+        slot = RANGES.out_slot(x2.device)
+        lz = LazyNorm(x2, w, b, eps, y, stats, slot)
+        if not lazy:
+            lz.run()
         ctx.save_for_backward(x2, w, stats)
         ctx.has_b = b is not None
         ctx.bias = b
-        return RANGES.tag(y.view(x.shape), slot)
+        out = RANGES.tag(y.view(x.shape), slot)
+        if lazy:
+            out._lazy_ln = lz
+        return out
 
     @staticmethod
     def backward(ctx, dy, dres=None):
@@ -92,15 +122,15 @@ class _LayerNormFork(Function):
     on its way out (dx_add of rscotr_layernorm_bwd) instead of autograd launching an element-wise add."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, lazy=False):
         ctx.set_materialize_grads(False)
-        return _LayerNorm.forward(ctx, x, w, b, eps), x
+        return _LayerNorm.forward(ctx, x, w, b, eps, lazy), x
 
     @staticmethod
     def backward(ctx, dy, dres):
         if dy is None:  # norm output unused: only the residual gradient flows
-            return dres, None, None, None
-        return _LayerNorm._backward(ctx, dy, dres)
+            return dres, None, None, None, None
+        return _LayerNorm._backward(ctx, dy, dres) + (None,)
 
 
 class _LayerNormSum(Function):
@@ -186,9 +216,10 @@ def layer_norm_sum(x, w, b, add, eps=LN_EPS):
     return _LayerNormSum.apply(x, w, b, eps, add.detach())
 
 
-def layer_norm_fork(x, w, b, eps=LN_EPS):
-    """(LayerNorm(x), x) for pre-norm residual blocks: use the second output as the residual."""
-    return _LayerNormFork.apply(x, w, b, eps)
+def layer_norm_fork(x, w, b, eps=LN_EPS, lazy=False):
+    """(LayerNorm(x), x) for pre-norm residual blocks: use the second output as the residual.  lazy=True: the norm's output goes
+    to ops.mlp and nowhere else — its launch is left to that call (LazyNorm), which may fold it into the fused MLP kernel."""
+    return _LayerNormFork.apply(x, w, b, eps, bool(lazy))
 
 
 class _GroupNormTokens(Function):

@@ -80,7 +80,8 @@ class SwinBlock(nn.Module):
         # layer_norm_fork hands x back as the residual: its gradient is added inside the LayerNorm backward kernel
         y, x = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias)
         x = self.attn(y, hw, identity=x, out_scale=scale_attn)
-        y, x = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias)
+        # (lazy: the norm's launch is left to the MLP call, its only reader, which folds it into the fused kernel where that exists)
+        y, x = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias, lazy=True)
         return self.ffn(y, identity=x, out_scale=scale_ffn)
 
 

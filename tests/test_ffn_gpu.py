@@ -189,3 +189,56 @@ def test_fused_swin_mlp_matches_fp64_and_the_two_product_route(cuda, B, L, C, dr
         ops.FFN_FUSED.enabled = old
         ops.DEFER.drop()
         opt.close()
+
+
+@pytest.mark.parametrize('B,L,C,drop', [(2, 16384, 96, True), (2, 4096, 192, False), (2, 1024, 384, True), (3, 500, 384, False), (1, 2500, 96, False)])
+def test_fused_swin_mlp_with_the_norm_in_front(cuda, B, L, C, drop):
+    """x + DropPath(MLP(LayerNorm(x))) with the norm left to the MLP call (ops.layer_norm_fork(lazy=True) -> rscotr_ffn_h3_ln: the rows
+    are normalised while the fused kernel stages them): output, the norm's output and statistics, the input gradient and all six
+    parameter gradients against fp64 and against the same block with the norm as its own launch."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    H = 4 * C
+    g = torch.Generator().manual_seed(B * L + C + 1)
+    x = (torch.randn(B, L, C, generator=g) * 1.7 + 0.3).to(cuda)
+    dy = torch.randn(B, L, C, generator=g).to(cuda)
+    scale = (torch.tensor([1.25, 0.0, 1.25][:B]) if drop else None)
+    shapes = (((C,), 0.4, 1.0), ((C,), 0.3, 0.0), ((H, C), 0.1, 0.0), ((H,), 0.3, 0.0), ((C, H), 0.05, 0.0), ((C,), 0.3, 0.0))
+    ps = [torch.nn.Parameter((torch.randn(sh, generator=g) * sc + off).to(cuda)) for sh, sc, off in shapes]
+    opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
+    old = ops.FFN_FUSED.ln
+    try:
+        xd = x.double().cpu()
+        gm, bt, w1, b1, w2, b2 = [p.detach().double().cpu().requires_grad_(True) for p in ps]
+        xr = xd.clone().requires_grad_(True)
+        sd = torch.ones(B, dtype=torch.float64) if scale is None else scale.double()
+        n64 = torch.nn.functional.layer_norm(xr, (C,), gm, bt, 1e-5)
+        pre = n64 @ w1.T + b1
+        y64 = (_gelu64(pre) @ w2.T + b2) * sd[:, None, None] + xr
+        y64.backward(dy.double().cpu())
+        ref = [y64.detach(), n64.detach(), xr.grad] + [t.grad for t in (gm, bt, w1, b1, w2, b2)]
+        res = {}
+        for fused_ln in (True, False):
+            ops.FFN_FUSED.ln = fused_ln
+            for p in ps:
+                p.grad.zero_()
+            xx = x.clone().requires_grad_(True)
+            ops.RANGES.begin(cuda)
+            n0 = ops.FFN_FUSED.ln_calls
+            n, xres = ops.layer_norm_fork(xx, ps[0], ps[1], lazy=True)
+            y = ops.mlp(n, [(ps[2], ps[3]), (ps[4], ps[5])], act='gelu', identity=xres, out_scale=None if scale is None else scale.to(cuda))
+            y.backward(dy)
+            ops.flush_deferred()
+            torch.cuda.synchronize()
+            assert (ops.FFN_FUSED.ln_calls - n0 == 1) == fused_ln
+            res[fused_ln] = [y.detach(), n.detach(), xx.grad.detach()] + [p.grad.detach().clone() for p in ps]
+        errs = [(i, _rel(a, r), _rel(b, r)) for i, (a, b, r) in enumerate(zip(res[True], res[False], ref))]
+        assert all(torch.isfinite(a).all() for a in res[True])
+        assert all(e_f <= max(1e-6, 1.5 * e_u) for _, e_f, e_u in errs), errs
+        # the norm's output range word: the true maximum, as the norm's own launch leaves it
+    finally:
+        ops.FFN_FUSED.ln = old
+        ops.DEFER.drop()
+        opt.close()
