@@ -487,6 +487,11 @@ def main():
         r_wa = named('mfma', ['swin_wattn_fwd_kernel', 'swin_wattn_bwd_kernel'], 'mfma', MFMA_F32_PEAK_TF, 'TFLOP/s', 1e12,
                      note='4 (forward) / 10 (backward) x 49 x 49 x 32 flop per (image, window, head) on the real tokens, '
                           'v_mfma_f32_32x32x2_f32; latency-bound per item (49 x 49 x 32 products on 64-row MFMA tiles)')
+        # the fused two-Linear launches (round 6): by total time the largest kernel family of the round after the 64 x 64 split product
+        r_ffn = named('gemm', ['ffn_h3_kernel'], 'mfma', H3_PEAK_TF, 'TFLOP/s', 1e12,
+                      note='4 M C H fp32-equivalent flops per launch (both products; the few-row launches without their combine), three '
+                           'v_mfma_f32_16x16x32_f16 per 32 k, peak = dense fp16 MFMA peak / 3; encoder FFN 256 -> 2048 -> 256 (ReLU), the '
+                           'detection decoder\'s, Swin stage 1-3 MLPs (GELU, the norm in front as the prologue), forward and mirrored backward')
         r_f = hbm('msda_fwd', 'rscotr::msda_fwd_kernel<32, 4>')
         r_b = hbm('msda_bwd', 'rscotr_msda_bwd (sample + tile + combine kernels)')
         try:  # HBM bytes per call from the same PMC passes (every msda_* kernel of the backward entry summed)
@@ -523,7 +528,7 @@ def main():
                                hipgraph_tasks=list(runner.graphed.keys())),
                    roofline=r_gemm, roofline_gemm_family=fam, roofline_msda_fwd=r_f, roofline_msda_bwd=r_b,
                    roofline_attn_fwd=r_af, roofline_attn_bwd=r_ab, roofline_swin_wattn=r_wa, roofline_layernorm=r_ln,
-                   roofline_splitk=r_sk, roofline_adamw=r_ad,
+                   roofline_splitk=r_sk, roofline_adamw=r_ad, roofline_ffn=r_ffn,
                    roofline_bracket_us=round(bracket_s * 1e6, 3),  # median empty event bracket, subtracted from every roofline sample
                    per_task_ms=per_task)  # rank 0, device time per iteration inside the timed region
         if world == 1 and not a.no_cpu_baseline:

@@ -101,6 +101,18 @@ __device__ __forceinline__ void store_b128(float4 v, __amdgpu_buffer_rsrc_t r, i
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef FFN_PHASES
+#define FFN_PHASES 4  // distinct starting chunks among the workgroups that share an L2.  16 (every chunk of 256 -> 2048 a starting point) spreads the
+                      // cold requests widest but puts all 4 MB of both weights' planes into the working set of a 4 MB L2 next to the 89 MB hidden
+                      // stream: 2 x 155 MiB fetched per launch against 2 x 27 without rotation (scripts/lab/pmc_ffn_traffic.sh); 4: 2 x 77 MiB, the
+                      // same launch time cold and in the step (29.66-29.72 ms per round; 8: 29.64-29.65; 16: 29.72-29.79; 2: 29.96-29.99)
+#endif
+// first chunk of workgroup j (of those sharing the weights through one L2) in a run of n chunks
+__device__ __forceinline__ int ffn_phase(int j, int n) {
+  const int ph = n < FFN_PHASES ? n : FFN_PHASES;
+  return (int)((unsigned)j % (unsigned)ph) * n / ph;
+}
+
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0r = cbase;
 #else
-  const int c0r = cbase + (C >= 256 ? (int)((unsigned)jx % (unsigned)nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
+  const int c0r = cbase + (C >= 256 ? ffn_phase(jx, nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
 #endif
   uint4 ring[RING];
   if (role_a) {
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0 = 0;
 #else
-  const int c0 = C >= 256 ? (int)((unsigned)jx % (unsigned)nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
+  const int c0 = C >= 256 ? ffn_phase(jx, nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
 #endif
   auto chunk_of = [&](int c) {
     if constexpr (C < 256) return cbase + c;

@@ -5,7 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 out=$R/gpurun_out/ffn_split_cold.txt; : > $out
 for v in "" "$@"; do
-  for shape in "2048 384 1536" "1600 256 2048" "10880 256 2048"; do
+  IFS=';' read -ra SH <<< "${SHAPES:-2048 384 1536;1600 256 2048;10880 256 2048}"
+  for shape in "${SH[@]}"; do
     for fl in flush ""; do
       rm -rf /tmp/fsl
       env ${v:+RSCOTR_LIB=$R/rscotr_amd/_ab/lib_$v.so} RSCOTR_FFN_FUSED_MIN_ROWS=256 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fsl -o t -- python $R/scripts/lab/ffn_cold.py $shape fused $fl > /tmp/fsl.log 2>&1
