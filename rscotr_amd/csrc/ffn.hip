@@ -101,6 +101,10 @@ __device__ __forceinline__ void store_b128(float4 v, __amdgpu_buffer_rsrc_t r, i
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef FFN_STAG_MINC
+#define FFN_STAG_MINC 192  // narrowest width whose launches rotate their chunk order: 8192 x 192 -> 768 cold 45.6 / 41.5 -> 38.2 / 37.6 us with it; C = 96 (held to
+                           // 128 registers, where the rotation's index arithmetic spills) 57 -> 61: stays in order
+#endif
 #ifndef FFN_PHASES
 #define FFN_PHASES 4  // distinct starting chunks among the workgroups that share an L2.  16 (every chunk of 256 -> 2048 a starting point) spreads the
                       // cold requests widest but puts all 4 MB of both weights' planes into the working set of a 4 MB L2 next to the 89 MB hidden
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0r = cbase;
 #else
-  const int c0r = cbase + (C >= 256 ? ffn_phase(jx, nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
+  const int c0r = cbase + (C >= FFN_STAG_MINC ? ffn_phase(jx, nloc) : 0);  // (= chunk_of(0) below: the first chunk of this workgroup)
 #endif
   uint4 ring[RING];
   if (role_a) {
@@ -303,10 +307,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
 #ifdef FFN_NO_STAGGER
   const int c0 = 0;
 #else
-  const int c0 = C >= 256 ? ffn_phase(jx, nloc) : 0;  // (the Swin widths' weights are a few hundred KB: nothing to spread)
+  const int c0 = C >= FFN_STAG_MINC ? ffn_phase(jx, nloc) : 0;  // (C = 96 stays in order: FFN_STAG_MINC)
 #endif
   auto chunk_of = [&](int c) {
-    if constexpr (C < 256) return cbase + c;
+    if constexpr (C < FFN_STAG_MINC) return cbase + c;
     const int v = c + c0;
     return cbase + (v >= nloc ? v - nloc : v);
   };
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
             }
             // (k step ks + FFN_DB of this chunk, or the first ones of the next chunk in this workgroup's order)
             int tn;
-            if constexpr (C < 256) tn = cbase * HST + min(c * HST + ks + FFN_DB, nloc * HST - 1);
+            if constexpr (C < FFN_STAG_MINC) tn = cbase * HST + min(c * HST + ks + FFN_DB, nloc * HST - 1);
             else tn = ks + FFN_DB < HST ? cb * HST + ks + FFN_DB : chunk_of(min(c + 1, nloc - 1)) * HST + (ks + FFN_DB - HST);
 #pragma unroll
             for (int it = 0; it < TPB; ++it) {
