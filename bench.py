@@ -391,7 +391,7 @@ def main():
             return 'bf16x6' in k or 'wplanes' in k or 'gemm_f32_group_kernel<6>' in k
 
         def is_h3(k):  # ... the three-term fp16 split (2500 / 3)
-            return 'gemm_h3' in k or 'ffn_h3' in k
+            return 'gemm_h3' in k or 'ffn_h3' in k or 'lin_h3' in k
         if gg:
             name, d = max(gg.items(), key=lambda kv: kv[1][1])
             ach = d[0] / d[1] / 1e12

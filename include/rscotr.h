@@ -31,7 +31,7 @@ extern "C" {
  * `stream` in the LayerNorm, window-attention, MSDA backward, pack4, splitk_flush and grouped-dW entries = revision 6;
  * round 6 = 7).  rscotr_version() returns the revision the shared object was BUILT with; a binding compares the two before
  * its first call (rscotr_amd/_lib.py does) — a stale .so would take a stream handle for a pointer. */
-#define RSCOTR_ABI_VERSION 8
+#define RSCOTR_ABI_VERSION 9
 int rscotr_version(void);
 const char* rscotr_last_error(void);
 int rscotr_device_count(void);
@@ -254,6 +254,21 @@ int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks
  * C in {96, 192, 384}.  amax_ln_weight (required) / amax_ln_bias: range words of the affine parameters — the planes of the
  * normalised rows are scaled from sqrt(C) max|weight| + max|bias|; amax_ln_out (optional): range word of ln_out, committed.
  * Everything else as rscotr_ffn_h3 (no bits, no xscale). */
+/* ONE Linear on the fused kernel's machinery for the tall, narrow products of Swin stages 1 / 2 (mmdet WindowMSA's qkv / proj Linears
+ * and their input gradients, reached through ShiftWindowMSA.forward of the backbone, cfg :9-25): Y (M, N) = (X Wop^T + bias) *
+ * yscale[row / rows_per] + resid, X' = X * xscale[row / rows_per]; X (M, K) row-major fp32, K in {96, 128, 192, 256, 288, 384, 576},
+ * N % 32 == 0 (rscotr_lin_h3_ok).  Wf: fragment-major fp16 planes of Wop (N rows, reduction K; rscotr_gemm_split_weights_frag).  A
+ * workgroup stages the planes of 32 rows once and its eight wavefronts take 32 output columns each — memory-bound shapes, where the
+ * tiled kernels re-stage the rows per column tile.  The three-term fp16 split product (rscotr_gemm_f32_r's arithmetic on 16 x 16 x 32
+ * MFMAs: equal at fp32 rounding).  rscotr_lin_h3_ln: with the LayerNorm in front (K in {96, 192, 384}), as rscotr_ffn_h3_ln. */
+int rscotr_lin_h3_ok(int M, int N, int K);
+int rscotr_lin_h3(const float* X, int M, int N, int K, const void* Wf, const float* bias, const float* resid, float* Y,
+                  const float* xscale, const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w,
+                  uint32_t* amax_y, void* stream);
+int rscotr_lin_h3_ln(const float* X, int M, int N, int K, const float* ln_weight, const float* ln_bias, float ln_eps, float* ln_out,
+                     float* ln_mean, float* ln_rstd, const void* Wf, const float* bias, const float* resid, float* Y,
+                     const float* yscale, int rows_per, const uint32_t* amax_ln_weight, const uint32_t* amax_ln_bias,
+                     const uint32_t* amax_w, uint32_t* amax_ln_out, uint32_t* amax_y, void* stream);
 int rscotr_ffn_h3_ln(const float* X, int M, int C, int H, const float* ln_weight, const float* ln_bias, float ln_eps, float* ln_out,
                      float* ln_mean, float* ln_rstd, const void* W1f, const float* b1, const void* W2f, const float* b2, float* Pre,
                      float* Hid, const float* resid, float* Y, const float* yscale, int rows_per, const uint32_t* amax_ln_weight,

@@ -552,6 +552,208 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   }
 }
 
+// ONE Linear on the same machinery for the TALL, NARROW products of Swin stages 1 and 2 (mmdet WindowMSA's qkv / proj Linears and their
+// input gradients: 32768 x 96 -> 288, 32768 x 96 -> 96, 32768 x 288 -> 96; 8192 x 192 -> 576 ...; cfg configs/multi/...potsdam.py:9-25):
+// y = (x W^T + b) * yscale (+ resid).  These move 25-50 MB for 0.6-1.8 GFLOP — memory-bound shapes on which the tiled 64 x 64
+// kernels spend 17-36 us (each of the 5-9 column tiles of a row tile stages and converts the rows again, six k steps of fixed cost
+// per workgroup) against 8-11 us of HBM time.  Here a workgroup (512 threads) stages the planes of 32 rows ONCE (optionally
+// normalising them on the way: the LayerNorm in front of qkv) and its eight wavefronts take 32 output columns each, 256 per sweep,
+// weight fragments straight from the fragment-major planes; no barrier after the staging one.  (The same form for the 256-wide
+// 10880-row Linears of the encoder lost to the tiled kernel in the step — profiles/r6_ffn_lab.txt item 4: those are not memory-bound.)
+struct LinParams {
+  const float* X;
+  int M, N;            // rows; output columns (N % 32 == 0)
+  const uint4* Wf;     // fragment-major planes of the weight operand (N rows, reduction C)
+  const float* bias;
+  const float* resid;
+  float* Y;
+  const float* xscale; // per-sample factor on the rows of X while they are staged | null
+  const float* yscale; // per-sample factor on Y before the residual | null
+  int rows_per;
+  const unsigned *amax_x, *amax_w;
+  unsigned* amax_y;
+  const float *ln_g, *ln_b;  // LN instantiations: see FfnParams
+  float ln_eps;
+  float *ln_out, *ln_mean, *ln_rstd;
+  const unsigned *amax_g, *amax_bt;
+  unsigned* amax_ln;
+};
+
+template <int C, bool LN>
+__global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
+  constexpr int NT = 2, BM = 16 * NT, STG = BM * FFN_LDRB, KS1 = C / 32;
+  constexpr int DA = KS1 % 2 == 0 ? 2 : KS1 % 3 == 0 ? 3 : 1;  // k steps the weight loads run ahead (DA | KS1: the ring position of a k step is the same in every sweep)
+  static_assert(C % 32 == 0 && KS1 % DA == 0, "reduction in whole 32-k steps");
+  unsigned char* xs = ffn_lds;  // [KS1][BM][160]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const long sub = (long)(lane & (kAmaxPlanes - 1)) * kAmaxStride;
+  const unsigned rx = LN ? 0u : p.amax_x[sub], rw = p.amax_w[sub];
+  const unsigned rg = LN ? p.amax_g[sub] : 0u, rbt = (LN && p.amax_bt) ? p.amax_bt[sub] : 0u;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.Wf), 0, p.N * C * 4, 0x00020000);
+  auto ld_w = [&](int col0, int ks, int it, int pl) {  // fragment of column tile col0 / 16 + it, k step ks, plane pl
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, ((col0 >> 4) + it) * (KS1 * 2048) + ks * 2048 + pl * 1024, 0));
+  };
+  // (the first sweep's fragments are requested before the rows: cold lines)
+  const int c_first = wv * 32;
+  uint4 ring[4 * DA];
+  if (c_first < p.N) {
+#pragma unroll
+    for (int q = 0; q < 4 * DA; ++q) ring[q] = ld_w(c_first, q >> 2, (q >> 1) & 1, q & 1);
+  }
+  const int rows_ok = min(BM, p.M - m0);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)m0 * p.N, 0, rows_ok * p.N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * p.N : p.X), 0, rows_ok * p.N * 4, 0x00020000);
+  const unsigned ux = LN ? __float_as_uint(sqrtf((float)C) * __uint_as_float(amax_fold(rg)) + __uint_as_float(amax_fold(rbt))) : amax_fold(rx);
+  const int ex = h3_scale_exp(ux);
+  const H3Scale hx{__uint_as_float((unsigned)ex << 23), __uint_as_float((unsigned)(ex + 11) << 23)};
+  if constexpr (!LN) {
+    constexpr int TOT = BM * (C / 4), NV = (TOT + 511) / 512;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (tid + i * 512) * 16, 0, 0));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 512;
+      if (TOT % 512 == 0 || idx < TOT) {
+        const int row = idx / (C / 4), kq = (idx % (C / 4)) * 4;
+        if (p.xscale) {
+          const float f = p.xscale[min(m0 + row, p.M - 1) / p.rows_per];
+          v[i].x *= f; v[i].y *= f; v[i].z *= f; v[i].w *= f;
+        }
+        unsigned ab[3], cd[3];
+        split_pair_h(v[i].x, v[i].y, hx, ab);
+        split_pair_h(v[i].z, v[i].w, hx, cd);
+        unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+      }
+    }
+  } else {  // (ffn_h3_kernel's LN staging: C / 12 lanes per row, three float4 each)
+    static_assert(!LN || (C % 48 == 0 && (C / 12 == 8 || C / 12 == 16 || C / 12 == 32)), "LN rows: 8 / 16 / 32 lanes x 3 float4");
+    constexpr int G = C / 12, RPP = 512 / G, NP = (BM + RPP - 1) / RPP;
+    const int sb = tid % G, rr = tid / G;
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
+    float amx = 0.f;
+    if (RPP <= BM || wv < 8 * BM / RPP) {
+      float4 gw[3], gb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        gw[j] = reinterpret_cast<const float4*>(p.ln_g)[sb + j * G];
+        gb[j] = p.ln_b ? reinterpret_cast<const float4*>(p.ln_b)[sb + j * G] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int row = ps * RPP + rr;
+        float4 v[3];
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (row * C + 4 * (sb + j * G)) * 4, 0, 0));
+          sm += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const float mu = sm * (1.f / (float)C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+          q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q * (1.f / (float)C) + p.ln_eps);
+        if (sb == 0 && row < rows_ok) { p.ln_mean[m0 + row] = mu; p.ln_rstd[m0 + row] = rs; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float4 o;
+          o.x = v[j].x * rs * gw[j].x + gb[j].x; o.y = v[j].y * rs * gw[j].y + gb[j].y;
+          o.z = v[j].z * rs * gw[j].z + gb[j].z; o.w = v[j].w * rs * gw[j].w + gb[j].w;
+          if (row >= rows_ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int kq = 4 * (sb + j * G);
+          store_b128(o, rL, (row * C + kq) * 4, 0);
+          amx = amax4(amx, o);
+          unsigned ab[3], cd[3];
+          split_pair_h(o.x, o.y, hx, ab);
+          split_pair_h(o.z, o.w, hx, cd);
+          unsigned char* dst = xs + (kq / 32) * STG + row * FFN_LDRB + (kq % 32) * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(ab[0], cd[0]);
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(ab[1], cd[1]);
+        }
+      }
+    }
+    amax_commit(p.amax_ln, amx);
+  }
+  const int ew = h3_scale_exp(amax_fold(rw));
+  const float inv = __uint_as_float((unsigned)(254 - ex) << 23) * __uint_as_float((unsigned)(254 - ew) << 23);
+  const int fo = li * FFN_LDRB + kg * 16;
+  __syncthreads();
+
+  float amy = 0.f;
+#pragma unroll 1
+  for (int col0 = c_first; col0 < p.N; col0 += 256) {  // (wave-uniform)
+    f32x4_t ha[2][NT], hb[2][NT];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int cnext = col0 + 256 < p.N ? col0 + 256 : col0;  // (past the last sweep: a harmless re-read)
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      uint4 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const unsigned char* q = xs + ks * STG + n * 16 * FFN_LDRB + fo;
+        xh[n] = *reinterpret_cast<const uint4*>(q);
+        xl[n] = *reinterpret_cast<const uint4*>(q + 64);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int slot = (ks % DA) * 4 + it * 2;
+        const uint4 wh = ring[slot], wl = ring[slot + 1];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wh, xl[n], hb[it][n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) hb[it][n] = mfma16(wl, xh[n], hb[it][n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ha[it][n] = mfma16(wh, xh[n], ha[it][n]);
+        if (ks + DA < KS1) { ring[slot] = ld_w(col0, ks + DA, it, 0); ring[slot + 1] = ld_w(col0, ks + DA, it, 1); }
+        else { ring[slot] = ld_w(cnext, ks + DA - KS1, it, 0); ring[slot + 1] = ld_w(cnext, ks + DA - KS1, it, 1); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // y = ((h h + (l h + h l) 2^-11) 2^-(s_x + s_w) + b) * yscale (+ resid): four consecutive columns of a row per lane
+    const int vY = (li * p.N + col0 + 4 * kg) * 4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col0 + it * 16 + 4 * kg);
+      float4 e[NT];
+      float ysc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        e[n] = p.resid ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, vY, (n * 16 * p.N + it * 16) * 4, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ysc[n] = p.yscale ? p.yscale[min(m0 + n * 16 + li, p.M - 1) / p.rows_per] : 1.f;
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float4 v;
+        v.x = fmaf(fmaf(hb[it][n][0], 0x1p-11f, ha[it][n][0]) * inv + bv.x, ysc[n], e[n].x);
+        v.y = fmaf(fmaf(hb[it][n][1], 0x1p-11f, ha[it][n][1]) * inv + bv.y, ysc[n], e[n].y);
+        v.z = fmaf(fmaf(hb[it][n][2], 0x1p-11f, ha[it][n][2]) * inv + bv.z, ysc[n], e[n].z);
+        v.w = fmaf(fmaf(hb[it][n][3], 0x1p-11f, ha[it][n][3]) * inv + bv.w, ysc[n], e[n].w);
+        store_b128(v, rY, vY, (n * 16 * p.N + it * 16) * 4);
+        amy = amax4(amy, v);
+      }
+    }
+  }
+  amax_commit(p.amax_y, amy);
+}
+
 // (Measured and removed, profiles/r6_ffn_lab.txt: the same machinery for the ONE-product 256-wide Linears of the encoder — value /
 //  output projections, offsets | logits, their input gradients; rows' planes staged once, weight fragments from fragment-major
 //  planes, 16-byte stores — 12.9 us per 10880 x 256 x 256 launch against 14.1 for the tiled 64 x 64 kernel in the cold lab, but
@@ -771,4 +973,73 @@ extern "C" int rscotr_ffn_h3_ln(const float* X, int M, int C, int H, const float
   const FfnNorm ln{ln_weight, ln_bias, ln_eps, ln_out, ln_mean, ln_rstd, amax_ln_weight, amax_ln_bias, amax_ln_out};
   return ffn_h3_run(X, M, C, H, W1f, b1, W2f, b2, FFN_GELU, nullptr, Pre, Hid, resid, Y, nullptr, yscale, rows_per, nullptr, amax_w1, amax_w2,
                     amax_b1, amax_hid, amax_y, workspace, workspace_bytes, ln, stream);
+}
+
+// ---- the one-Linear launch (lin_h3_kernel)
+template <int C, bool LN>
+static void lin_launch(const LinParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)(C / 32) * 32 * FFN_LDRB;
+  static bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_h3_kernel<C, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((lin_h3_kernel<C, LN>), dim3((unsigned)((p.M + 31) / 32)), dim3(512), lds, s, p);
+}
+
+extern "C" int rscotr_lin_h3_ok(int M, int N, int K) {
+  const bool k_ok = K == 96 || K == 128 || K == 192 || K == 256 || K == 288 || K == 384 || K == 576;
+  return (k_ok && N >= 32 && N % 32 == 0 && M >= 1 && (long)M * N * 4 < (1l << 32) && (long)M * K * 4 < (1l << 32)) ? 1 : 0;
+}
+
+static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const float* bias, const float* resid, float* Y,
+                      const float* xscale, const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w,
+                      uint32_t* amax_y, const FfnNorm& ln, void* stream) {
+  if (!rscotr_lin_h3_ok(M, N, K)) return fail(RSCOTR_E_SHAPE, "lin_h3: M=%d N=%d K=%d (K in {96, 128, 192, 256, 288, 384, 576}, N %% 32 == 0)", M, N, K);
+  if (!X || !Wf || !Y || (!amax_x && !ln.g) || !amax_w) return fail(RSCOTR_E_ARG, "lin_h3: null argument");
+  if ((xscale || yscale) && rows_per <= 0) return fail(RSCOTR_E_ARG, "lin_h3: rows_per with a row scale");
+  if (((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)bias) & 15)
+    return fail(RSCOTR_E_ALIGN, "lin_h3: operands must be 16-byte aligned");
+  if (ln.g) {
+    if (!(K == 96 || K == 192 || K == 384)) return fail(RSCOTR_E_SHAPE, "lin_h3_ln: the norm prologue exists at K in {96, 192, 384} (K=%d)", K);
+    if (!ln.out || !ln.mean || !ln.rstd || !ln.amax_g || xscale) return fail(RSCOTR_E_ARG, "lin_h3_ln: null argument (or a row scale on X)");
+    if (((uintptr_t)ln.g | (uintptr_t)ln.b | (uintptr_t)ln.out) & 15) return fail(RSCOTR_E_ALIGN, "lin_h3_ln: operands must be 16-byte aligned");
+  }
+  LinParams p{};
+  p.X = X; p.M = M; p.N = N; p.Wf = static_cast<const uint4*>(Wf); p.bias = bias; p.resid = resid; p.Y = Y;
+  p.xscale = xscale; p.yscale = yscale; p.rows_per = rows_per > 0 ? rows_per : 1;
+  p.amax_x = amax_x; p.amax_w = amax_w; p.amax_y = amax_y;
+  p.ln_g = ln.g; p.ln_b = ln.b; p.ln_eps = ln.eps; p.ln_out = ln.out; p.ln_mean = ln.mean; p.ln_rstd = ln.rstd;
+  p.amax_g = ln.amax_g; p.amax_bt = ln.amax_b; p.amax_ln = ln.amax_out;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, s, "rscotr::lin_h3_kernel<%d, %s>", K, ln.g ? "true" : "false");
+  if (ln.g) {
+    if (K == 96) lin_launch<96, true>(p, s);
+    else if (K == 192) lin_launch<192, true>(p, s);
+    else lin_launch<384, true>(p, s);
+  } else switch (K) {
+    case 96: lin_launch<96, false>(p, s); break;
+    case 128: lin_launch<128, false>(p, s); break;
+    case 192: lin_launch<192, false>(p, s); break;
+    case 256: lin_launch<256, false>(p, s); break;
+    case 288: lin_launch<288, false>(p, s); break;
+    case 384: lin_launch<384, false>(p, s); break;
+    default: lin_launch<576, false>(p, s); break;
+  }
+  return check_launch("lin_h3");
+}
+
+extern "C" int rscotr_lin_h3(const float* X, int M, int N, int K, const void* Wf, const float* bias, const float* resid, float* Y,
+                             const float* xscale, const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w,
+                             uint32_t* amax_y, void* stream) {
+  return lin_h3_run(X, M, N, K, Wf, bias, resid, Y, xscale, yscale, rows_per, amax_x, amax_w, amax_y, FfnNorm{}, stream);
+}
+
+extern "C" int rscotr_lin_h3_ln(const float* X, int M, int N, int K, const float* ln_weight, const float* ln_bias, float ln_eps,
+                                float* ln_out, float* ln_mean, float* ln_rstd, const void* Wf, const float* bias, const float* resid,
+                                float* Y, const float* yscale, int rows_per, const uint32_t* amax_ln_weight, const uint32_t* amax_ln_bias,
+                                const uint32_t* amax_w, uint32_t* amax_ln_out, uint32_t* amax_y, void* stream) {
+  if (!ln_weight) return fail(RSCOTR_E_ARG, "lin_h3_ln: null LayerNorm weight");
+  const FfnNorm ln{ln_weight, ln_bias, ln_eps, ln_out, ln_mean, ln_rstd, amax_ln_weight, amax_ln_bias, amax_ln_out};
+  return lin_h3_run(X, M, N, K, Wf, bias, resid, Y, nullptr, yscale, rows_per, nullptr, amax_w, amax_y, ln, stream);
 }

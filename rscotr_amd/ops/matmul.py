@@ -835,6 +835,67 @@ class _FusedFFN:
 FFN_FUSED = _FusedFFN()
 
 
+class _FusedLinear:
+    """ONE Linear on the fused MLP kernel's machinery (rscotr_lin_h3, csrc/ffn.hip: the rows' planes staged once per workgroup, the
+    weight as fragment-major planes) for the TALL, NARROW products — Swin stages 1 / 2: the qkv / proj Linears of the window attention,
+    PatchMerging's reduction, and their input gradients: 32768 x 96 -> 288 and the like, 25-50 MB for ~1 GFLOP, where the tiled
+    kernels re-stage the rows once per column tile.  Taken where the weight is a parameter of the optimizer's arena and the value
+    ranges are on; the 256-wide 10880-row Linears of the encoder stay on the tiled kernel (measured: profiles/r6_ffn_lab.txt)."""
+
+    MIN_ROWS = int(os.environ.get('RSCOTR_LIN_FUSED_MIN_ROWS', 8192))
+
+    def __init__(self):
+        self.enabled = os.environ.get('RSCOTR_LIN_FUSED', '1') != '0'
+        self.ln = os.environ.get('RSCOTR_LIN_FUSED_LN', '1') != '0'
+        self.calls = 0
+        self.ln_calls = 0
+
+    def ok(self, x2, W, N, K):
+        M = x2.shape[0]
+        sink = STATE.grad_sink
+        if (not self.enabled or not RANGES.enabled or sink is None or STATE.profile is not None or M < self.MIN_ROWS
+                or min(N, K) > 192 or max(N, K) > 576 or x2.data_ptr() % 16 or not W.is_contiguous()):
+            return False
+        return sink.is_param_ptr(W.data_ptr()) and bool(lib.rscotr_lin_h3_ok(M, N, K))
+
+    def ln_ok(self, lz, K):
+        sink = STATE.grad_sink
+        return (self.ln and K in (96, 192, 384) and lz.w is not None and sink is not None and sink.is_param_ptr(lz.w.data_ptr())
+                and (lz.b is None or sink.is_param_ptr(lz.b.data_ptr())))
+
+    def run(self, x2, W, bias, tr, resid, want_y_range, xscale=None, yscale=None, rows_per=0, ln=None):
+        """tr = 0: y = x W^T (W (N, K) as stored); tr = 1: y = x W (W (K, N): the input gradient of the Linear).  ln: a pending LazyNorm whose
+        output x2 is (rscotr_lin_h3_ln).  -> y (M, N)."""
+        M, K = x2.shape
+        N = W.shape[1] if tr else W.shape[0]
+        dev = x2.device
+        sink = STATE.grad_sink
+        s_x = 0 if ln is not None else RANGES.of(x2, M, K, K)
+        s_w = RANGES.of(W, W.shape[0], W.shape[1], W.shape[1])
+        wf = FPLANES.get(W, tr, s_w)
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        s_y = 0
+        if want_y_range:
+            s_y = RANGES.new_slot(dev)
+            RANGES.tag(y, s_y)
+        if ln is not None:
+            assert xscale is None and ln.y.data_ptr() == x2.data_ptr()
+            lib.call('rscotr_lin_h3_ln', ln.x2.data_ptr(), M, N, K, _ptr(ln.w), _ptr(ln.b), float(ln.eps), x2.data_ptr(),
+                     ln.stats[0].data_ptr(), ln.stats[1].data_ptr(), wf, _ptr(bias), _ptr(resid), y.data_ptr(), _ptr(yscale),
+                     int(rows_per), sink.amax_slot(ln.w.data_ptr()), 0 if ln.b is None else sink.amax_slot(ln.b.data_ptr()), s_w,
+                     ln.slot, s_y, _stream())
+            ln.done = True
+            self.ln_calls += 1
+        else:
+            lib.call('rscotr_lin_h3', x2.data_ptr(), M, N, K, wf, _ptr(bias), _ptr(resid), y.data_ptr(), _ptr(xscale), _ptr(yscale),
+                     int(rows_per), s_x, s_w, s_y, _stream())
+        self.calls += 1
+        return y
+
+
+LIN_FUSED = _FusedLinear()
+
+
 class _MLP(Function):
     """y = L_n(act(L_{n-1}(... act(L_1(x))))) [+ identity], L_i(h) = h W_i^T + b_i: every Linear is
     one MFMA GEMM with bias/activation/residual fused in its epilogue; backward folds act' into the
@@ -873,10 +934,15 @@ class _MLP(Function):
         RANGE_OUT.skip_next = False
         ctx.fused = FFN_FUSED.ok(x2, ws, act, out_scale, sum_with)
         lz = getattr(x, '_lazy_ln', None)  # (the norm in front has not run yet: ops.layer_norm_fork(lazy=True))
-        if lz is not None and not lz.done and not (ctx.fused and FFN_FUSED.ln_ok(lz, K0, act)):
+        # ONE Linear, tall and narrow (ops.LIN_FUSED): the rows-resident launch instead of the tiled product
+        ctx.lin = (n == 1 and act == ACT_NONE and sum_with is None and LIN_FUSED.ok(x2, ws[0], ws[0].shape[0], K0))
+        if lz is not None and not lz.done and not ((ctx.fused and FFN_FUSED.ln_ok(lz, K0, act)) or (ctx.lin and LIN_FUSED.ln_ok(lz, K0))):
             lz.run()
         if lz is not None and lz.done:
             lz = None
+        if ctx.lin:
+            h = LIN_FUSED.run(x2, ws[0], bs[0], 0, id2, want_last, yscale=out_scale, rows_per=rows_per, ln=lz)
+            n = 0
         if ctx.fused:
             W1 = ws[0] if ws[0].is_contiguous() else ws[0].contiguous()
             W2 = ws[1] if ws[1].is_contiguous() else ws[1].contiguous()
@@ -1002,7 +1068,11 @@ class _MLP(Function):
                 # identity == input: its gradient (dy) rides in this epilogue instead of a separate add
                 # (the node's input gradient goes to a norm's backward, an attention backward or a merge: no later product
                 #  multiplies with it directly)
-                dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, range_out=RANGE_OUT.want(False), **scr)
+                if n == 1 and getattr(ctx, 'lin', False) and LIN_FUSED.ok(g, W, K, N):
+                    dx = LIN_FUSED.run(g, W, None, 1, g_out if ctx.id_is_x else None, RANGE_OUT.want(False),
+                                       yscale=scr.get('rowscale'), rows_per=scr.get('rows_per', 0))
+                else:
+                    dx = gemm(g, W, M, K, N, N, K, 0, 1, resid=g_out if ctx.id_is_x else None, range_out=RANGE_OUT.want(False), **scr)
                 dx = RANGES.carry(dx, dx.view(ctx.x_shape))
         return (dx, d_id, None, None, None, *grads_wb)
 

@@ -78,7 +78,8 @@ class SwinBlock(nn.Module):
         """x + DropPath(attn(LN1 x)); then x + DropPath(ffn(LN2 x)).  scale_* (B,) = keep / keep_prob of mmcv's
         drop_path (None: no stochastic depth): residual add and scaling ride the proj / fc2 GEMM epilogues."""
         # layer_norm_fork hands x back as the residual: its gradient is added inside the LayerNorm backward kernel
-        y, x = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias)
+        # (lazy: the norm's output has one reader, the qkv Linear, which takes the norm as its prologue where that launch exists)
+        y, x = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias, lazy=True)
         x = self.attn(y, hw, identity=x, out_scale=scale_attn)
         # (lazy: the norm's launch is left to the MLP call, its only reader, which folds it into the fused kernel where that exists)
         y, x = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias, lazy=True)

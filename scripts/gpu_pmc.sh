@@ -9,7 +9,7 @@ TAG=${1:-r1}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_h3|ffn_h3|gemm_bf16x6|gemm_f32_group|msda_|attn_' --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-rounds 1 > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'gemm_f32_kernel|gemm_h3|ffn_h3|lin_h3|gemm_bf16x6|gemm_f32_group|msda_|attn_' --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-rounds 1 > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   python - "$f" "$R/gpurun_out/${TAG}_pmc_$c.csv" <<'PY'
 import csv, sys, collections

@@ -61,7 +61,7 @@ def _product_state():
     st = dict(switches=tuple(sorted(ops.STATE.changed().items())),
               hooks=(ops.STATE.side is None, ops.STATE.profile is None),
               defer=(ops.DEFER.enabled, ops.DEFER.group_enabled, ops.DEFER.group_x6, ops.DEFER.pin),
-              wplanes=(ops.WPLANES.enabled, ops.HPLANES.enabled, ops.RELU_BITS.enabled, ops.FFN_FUSED.enabled),
+              wplanes=(ops.WPLANES.enabled, ops.HPLANES.enabled, ops.RELU_BITS.enabled, ops.FFN_FUSED.enabled, ops.LIN_FUSED.enabled),
               ranges=(ops.RANGES.enabled, ops.RANGES.check, ops.RANGE_OUT.all, ops.RANGE_OUT.skip_next),
               env=tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('RSCOTR_'))))
     if os.path.exists(LIB_PATH):

@@ -242,3 +242,58 @@ def test_fused_swin_mlp_with_the_norm_in_front(cuda, B, L, C, drop):
         ops.FFN_FUSED.ln = old
         ops.DEFER.drop()
         opt.close()
+
+
+@pytest.mark.parametrize('B,L,K,N,norm,resid', [(2, 16384, 96, 288, True, False), (2, 16384, 96, 96, False, True), (2, 4096, 192, 576, True, False),
+                                                (2, 4096, 192, 192, False, True), (1, 9000, 96, 288, True, False), (3, 3000, 192, 192, False, True),
+                                                (2, 4096, 384, 192, False, False), (2, 4096, 96, 288, False, False)])
+def test_tall_narrow_linear_on_the_rows_resident_launch(cuda, B, L, K, N, norm, resid):
+    """One Linear of the Swin window attention at stage 1 / 2 sizes on ops.LIN_FUSED (rscotr_lin_h3 / _ln): y = [LayerNorm](x) W^T + b
+    [* DropPath factor + identity] forward, the input gradient (the mirrored launch: K and N swapped, planes of W^T) and every parameter
+    gradient against fp64 and against the tiled route, ragged row counts included."""
+    from rscotr_amd import ops
+    from rscotr_amd.optim import FlatAdamW
+    if not ops.RANGES.enabled:
+        pytest.skip('value ranges are off')
+    g = torch.Generator().manual_seed(B * L + K + N)
+    x = (torch.randn(B, L, K, generator=g) * 1.3 + 0.2).to(cuda)
+    dy = torch.randn(B, L, N, generator=g).to(cuda)
+    ident = torch.randn(B, L, N, generator=g).to(cuda) if resid else None
+    scale = torch.tensor([1.25, 0.0, 1.25][:B]) if resid else None
+    ps = [torch.nn.Parameter((torch.randn(sh, generator=g) * sc + off).to(cuda))
+          for sh, sc, off in (((K,), 0.4, 1.0), ((K,), 0.3, 0.0), ((N, K), 0.1, 0.0), ((N,), 0.3, 0.0))]
+    opt = FlatAdamW([dict(name=f'p{i}', param=p, lr=1e-3, weight_decay=0.0) for i, p in enumerate(ps)])
+    old, old_rows = ops.LIN_FUSED.enabled, ops.LIN_FUSED.MIN_ROWS
+    ops.LIN_FUSED.MIN_ROWS = 1024
+    try:
+        gm, bt, w, b = [p.detach().double().cpu().requires_grad_(True) for p in ps]
+        xr = x.double().cpu().requires_grad_(True)
+        sd = torch.ones(B, dtype=torch.float64) if scale is None else scale.double()
+        n64 = torch.nn.functional.layer_norm(xr, (K,), gm, bt, 1e-5) if norm else xr
+        y64 = (n64 @ w.T + b) * sd[:, None, None] + (ident.double().cpu() if resid else 0)
+        y64.backward(dy.double().cpu())
+        ref = [y64.detach(), xr.grad, w.grad, b.grad] + ([gm.grad, bt.grad] if norm else [])
+        res = {}
+        for fused in (True, False):
+            ops.LIN_FUSED.enabled = fused
+            for p in ps:
+                p.grad.zero_()
+            xx = x.clone().requires_grad_(True)
+            ops.RANGES.begin(cuda)
+            n0, l0 = ops.LIN_FUSED.calls, ops.LIN_FUSED.ln_calls
+            h = ops.layer_norm_fork(xx, ps[0], ps[1], lazy=True)[0] if norm else xx
+            y = ops.linear(h, ps[2], ps[3], resid=ident, out_scale=None if scale is None else scale.to(cuda))
+            y.backward(dy)
+            ops.flush_deferred()
+            torch.cuda.synchronize()
+            assert ops.LIN_FUSED.calls - n0 == (2 if fused else 0), ops.LIN_FUSED.calls - n0
+            assert ops.LIN_FUSED.ln_calls - l0 == (1 if fused and norm else 0)
+            res[fused] = [y.detach(), xx.grad.detach(), ps[2].grad.detach().clone(), ps[3].grad.detach().clone()] + \
+                ([ps[0].grad.detach().clone(), ps[1].grad.detach().clone()] if norm else [])
+        errs = [(i, _rel(a, r), _rel(bb, r)) for i, (a, bb, r) in enumerate(zip(res[True], res[False], ref))]
+        assert all(torch.isfinite(a).all() for a in res[True])
+        assert all(e_f <= max(1e-6, 1.5 * e_u) for _, e_f, e_u in errs), errs
+    finally:
+        ops.LIN_FUSED.enabled, ops.LIN_FUSED.MIN_ROWS = old, old_rows
+        ops.DEFER.drop()
+        opt.close()

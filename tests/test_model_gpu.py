@@ -132,7 +132,7 @@ def test_train_step_main_config_512_on_the_optimizer_arena(task, cuda):
     model = build_model(mcfg, seed=4).to(cuda)
     opt = FlatAdamW(build_param_groups(model, dict(type='AdamW', lr=1e-4, weight_decay=0.05)))
     try:
-        n0, h0 = ops.FFN_FUSED.calls, len(ops.HPLANES.entries)
+        n0, h0, l0 = ops.FFN_FUSED.calls, len(ops.HPLANES.entries), ops.LIN_FUSED.calls
         with ranges_checked():
             out, oout, rec, orec, P = run_step_pair(model, mcfg, task, 512, seed=17, device=cuda, fp64=True, opt=opt)
         if ops.RANGES.enabled and ops.FFN_FUSED.enabled:
@@ -140,6 +140,8 @@ def test_train_step_main_config_512_on_the_optimizer_arena(task, cuda):
             # (1600 query rows): 6 layers x 2
             assert ops.FFN_FUSED.calls - n0 == dict(cls=20, det=44, seg=32)[task], ops.FFN_FUSED.calls - n0
             assert len(ops.HPLANES.entries) > h0
+            if ops.LIN_FUSED.enabled:  # Swin stages 1-2: 4 blocks x (qkv, proj) x (forward + input gradient), PatchMerging's reduction
+                assert ops.LIN_FUSED.calls - l0 >= 16, ops.LIN_FUSED.calls - l0
         check_step_pair(model, out, oout, rec, orec, P)
     finally:
         ops.DEFER.drop()
