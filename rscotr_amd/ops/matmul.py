@@ -843,6 +843,7 @@ class _FusedLinear:
     ranges are on; the 256-wide 10880-row Linears of the encoder stay on the tiled kernel (measured: profiles/r6_ffn_lab.txt)."""
 
     MIN_ROWS = int(os.environ.get('RSCOTR_LIN_FUSED_MIN_ROWS', 8192))
+    MAX_NARROW = int(os.environ.get('RSCOTR_LIN_FUSED_NARROW', 192))  # the smaller of (N, K) at most this
 
     def __init__(self):
         self.enabled = os.environ.get('RSCOTR_LIN_FUSED', '1') != '0'
@@ -854,7 +855,7 @@ class _FusedLinear:
         M = x2.shape[0]
         sink = STATE.grad_sink
         if (not self.enabled or not RANGES.enabled or sink is None or STATE.profile is not None or M < self.MIN_ROWS
-                or min(N, K) > 192 or max(N, K) > 576 or x2.data_ptr() % 16 or not W.is_contiguous()):
+                or min(N, K) > self.MAX_NARROW or max(N, K) > 576 or x2.data_ptr() % 16 or not W.is_contiguous()):
             return False
         return sink.is_param_ptr(W.data_ptr()) and bool(lib.rscotr_lin_h3_ok(M, N, K))
 
