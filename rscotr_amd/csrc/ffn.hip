@@ -579,10 +579,10 @@ struct LinParams {
   unsigned* amax_ln;
 };
 
-template <int C, bool LN>
+template <int C, bool LN, int NT = 2>
 __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
-  constexpr int NT = 2, BM = 16 * NT, STG = BM * FFN_LDRB, KS1 = C / 32;
+  constexpr int BM = 16 * NT, STG = BM * FFN_LDRB, KS1 = C / 32;
   constexpr int DA = KS1 % 2 == 0 ? 2 : KS1 % 3 == 0 ? 3 : 1;  // k steps the weight loads run ahead (DA | KS1: the ring position of a k step is the same in every sweep)
   static_assert(C % 32 == 0 && KS1 % DA == 0, "reduction in whole 32-k steps");
   unsigned char* xs = ffn_lds;  // [KS1][BM][160]
@@ -976,15 +976,15 @@ extern "C" int rscotr_ffn_h3_ln(const float* X, int M, int C, int H, const float
 }
 
 // ---- the one-Linear launch (lin_h3_kernel)
-template <int C, bool LN>
+template <int C, bool LN, int NT = 2>
 static void lin_launch(const LinParams& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)(C / 32) * 32 * FFN_LDRB;
+  constexpr size_t lds = (size_t)(C / 32) * (16 * NT) * FFN_LDRB;
   static bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_h3_kernel<C, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_h3_kernel<C, LN, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((lin_h3_kernel<C, LN>), dim3((unsigned)((p.M + 31) / 32)), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((lin_h3_kernel<C, LN, NT>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT))), dim3(512), lds, s, p);
 }
 
 extern "C" int rscotr_lin_h3_ok(int M, int N, int K) {
@@ -1013,7 +1013,10 @@ static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const
   p.amax_g = ln.amax_g; p.amax_bt = ln.amax_b; p.amax_ln = ln.amax_out;
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, s, "rscotr::lin_h3_kernel<%d, %s>", K, ln.g ? "true" : "false");
-  if (ln.g) {
+  static const int rows64 = getenv("RSCOTR_LIN_ROWS64") ? atoi(getenv("RSCOTR_LIN_ROWS64")) : 0;  // (A/B: 64-row workgroups at K = 96)
+  if (rows64 && K == 96 && M >= 16384) {
+    if (ln.g) lin_launch<96, true, 4>(p, s); else lin_launch<96, false, 4>(p, s);
+  } else if (ln.g) {
     if (K == 96) lin_launch<96, true>(p, s);
     else if (K == 192) lin_launch<192, true>(p, s);
     else lin_launch<384, true>(p, s);
