@@ -256,7 +256,7 @@ int rscotr_gemm_split_weights_frag(const int64_t* table, int n, int total_blocks
  * Everything else as rscotr_ffn_h3 (no bits, no xscale). */
 /* ONE Linear on the fused kernel's machinery for the tall, narrow products of Swin stages 1 / 2 (mmdet WindowMSA's qkv / proj Linears
  * and their input gradients, reached through ShiftWindowMSA.forward of the backbone, cfg :9-25): Y (M, N) = (X Wop^T + bias) *
- * yscale[row / rows_per] + resid, X' = X * xscale[row / rows_per]; X (M, K) row-major fp32, K in {96, 128, 192, 256, 288, 384, 576},
+ * yscale[row / rows_per] + resid, X' = X * xscale[row / rows_per]; X (M, K) row-major fp32, K in {96, 128, 192, 256, 288, 384, 576, 768, 1152 (few rows only)},
  * N % 32 == 0 (rscotr_lin_h3_ok).  Wf: fragment-major fp16 planes of Wop (N rows, reduction K; rscotr_gemm_split_weights_frag).  A
  * workgroup stages the planes of 32 rows once and its eight wavefronts take 32 output columns each — memory-bound shapes, where the
  * tiled kernels re-stage the rows per column tile.  The three-term fp16 split product (rscotr_gemm_f32_r's arithmetic on 16 x 16 x 32

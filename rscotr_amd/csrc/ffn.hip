@@ -572,6 +572,7 @@ struct LinParams {
   int rows_per;
   const unsigned *amax_x, *amax_w;
   unsigned* amax_y;
+  int col_groups;      // grid.y: 1 = sweeps inside the workgroup
   const float *ln_g, *ln_b;  // LN instantiations: see FfnParams
   float ln_eps;
   float *ln_out, *ln_mean, *ln_rstd;
@@ -596,8 +597,10 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
   auto ld_w = [&](int col0, int ks, int it, int pl) {  // fragment of column tile col0 / 16 + it, k step ks, plane pl
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, ((col0 >> 4) + it) * (KS1 * 2048) + ks * 2048 + pl * 1024, 0));
   };
-  // (the first sweep's fragments are requested before the rows: cold lines)
-  const int c_first = wv * 32;
+  // (the first sweep's fragments are requested before the rows: cold lines).  gridDim.y > 1: FEW rows (Swin stages 3 / 4: 2048 / 512) — a
+  // workgroup per (row tile, group of 256 columns) instead of sweeps, every group staging the rows again (from L2)
+  const int c_first = (int)blockIdx.y * 256 + wv * 32;
+  const int c_step = 256 * (int)gridDim.y;
   uint4 ring[4 * DA];
   if (c_first < p.N) {
 #pragma unroll
@@ -636,7 +639,8 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
     static_assert(!LN || (C % 48 == 0 && (C / 12 == 8 || C / 12 == 16 || C / 12 == 32)), "LN rows: 8 / 16 / 32 lanes x 3 float4");
     constexpr int G = C / 12, RPP = 512 / G, NP = (BM + RPP - 1) / RPP;
     const int sb = tid % G, rr = tid / G;
-    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (long)m0 * C, 0, rows_ok * C * 4, 0x00020000);
+    const bool own = blockIdx.y == 0;  // (one column group writes the norm's output and statistics)
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (long)m0 * C, 0, (own ? rows_ok : 0) * C * 4, 0x00020000);
     float amx = 0.f;
     if (RPP <= BM || wv < 8 * BM / RPP) {
       float4 gw[3], gb[3];
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         const float rs = rsqrtf(q * (1.f / (float)C) + p.ln_eps);
-        if (sb == 0 && row < rows_ok) { p.ln_mean[m0 + row] = mu; p.ln_rstd[m0 + row] = rs; }
+        if (sb == 0 && own && row < rows_ok) { p.ln_mean[m0 + row] = mu; p.ln_rstd[m0 + row] = rs; }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           float4 o;
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
         }
       }
     }
-    amax_commit(p.amax_ln, amx);
+    if (own) amax_commit(p.amax_ln, amx);
   }
   const int ew = h3_scale_exp(amax_fold(rw));
   const float inv = __uint_as_float((unsigned)(254 - ex) << 23) * __uint_as_float((unsigned)(254 - ew) << 23);
@@ -695,13 +699,13 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
 
   float amy = 0.f;
 #pragma unroll 1
-  for (int col0 = c_first; col0 < p.N; col0 += 256) {  // (wave-uniform)
+  for (int col0 = c_first; col0 < p.N; col0 += c_step) {  // (wave-uniform)
     f32x4_t ha[2][NT], hb[2][NT];
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int n = 0; n < NT; ++n) { ha[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; hb[it][n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    const int cnext = col0 + 256 < p.N ? col0 + 256 : col0;  // (past the last sweep: a harmless re-read)
+    const int cnext = col0 + c_step < p.N ? col0 + c_step : col0;  // (past the last sweep: a harmless re-read)
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       uint4 xh[NT], xl[NT];
@@ -984,18 +988,18 @@ static void lin_launch(const LinParams& p, hipStream_t s) {
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((lin_h3_kernel<C, LN, NT>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT))), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((lin_h3_kernel<C, LN, NT>), dim3((unsigned)((p.M + 16 * NT - 1) / (16 * NT)), (unsigned)p.col_groups), dim3(512), lds, s, p);
 }
 
 extern "C" int rscotr_lin_h3_ok(int M, int N, int K) {
-  const bool k_ok = K == 96 || K == 128 || K == 192 || K == 256 || K == 288 || K == 384 || K == 576;
+  const bool k_ok = K == 96 || K == 128 || K == 192 || K == 256 || K == 288 || K == 384 || K == 576 || K == 768 || K == 1152;
   return (k_ok && N >= 32 && N % 32 == 0 && M >= 1 && (long)M * N * 4 < (1l << 32) && (long)M * K * 4 < (1l << 32)) ? 1 : 0;
 }
 
 static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const float* bias, const float* resid, float* Y,
                       const float* xscale, const float* yscale, int rows_per, const uint32_t* amax_x, const uint32_t* amax_w,
                       uint32_t* amax_y, const FfnNorm& ln, void* stream) {
-  if (!rscotr_lin_h3_ok(M, N, K)) return fail(RSCOTR_E_SHAPE, "lin_h3: M=%d N=%d K=%d (K in {96, 128, 192, 256, 288, 384, 576}, N %% 32 == 0)", M, N, K);
+  if (!rscotr_lin_h3_ok(M, N, K)) return fail(RSCOTR_E_SHAPE, "lin_h3: M=%d N=%d K=%d (K in {96, 128, 192, 256, 288, 384, 576, 768, 1152}, N %% 32 == 0)", M, N, K);
   if (!X || !Wf || !Y || (!amax_x && !ln.g) || !amax_w) return fail(RSCOTR_E_ARG, "lin_h3: null argument");
   if ((xscale || yscale) && rows_per <= 0) return fail(RSCOTR_E_ARG, "lin_h3: rows_per with a row scale");
   if (((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Y | (uintptr_t)resid | (uintptr_t)bias) & 15)
@@ -1011,6 +1015,9 @@ static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const
   p.amax_x = amax_x; p.amax_w = amax_w; p.amax_y = amax_y;
   p.ln_g = ln.g; p.ln_b = ln.b; p.ln_eps = ln.eps; p.ln_out = ln.out; p.ln_mean = ln.mean; p.ln_rstd = ln.rstd;
   p.amax_g = ln.amax_g; p.amax_bt = ln.amax_b; p.amax_ln = ln.amax_out;
+  // fewer than 200 row tiles: one workgroup per (row tile, 256 columns)
+  p.col_groups = (M + 31) / 32 >= 200 ? 1 : (N + 255) / 256;
+  if (K == 1152 && M >= 8192) return fail(RSCOTR_E_SHAPE, "lin_h3: K = 1152 is a few-row width (M=%d)", M);
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, s, "rscotr::lin_h3_kernel<%d, %s>", K, ln.g ? "true" : "false");
   static const int rows64 = getenv("RSCOTR_LIN_ROWS64") ? atoi(getenv("RSCOTR_LIN_ROWS64")) : 0;  // (A/B: 64-row workgroups at K = 96)
@@ -1027,7 +1034,9 @@ static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const
     case 256: lin_launch<256, false>(p, s); break;
     case 288: lin_launch<288, false>(p, s); break;
     case 384: lin_launch<384, false>(p, s); break;
-    default: lin_launch<576, false>(p, s); break;
+    case 576: lin_launch<576, false>(p, s); break;
+    case 768: lin_launch<768, false>(p, s); break;
+    default: lin_launch<1152, false, 1>(p, s); break;  // (16-row workgroups: 92 KB of planes)
   }
   return check_launch("lin_h3");
 }

@@ -844,18 +844,26 @@ class _FusedLinear:
 
     MIN_ROWS = int(os.environ.get('RSCOTR_LIN_FUSED_MIN_ROWS', 8192))
     MAX_NARROW = int(os.environ.get('RSCOTR_LIN_FUSED_NARROW', 192))  # the smaller of (N, K) at most this
+    FEW_K = tuple(int(k) for k in os.environ.get('RSCOTR_LIN_FUSED_FEW_K', '384,768').split(','))
 
     def __init__(self):
         self.enabled = os.environ.get('RSCOTR_LIN_FUSED', '1') != '0'
         self.ln = os.environ.get('RSCOTR_LIN_FUSED_LN', '1') != '0'
+        self.few = os.environ.get('RSCOTR_LIN_FUSED_FEW', '1') != '0'
         self.calls = 0
         self.ln_calls = 0
 
     def ok(self, x2, W, N, K):
         M = x2.shape[0]
         sink = STATE.grad_sink
-        if (not self.enabled or not RANGES.enabled or sink is None or STATE.profile is not None or M < self.MIN_ROWS
-                or min(N, K) > self.MAX_NARROW or max(N, K) > 576 or x2.data_ptr() % 16 or not W.is_contiguous()):
+        if not self.enabled or not RANGES.enabled or sink is None or STATE.profile is not None or x2.data_ptr() % 16 or not W.is_contiguous():
+            return False
+        tall = M >= self.MIN_ROWS and min(N, K) <= self.MAX_NARROW and max(N, K) <= 576
+        # FEW rows with a wide reduction (Swin stages 3 / 4: 2048 x 384 -> 1152 / 384, 512 x 768 -> 2304 / 768, the neck's 1x1
+        # convolutions on them): one workgroup per (row tile, 256 columns), all of K staged once — 11 us against 17-27 for the tiled
+        # kernels (fp32 pipe at 96-192 workgroups).  The decoders' K = 256 products stay where they are (measured: +1.35 ms per round)
+        few = self.few and 512 <= M < self.MIN_ROWS and K in self.FEW_K and N <= 3 * K
+        if not (tall or few):
             return False
         return sink.is_param_ptr(W.data_ptr()) and bool(lib.rscotr_lin_h3_ok(M, N, K))
 
