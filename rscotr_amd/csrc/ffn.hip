@@ -1035,7 +1035,11 @@ static int lin_h3_run(const float* X, int M, int N, int K, const void* Wf, const
     case 288: lin_launch<288, false>(p, s); break;
     case 384: lin_launch<384, false>(p, s); break;
     case 576: lin_launch<576, false>(p, s); break;
-    case 768: lin_launch<768, false>(p, s); break;
+    case 768: {
+      static const int rows16 = getenv("RSCOTR_LIN_ROWS16") ? atoi(getenv("RSCOTR_LIN_ROWS16")) : 0;  // (A/B: 16-row workgroups for the 512-row launches of Swin stage 4)
+      if (rows16 && M <= 1024) lin_launch<768, false, 1>(p, s); else lin_launch<768, false>(p, s);
+      break;
+    }
     default: lin_launch<1152, false, 1>(p, s); break;  // (16-row workgroups: 92 KB of planes)
   }
   return check_launch("lin_h3");
