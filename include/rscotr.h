@@ -31,7 +31,7 @@ extern "C" {
  * `stream` in the LayerNorm, window-attention, MSDA backward, pack4, splitk_flush and grouped-dW entries = revision 6;
  * round 6 = 7).  rscotr_version() returns the revision the shared object was BUILT with; a binding compares the two before
  * its first call (rscotr_amd/_lib.py does) — a stale .so would take a stream handle for a pointer. */
-#define RSCOTR_ABI_VERSION 9
+#define RSCOTR_ABI_VERSION 10
 int rscotr_version(void);
 const char* rscotr_last_error(void);
 int rscotr_device_count(void);
@@ -177,12 +177,17 @@ int rscotr_gemm_f32(const float* A, const float* B, float* C, int M, int N, int 
  * accumulate.  The two planes carry an element to 2^-24 relative down to 2^-26 of the tensor's amax (2^-48 of amax absolute
  * below): the error class of an fp32 FMA chain, like the six-term bf16 product, at half the MFMA issues and two thirds of
  * the conversion / LDS traffic.  A RANGE WORD is RSCOTR_RANGE_PLANES (32) sub-words at a stride of RSCOTR_RANGE_STRIDE (16384)
- * words — the caller owns one buffer of [32][16384] uint32 and names a word by the address of its sub-word 0; the value is
- * the maximum over the sub-words (producers spread their atomics over them: thousands of same-address atomics from the
- * wavefronts of one product would take longer than the product).  Everything else (tiles, k-slices, epilogue, row sums, k scaling, workspace) is
+ * words — the caller owns one buffer of [32][16384] uint32 and names a word by the address of its sub-word 0 — read as an EXPONENT
+ * MAP of 128 bytes (round 6): byte i != 0 <=> the tensor holds an element whose biased fp32 exponent is RSCOTR_RANGE_EXP_LO + i
+ * (clamped into the window).  Producers mark with plain one-byte stores of the constant 1 (idempotent: no atomics, any order, any
+ * XCD); consumers take the highest byte set: the binade of max |x|, which is all the scale of a split product uses.  A word is
+ * zeroed by the caller before its producers run (one memset per iteration); a parameter's persistent word is rewritten whole by the
+ * optimizer kernels.  Until round 6 the word was the maximum's bit pattern folded by atomicMax (L2 atomics at the tails of ~800
+ * producer launches per co-training round: ~0.3 ms).  Everything else (tiles, k-slices, epilogue, row sums, k scaling, workspace) is
  * rscotr_gemm_f32; null ranges = exactly rscotr_gemm_f32.  rscotr_gemm_set_h3(0 | 1): A/B switch (RSCOTR_GEMM_H3),
- * returns the previous setting.  amax_out (optional): max |C| of the stored result is folded into this word (atomicMax on
- * the bit pattern; the caller zeroes it).  rscotr_amax_f32: slot = max(slot, max |X|) over rows x cols, row stride ld. */
+ * returns the previous setting.  amax_out (optional): the binade of max |C| of the stored result is marked in this word (the
+ * caller zeroes it).  rscotr_amax_f32: marks the binade of max |X| over rows x cols, row stride ld. */
+#define RSCOTR_RANGE_EXP_LO 80
 #define RSCOTR_RANGE_PLANES 32
 #define RSCOTR_RANGE_STRIDE 16384
 int rscotr_gemm_f32_r(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
@@ -627,7 +632,8 @@ int rscotr_adamw_clip_step(float* param, const float* grad, float* exp_avg, floa
                            const float* seg_dyn, int nchunks, const float* sumsq, float max_norm,
                            float beta1, float beta2, float eps, void* stream);
 /* The same step keeping the VALUE RANGES of the parameters (round 5; consumed by rscotr_gemm_f32_r as amax_b of a weight
- * operand): seg_amax[segment] = bit pattern of max |w| over the segment, refreshed for every live segment by the update
+ * operand): seg_amax[segment] = the range word (exponent map, rscotr_gemm_f32_r; all RSCOTR_RANGE_PLANES sub-words of it: seg_amax is
+ * a row of the caller's range buffer) of max |w| over the segment, refreshed for every live segment by the update
  * itself (each chunk's wavefronts store their maxima into the scratch chunk_amax — 4 * nchunks uint32, 16-byte aligned — and
  * a second small launch folds them per segment, found by bisection of the ascending chunk_seg: no atomics, deterministic);
  * other segments keep their word.  chunk_amax is required when seg_amax is given.

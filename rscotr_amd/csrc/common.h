@@ -74,40 +74,58 @@ __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
 // A value-range WORD is kAmaxPlanes sub-words at stride kAmaxStride (the caller's buffer is [kAmaxPlanes][kAmaxStride] words;
-// include/rscotr.h): its value is the maximum of the sub-words.  Producers spread their atomics over the sub-words (a
-// wavefront takes sub-word (4 * workgroup + wavefront) % kAmaxPlanes; the planes are 64 KB apart: different memory channels),
-// consumers read all of them with one load per lane.
+// include/rscotr.h) = 128 BYTES read as an exponent map: byte i != 0 <=> the tensor holds an element whose biased fp32 exponent
+// is kRangeExpLo + i (clamped into the window 2^-47 .. 2^80: a smaller maximum is taken for 2^-47 — an upper bound, and the planes keep full
+// relative precision down to maxima of 2^-73; nothing a training step holds is larger than 2^80).  A producer wavefront commits its maximum with ONE PLAIN BYTE
+// STORE of the constant 1 — idempotent, so any number of wavefronts on any XCD may write the same word with no atomic and no
+// order — and a consumer reads the 32 sub-words with one load per lane and takes the highest byte set.  What the word delivers is
+// the BINADE of max |x| (2^e <= max |x| < 2^(e+1)), which is all the fp16 split product uses (h3_scale_exp reads the exponent field
+// only: the scales are bit for bit the ones the full maximum gave); bounds built from words take the upper end, amax_hi.
+// (Round 6.  Until then a wavefront folded its maximum into sub-word (XCD, wavefront) with an atomicMax on the bit pattern: a few
+// hundred to a few thousand L2 atomics per producer launch on four lines per XCD.  In the step, one box, alternating: 29.20 / 29.30 ms
+// per round with the byte marks, 29.39 / 29.68 with the atomics.  Two timing-only builds had promised 2.1 ms — a plain store of the
+// wavefront's maximum, and a racy load - compare - store — but both leave words that are too SMALL, and a step whose planes overflow
+// runs a different, shorter course through its losses: profiles/r6_range_words.txt.)
 constexpr int kAmaxPlanes = 32;
 constexpr int kAmaxStride = 16384;
+constexpr int kRangeExpLo = 80;  // biased exponent of byte 0
 
-// (lane l holds sub-word l % kAmaxPlanes, loaded by the caller as early as it likes) -> the word's value, wave-uniform
+// byte index (0 .. 127) of a non-zero |x| bit pattern
+__device__ __forceinline__ int range_byte(unsigned bits) {
+  return min(max((int)((bits >> 23) & 0xffu), kRangeExpLo), kRangeExpLo + 4 * kAmaxPlanes - 1) - kRangeExpLo;
+}
+// the plain store that marks byte i of the word at `slot`
+__device__ __forceinline__ void range_mark(unsigned* slot, int i) {
+  reinterpret_cast<unsigned char*>(slot + (long)(i >> 2) * kAmaxStride)[i & 3] = 1;
+}
+
+// (lane l holds sub-word l % kAmaxPlanes, loaded by the caller as early as it likes) -> the bit pattern of 2^e, e = the binade of
+// the tensor's maximum (0 for a word nobody marked: an all-zero tensor); wave-uniform
 __device__ __forceinline__ unsigned amax_fold(unsigned v) {
+  int c = v ? 4 * (int)(threadIdx.x & (kAmaxPlanes - 1)) + ((31 - __clz((int)v)) >> 3) + 1 : 0;  // byte index + 1
 #pragma unroll
-  for (int o = kAmaxPlanes / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  for (int o = kAmaxPlanes / 2; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o, 64));
+  c = __builtin_amdgcn_readfirstlane(c);
+  return c ? (unsigned)(kRangeExpLo + c - 1) << 23 : 0u;
 }
 __device__ __forceinline__ unsigned amax_read(const unsigned* word) {
   return amax_fold(word[(long)(threadIdx.x & (kAmaxPlanes - 1)) * kAmaxStride]);
 }
+// upper end of the binade amax_fold returned: max |x| < amax_hi (for bounds computed from words)
+__device__ __forceinline__ float amax_hi(unsigned folded) { return folded ? __uint_as_float(folded + (1u << 23)) : 0.f; }
 
-// Same-address atomics execute one after the other at the memory side (~10 ns each: thousands of wavefronts finishing
-// together would cost more than a short product itself), so a wavefront first LOOKS at the word (a plain, possibly stale
-// read: staleness only costs an atomic that changes nothing) and stays silent unless it raises it — operands of one
-// tensor are of one magnitude, the first few finishers settle the word.
+// End of a kernel: the wavefront's maximum marks its byte.  Every lane of the wavefront must reach this call.
 __device__ __forceinline__ void amax_commit(unsigned* slot, float amx) {
   if (!slot) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
   if ((threadIdx.x & 63) == 0) {
-    const unsigned b = __float_as_uint(amx);
-#ifdef RSCOTR_AMAX_BY_BLOCK
-    unsigned* sub = slot + (long)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxPlanes - 1)) * kAmaxStride;
+    const unsigned b = __float_as_uint(amx) & 0x7fffffffu;
+#ifdef RSCOTR_RANGE_UNDER  // (experiment, profiles/r6_range_words.txt: words RSCOTR_RANGE_UNDER binades too small — what a lost maximum does to a step)
+    if (b) range_mark(slot, max(range_byte(b) - RSCOTR_RANGE_UNDER, 0));
 #else
-    // sub-word by (XCD, wavefront of the workgroup): a line is only ever touched by the atomics of ONE XCD's L2
-    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
-    unsigned* sub = slot + (long)(((xcc & 7) * 4 + ((threadIdx.x >> 6) & 3)) & (kAmaxPlanes - 1)) * kAmaxStride;
+    if (b) range_mark(slot, range_byte(b));
 #endif
-    if (b) atomicMax(sub, b);  // (fire and forget: nothing waits for the result; a look at the word first would put a second memory round trip at the end of every wavefront)
   }
 }
 

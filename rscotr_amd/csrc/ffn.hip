@@ -204,7 +204,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   // the rows' planes -> LDS (all eight wavefronts).  LN: |LayerNorm(x)| <= sqrt(C) max|gamma| + max|beta| — a normalised row has
   // no entry above sqrt(C - 1) — is the range the planes are scaled with (the row maxima are only known afterwards; a loose bound
   // costs nothing above 2^-26 of it, see the header)
-  const unsigned ux = LN ? __float_as_uint(sqrtf((float)C) * __uint_as_float(amax_fold(rg)) + __uint_as_float(amax_fold(rbt))) : amax_fold(rx);
+  // (words deliver binades, common.h: amax_fold = 2^e <= max, amax_hi its upper end; a scale taken from a word uses e, a bound the upper end)
+  const unsigned fx = LN ? 0u : amax_fold(rx);
+  const float xbound = LN ? sqrtf((float)C) * amax_hi(amax_fold(rg)) + amax_hi(amax_fold(rbt)) : amax_hi(fx);  // max |staged row entry| <= xbound
+  const unsigned ux = LN ? __float_as_uint(xbound) : fx;
   if constexpr (!LN) {
     constexpr int TOT = BM * (C / 4), NV = (TOT + 511) / 512;
     float4 v[NV];
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 96 ? F
   const int ex = h3_scale_exp(ux), e1 = h3_scale_exp(u1), e2 = h3_scale_exp(u2);
   // |hidden| <= C max|x| max|W1| + max|b1|: relu / a gate only shrink it, |gelu(t)| <= |t|, |gelu'| < 1.13 (hence the 1.25); a
   // DropPath factor on the rows of x (<= 2 for keep >= 0.5) rides in the scale's 8 x headroom
-  const float bound = ((float)C * __uint_as_float(ux) * __uint_as_float(u1) + __uint_as_float(ub)) * (GGRAD ? 1.25f : 1.f);
+  const float bound = ((float)C * xbound * amax_hi(u1) + amax_hi(ub)) * (GGRAD ? 1.25f : 1.f);
   const int eh = h3_scale_exp(__float_as_uint(bound));
   const H3Scale hh{__uint_as_float((unsigned)eh << 23), __uint_as_float((unsigned)(eh + 11) << 23)};
   const float invx = __uint_as_float((unsigned)(254 - ex) << 23), inv1 = __uint_as_float((unsigned)(254 - e1) << 23);
@@ -610,7 +613,10 @@ __global__ __launch_bounds__(512) void lin_h3_kernel(LinParams p) {
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)m0 * C), 0, rows_ok * C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)m0 * p.N, 0, rows_ok * p.N * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + (long)m0 * p.N : p.X), 0, rows_ok * p.N * 4, 0x00020000);
-  const unsigned ux = LN ? __float_as_uint(sqrtf((float)C) * __uint_as_float(amax_fold(rg)) + __uint_as_float(amax_fold(rbt))) : amax_fold(rx);
+  // (words deliver binades, common.h: amax_fold = 2^e <= max, amax_hi its upper end; a scale taken from a word uses e, a bound the upper end)
+  const unsigned fx = LN ? 0u : amax_fold(rx);
+  const float xbound = LN ? sqrtf((float)C) * amax_hi(amax_fold(rg)) + amax_hi(amax_fold(rbt)) : amax_hi(fx);  // max |staged row entry| <= xbound
+  const unsigned ux = LN ? __float_as_uint(xbound) : fx;
   const int ex = h3_scale_exp(ux);
   const H3Scale hx{__uint_as_float((unsigned)ex << 23), __uint_as_float((unsigned)(ex + 11) << 23)};
   if constexpr (!LN) {

@@ -2725,8 +2725,8 @@ extern "C" int rscotr_colsum_f32(const float* X, float* out, int M, int N, int l
 // ---------------------------------------------------------------------------------------------------------------
 // Value range of a tensor for the fp16 split product: slot = max(slot, bit pattern of max |X[r, c]|) over rows x cols with
 // row stride ld (slot = a range word of kAmaxPlanes sub-words, gemm_common.h).  The caller zeroes the slot (one memset for all slots of an iteration); the maximum is taken per lane,
-// per wavefront (shuffles), per workgroup (LDS) and then with ONE atomicMax on the bit pattern per workgroup — a maximum
-// does not depend on the order, so the result is deterministic.  NaNs compare above every finite pattern.
+// per wavefront (shuffles), per workgroup (LDS), and the workgroup marks the byte of its binade in the word (common.h: an idempotent plain
+// store — no atomics, deterministic).  NaNs compare above every finite pattern.
 namespace rscotr {
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, long rows, int cols, int ld, int vec,
                                                    unsigned* __restrict__ slot) {
@@ -2755,7 +2755,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-    if (m) atomicMax(slot + (long)(blockIdx.x & (kAmaxPlanes - 1)) * kAmaxStride, m);
+    if (m) range_mark(slot, range_byte(m));  // (a plain byte store: common.h)
   }
 }
 }  // namespace rscotr
@@ -2800,7 +2800,7 @@ __global__ __launch_bounds__(256) void amax_group_kernel(const int64_t* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-    if (m) atomicMax(slot + (long)(blockIdx.x & (kAmaxPlanes - 1)) * kAmaxStride, m);
+    if (m) range_mark(slot, range_byte(m));  // (a plain byte store: common.h)
   }
 }
 }  // namespace rscotr

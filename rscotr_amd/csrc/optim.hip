@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void seg_amax_reduce_kernel(const int32_t* __r
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-  if (lane == 0) seg_amax[sgm] = m;
+  // the parameter's word in the exponent-map form of common.h: persistent, so all 32 sub-words are rewritten (one lane each)
+  if (lane < kAmaxPlanes) {
+    const int i = m ? range_byte(m) : -1;
+    seg_amax[sgm + (long)lane * kAmaxStride] = (i >= 0 && (i >> 2) == lane) ? (1u << (8 * (i & 3))) : 0u;
+  }
 }
 
 __device__ __forceinline__ void chunk_amax_store(unsigned* __restrict__ chunk_amax, int c, float amx) {

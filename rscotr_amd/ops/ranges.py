@@ -189,14 +189,32 @@ class _Ranges:
         torch.cuda.current_stream().synchronize()
         idx = (slot - self.base) // 4
         assert 0 <= idx < self.STRIDE and self.buf is not None, 'a range word outside the range buffer'
-        bound = max(int(v) & 0xffffffff for v in self.buf[:, idx].tolist())
-        actual = max(int(v) & 0xffffffff for v in probe.view(-1)[::self.STRIDE].tolist())
+        bound = self.decode(self.buf[:, idx])
+        actual = self.decode(probe[:, 0])
         self.stats['checked'] = self.stats.get('checked', 0) + 1
-        if actual > bound:
-            import struct
-            f = lambda u: struct.unpack('f', struct.pack('I', u))[0]
-            raise AssertionError(f'stale value range ({what}): the tensor of shape {tuple(t.shape)} holds max |x| = {f(actual)} '
-                                 f'but its slot says {f(bound)}')
+        if actual[0] > bound[0]:
+            raise AssertionError(f'stale value range ({what}): the tensor of shape {tuple(t.shape)} holds max |x| in '
+                                 f'[{actual[0]}, {actual[1]}) but its slot says [{bound[0]}, {bound[1]})')
+
+    EXP_LO = 80  # kRangeExpLo of csrc/common.h
+
+    @classmethod
+    def decode(cls, subwords):
+        """The 32 sub-words of a range word (int32 tensor / sequence) -> (lo, hi): 2^e <= max |x| < 2^(e + 1) as floats, (0.0, 0.0) for a word
+        nobody marked.  A word is an exponent map (csrc/common.h): byte i of its 128 bytes is set when an element of the tensor has the
+        biased fp32 exponent EXP_LO + i."""
+        top = -1
+        for p, v in enumerate(int(x) & 0xffffffff for x in (subwords.tolist() if hasattr(subwords, 'tolist') else subwords)):
+            if v:
+                top = max(top, 4 * p + (v.bit_length() - 1) // 8)
+        if top < 0:
+            return 0.0, 0.0
+        e = cls.EXP_LO + top - 127
+        return 2.0 ** e, 2.0 ** (e + 1)
+
+    def word(self, slot):
+        """(lo, hi) of the word at device address `slot` (synchronises; tests and debugging)."""
+        return self.decode(self.buf[:, self.index(slot)])
 
     # ---- routing
     def wanted(self, M, N, K, lda, ldb, a_kmajor, b_kmajor, act, has_pre, has_rowscale, has_kscale, nws):

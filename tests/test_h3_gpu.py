@@ -14,9 +14,23 @@ def _rel(a, ref):
     return float((a.detach().cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-30))
 
 
+class _Binade:
+    """What a range word says about a tensor's maximum: its binade [lo, hi) (csrc/common.h: the word is an exponent map).  Compares equal
+    to the maxima that lie in it, so `_word(ops, slot) == float(t.abs().max())` reads as before."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def __eq__(self, m):
+        return (self.lo <= m < self.hi) or (m == 0.0 and self.hi == 0.0)
+
+    def __repr__(self):
+        return f'[{self.lo}, {self.hi})'
+
+
 def _word(ops, slot):
-    """value of a range word (the maximum over its sub-words) as a float"""
-    return float(ops.RANGES.buf[:, ops.RANGES.index(slot)].view(torch.float32).max())
+    """binade of a range word"""
+    return _Binade(*ops.RANGES.word(slot))
 
 
 @contextlib.contextmanager
