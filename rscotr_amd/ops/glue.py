@@ -244,7 +244,7 @@ def conv3x3s2_tokens(x, hw, w):
 def map_to_tokens(x):
     """(B, C, H, W) -> (B, H*W, C); free for the channels-last views tokens_to_map returns."""
     B, C, H, W = x.shape
-    return x.permute(0, 2, 3, 1).reshape(B, H * W, C), (H, W)
+    return RANGES.carry(x, x.permute(0, 2, 3, 1).reshape(B, H * W, C)), (H, W)  # (the same values: the range word travels along)
 
 
 def residual_droppath(x, y, keep, rate):
@@ -285,7 +285,7 @@ def tokens_to_map(x, hw):
     """(B, H*W, C) -> (B, C, H, W) as a channels-last VIEW (no copy): every consumer either flattens it
     back to tokens (free) or reduces over H, W."""
     B, L, C = x.shape
-    return x.view(B, hw[0], hw[1], C).permute(0, 3, 1, 2)
+    return RANGES.carry(x, x.view(B, hw[0], hw[1], C).permute(0, 3, 1, 2))
 
 
 class _GapTokens(Function):
